@@ -1,0 +1,72 @@
+"""Build-container-only check: oracle (oracle/avec_oracle.py) vs the reference itself at FULL
+dimensions (61.7 M-param AV model), forward + losses + gradients, train-mode BatchNorm,
+dropout p=0, SpecAugment off.  Needs /root/reference; not collected by pytest."""
+import sys, os, time
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import torch
+import ref_shims
+from oracle import avec_oracle as O
+
+
+def main(B=2):
+    nnet = ref_shims.import_reference()
+    torch.manual_seed(0)
+    model = nnet.AudioVisualEfficientConformerInterCTC()
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False),
+                  loss_weights=dict(O.AV_LOSS_WEIGHTS))
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    torch.manual_seed(1)
+    video = torch.randn(B, 100, 88, 88, 1)
+    audio = 0.1 * torch.randn(B, 63840)
+    vlen = torch.tensor([100, 63][:B])
+    alen = torch.tensor([63840, 40000][:B])
+    labels = torch.randint(1, 256, (B, 20))
+    llen = torch.tensor([20, 13][:B])
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    t = time.time()
+    losses, _, _, _ = model.forward_model([video, vlen, audio, alen], (labels, llen), compute_metrics=False)
+    losses["loss"].backward()
+    print("reference fwd+bwd %.2fs" % (time.time() - t))
+    ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and ("running" not in k)) for k, v in sd0.items()}
+    stats = {}
+    t = time.time()
+    out = O.av_forward(sd, video, vlen, audio, alen, train=True, stats_out=stats)
+    ls = O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)
+    ls["loss"].backward()
+    print("oracle fwd+bwd %.2fs" % (time.time() - t))
+    ok = True
+    for k in losses:
+        a, b = float(losses[k]), float(ls[k])
+        rel = abs(a - b) / max(abs(a), 1e-12)
+        print(f"{k:16s} ref {a:.6f} oracle {b:.6f} rel {rel:.2e}")
+        ok &= rel < 1e-5
+    ls2 = O.total_loss({k: [v[0].detach(), v[1]] for k, v in out.items()}, labels, llen, O.AV_LOSS_WEIGHTS, use_aten=False)
+    print("own-CTC loss", float(ls2["loss"]), "aten", float(ls["loss"]))
+    ok &= abs(float(ls2["loss"]) - float(ls["loss"])) < 1e-4 * abs(float(ls["loss"]))
+    worst = 0.0
+    for k, g in ref_grads.items():
+        go = sd[k].grad
+        err = (g - go).abs().max().item() / (g.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+    print("worst relative grad error (max-norm) over %d tensors: %.2e" % (len(ref_grads), worst))
+    ok &= worst < 1e-3
+    new_sd = model.state_dict()
+    w = 0.0
+    for k, v in stats.items():
+        w = max(w, (new_sd[k].float() - v.float()).abs().max().item())
+    print("BN running-stat max abs diff: %.2e over %d entries" % (w, len(stats)))
+    ok &= w < 1e-4
+    print("ORACLE FULL-SIZE CHECK:", "PASS" if ok else "FAIL")
+    return ok
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() else 1)

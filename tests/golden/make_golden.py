@@ -1,0 +1,260 @@
+"""Generate the committed golden vectors by running THE REFERENCE (/root/reference, imported via
+ref_shims) in the build container.  Output: tests/golden/*.npz + *.json (data only: inputs,
+weights at reduced dims, expected outputs).  Re-run:  python tests/golden/make_golden.py
+"""
+import json, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import numpy as np
+import torch
+import ref_shims
+
+nnet = ref_shims.import_reference()
+torch.set_num_threads(4)
+
+
+def nodrop(m):
+    for x in m.modules():
+        if isinstance(x, torch.nn.Dropout):
+            x.p = 0.0
+    return m
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                out[f"{k}/{kk}"] = vv.detach().cpu().numpy() if torch.is_tensor(vv) else np.asarray(vv)
+        else:
+            out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, sum(a.nbytes for a in out.values()) // 1024, "KiB")
+
+
+def grads_of(module):
+    return {k: p.grad.clone() for k, p in module.named_parameters()}
+
+
+ATT = lambda cls, **kw: {"class": cls, "params": dict(num_heads=4, attn_drop_rate=0.0, num_pos_embeddings=64,
+                                                      weight_init="default", bias_init="default", **kw)}
+CONV = {"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}
+
+
+def conformer_block_case(name, D, De, T, stride, patch, lens, seed):
+    torch.manual_seed(seed)
+    att = ATT("RelPosPatch1dMultiHeadAttention", patch_size=patch) if patch > 1 else ATT("RelPos1dMultiHeadAttention")
+    blk = nodrop(nnet.ConformerBlock(dim_model=D, dim_expand=De, ff_ratio=4, att_params=att, drop_rate=0.1,
+                                     conv_stride=stride, conv_params=CONV)).train()
+    # make BN / LN affine non-trivial
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    B = len(lens)
+    x = torch.randn(B, T, D, requires_grad=True)
+    lengths = torch.tensor(lens)
+    mask = nnet.Mask()(x, lengths)
+    y = blk(x, mask=mask)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save(name, x=x, lengths=lengths, mask=mask, y=y, w=w, dx=x.grad, sd=sd0, grads=grads_of(blk),
+         sd_after=blk.state_dict(), meta=np.array([D, De, T, stride, patch, 4]))
+
+
+def interctc_stack_case():
+    torch.manual_seed(7)
+    net = nodrop(nnet.ConformerInterCTC(dim_model=[32, 48], num_blocks=[2, 1], interctc_blocks=[1, 2], vocab_size=16,
+                                        loss_prefix="x_ctc", att_params=[ATT("RelPosPatch1dMultiHeadAttention", patch_size=3),
+                                                                          ATT("RelPos1dMultiHeadAttention")],
+                                        conv_params=CONV, ff_ratio=4, drop_rate=0.1, mask=nnet.Mask(), conv_stride=2)).train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(3, 23, 32)
+    lengths = torch.tensor([23, 17, 5])
+    y, ylen, inter = net(x, lengths)
+    flat = {}
+    for k, (lg, ln) in inter.items():
+        flat[k + ".logits"] = lg
+        flat[k + ".len"] = ln
+    save("interctc_stack", x=x, lengths=lengths, y=y, ylen=ylen, inter=flat, sd=sd0)
+
+
+def resnet_block_case(name, cin, cout, stride, seed):
+    torch.manual_seed(seed)
+    blk = nnet.ResNetBlock(in_features=cin, out_features=cout, kernel_size=(3, 3), stride=(stride, stride),
+                           act_fun="ReLU", joined_post_act=True).train()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(5, cin, 11, 11, requires_grad=True)
+    y = blk(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save(name, x=x, y=y, w=w, dx=x.grad, sd=sd0, grads=grads_of(blk), sd_after=blk.state_dict(),
+         meta=np.array([cin, cout, stride]))
+
+
+def visual_stem_case():
+    torch.manual_seed(11)
+    stem = torch.nn.Sequential(
+        nnet.ConvNeuralNetwork(dim_input=1, dim_layers=64, kernel_size=(5, 7, 7), strides=(1, 2, 2), norm="BatchNorm3d",
+                               act_fun="ReLU", drop_rate=0.0, dim=3),
+        nnet.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding="same")).train()
+    sd0 = {k: v.clone() for k, v in stem.state_dict().items()}
+    x = torch.randn(2, 1, 6, 24, 24)
+    y = stem(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save("visual_stem", x=x, y=y, w=w, sd=sd0, grads=grads_of(stem), sd_after=stem.state_dict())
+
+
+def audio_stem_case():
+    torch.manual_seed(12)
+    cnn = nnet.ConvNeuralNetwork(dim_input=1, dim_layers=180, kernel_size=3, strides=2, norm="BatchNorm2d", act_fun="Swish",
+                                 drop_rate=0.0, dim=2).train()
+    sd0 = {k: v.clone() for k, v in cnn.state_dict().items()}
+    x = torch.randn(2, 1, 80, 37)
+    lengths = torch.tensor([37, 20])
+    y, ylen = cnn(x, lengths)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save("audio_stem", x=x, lengths=lengths, y=y, ylen=ylen, w=w, sd=sd0, grads=grads_of(cnn))
+
+
+def mel_case():
+    torch.manual_seed(13)
+    ap = nnet.AudioPreprocessing(16000, 512, 25, 10, 80, False, -5.6501, 4.2280)
+    x = 0.1 * torch.randn(3, 4000)
+    lengths = torch.tensor([4000, 3999, 1600])
+    y, ylen = ap(x, lengths)
+    save("mel_frontend", x=x, lengths=lengths, y=y, ylen=ylen)
+
+
+def ctc_case():
+    torch.manual_seed(14)
+    loss = nnet.CTCLoss(zero_infinity=True, assert_shorter=False)
+    B, T, V = 5, 14, 9
+    logits = torch.randn(B, T, V, requires_grad=True)
+    logit_len = torch.tensor([14, 10, 14, 3, 7])
+    y = torch.randint(1, V, (B, 6))
+    y[2, 1] = y[2, 0]  # repeated label
+    y_len = torch.tensor([6, 4, 5, 6, 0])  # sample 3 infeasible (6 labels, 3 frames); sample 4 empty target
+    l = loss((y, y_len), (logits, logit_len))
+    l.backward()
+    per = torch.nn.functional.ctc_loss(torch.log_softmax(logits, -1).transpose(0, 1), y, logit_len, y_len, blank=0,
+                                       reduction="none", zero_infinity=True)
+    save("ctc_loss", logits=logits, logit_len=logit_len, y=y, y_len=y_len, loss=l, per_utt=per, dlogits=logits.grad)
+
+
+def small_modules_case():
+    torch.manual_seed(15)
+    ic = nnet.InterCTCResModule(dim_model=24, vocab_size=10)
+    fu = nnet.FusionModule(a_dim_model=12, v_dim_model=12, f_dim_model=12)
+    x = torch.randn(2, 5, 24)
+    y, lg = ic(x)
+    a, v = torch.randn(2, 5, 12), torch.randn(2, 5, 12)
+    f = fu(a, v)
+    save("small_modules", x=x, ic_y=y, ic_logits=lg, a=a, v=v, fu_y=f, ic_sd=ic.state_dict(), fu_sd=fu.state_dict())
+
+
+def int_cases():
+    out = {}
+    alen = torch.tensor([16000, 63840, 240000, 40000, 12000, 1, 159, 160, 161, 640, 1279, 1280])
+    l0 = torch.div(alen, 160, rounding_mode="floor") + 1
+    chain = [l0]
+    for _ in range(3):
+        chain.append(torch.div(chain[-1] - 1, 2, rounding_mode="floor") + 1)
+    out["audio_len"] = alen.tolist()
+    out["length_chain"] = [c.tolist() for c in chain]
+    x = torch.zeros(3, 8, 4)
+    m = nnet.Mask()(x, torch.tensor([8, 5, 1]))
+    out["mask_T8"] = m.tolist()
+    att = nnet.RelPosPatch1dMultiHeadAttention(dim_model=4, num_heads=1, patch_size=3, num_pos_embeddings=16, attn_drop_rate=0.0)
+    Q, K, V, mp, padding = att.pad(x, x, x, m, chunk_size=3)
+    mp = mp.squeeze(1)
+    mp = -att.mask_pool(-mp).transpose(1, 2)
+    mp = -att.mask_pool(-mp).transpose(1, 2).unsqueeze(1)
+    out["patch_mask_T8_P3"] = mp.tolist()
+    out["patch_padding"] = int(padding)
+    sch = nnet.NoamDecayScheduler(warmup_steps=10000, dim_decay=360, val_factor=2)
+    out["noam_lr"] = {str(s): float(sch.get_val_step(s)) for s in [1, 2, 100, 9999, 10000, 10001, 50000]}
+    json.dump(out, open(os.path.join(HERE, "int_cases.json"), "w"))
+    print("wrote int_cases.json")
+
+
+def adam_case():
+    torch.manual_seed(16)
+    p = torch.nn.Parameter(torch.randn(7, 5))
+    opt = nnet.Adam(params=[p], lr=nnet.NoamDecayScheduler(10000, 360, 2), betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    p0 = p.detach().clone()
+    gs, ps = [], []
+    for _ in range(3):
+        g = torch.randn(7, 5)
+        p.grad = g.clone()
+        opt.step()
+        gs.append(g)
+        ps.append(p.detach().clone())
+    save("adam_steps", p0=p0, g=torch.stack(gs), p=torch.stack(ps))
+
+
+def full_model_case():
+    torch.manual_seed(0)
+    model = nnet.AudioVisualEfficientConformerInterCTC()
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False),
+                  loss_weights={"v_ctc_2": 0.5 / 3, "v_ctc_5": 0.5 / 3, "a_ctc_7": 0.5 / 3, "a_ctc_10": 0.5 / 3,
+                                "f_ctc_1": 0.5 / 3, "outputs": 0.5})
+    nodrop(model).train()
+    sd = model.state_dict()
+    info = {"state_dict": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()],
+            "param_names": [k for k, _ in model.named_parameters()],
+            "n_params": sum(p.numel() for p in model.parameters()),
+            "param_checksums": {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()
+                                if v.is_floating_point()}}
+    torch.manual_seed(1)
+    B = 2
+    video = torch.randn(B, 100, 88, 88, 1)
+    audio = 0.1 * torch.randn(B, 63840)
+    vlen, alen = torch.tensor([100, 63]), torch.tensor([63840, 40000])
+    labels = torch.randint(1, 256, (B, 20))
+    llen = torch.tensor([20, 13])
+    outputs = model([video, vlen, audio, alen])
+    losses, _, _, _ = model.forward_model([video, vlen, audio, alen], (labels, llen), compute_metrics=False)
+    info["losses"] = {k: float(v) for k, v in losses.items()}
+    info["output_lengths"] = {k: v[1].tolist() for k, v in outputs.items()}
+    info["output_shapes"] = {k: list(v[0].shape) for k, v in outputs.items()}
+    info["logits_head"] = {k: v[0][0, :2, :6].tolist() for k, v in outputs.items()}
+    info["input_seed"] = 1
+    info["labels"] = labels.tolist()
+    json.dump(info, open(os.path.join(HERE, "av_full_seed0.json"), "w"))
+    print("wrote av_full_seed0.json")
+    # AO model, BASELINE config 1 (B=2, 1 s audio)
+    torch.manual_seed(0)
+    ao = nodrop(nnet.AudioEfficientConformerInterCTC(vocab_size=256, att_type="patch", interctc_blocks=[])).eval()
+    torch.manual_seed(2)
+    a = 0.1 * torch.randn(2, 16000)
+    o = ao([a, torch.tensor([16000, 12000])])
+    ao_info = {"n_params": sum(p.numel() for p in ao.parameters()), "shape": list(o["outputs"][0].shape),
+               "lengths": o["outputs"][1].tolist(), "logits_head": o["outputs"][0][0, :2, :6].tolist()}
+    json.dump(ao_info, open(os.path.join(HERE, "ao_cfg1_seed0.json"), "w"))
+    print("wrote ao_cfg1_seed0.json")
+
+
+if __name__ == "__main__":
+    conformer_block_case("block_relpos", 32, 32, 20, 1, 1, [20, 13, 7], 1)
+    conformer_block_case("block_patch", 32, 32, 20, 1, 3, [20, 16, 4], 2)
+    conformer_block_case("block_strided_patch", 32, 48, 21, 2, 3, [21, 10], 3)
+    conformer_block_case("block_strided_relpos", 40, 64, 16, 2, 1, [16, 9], 4)
+    interctc_stack_case()
+    resnet_block_case("resnet_block_s1", 8, 8, 1, 5)
+    resnet_block_case("resnet_block_s2", 8, 16, 2, 6)
+    visual_stem_case()
+    audio_stem_case()
+    mel_case()
+    ctc_case()
+    small_modules_case()
+    int_cases()
+    adam_case()
+    full_model_case()

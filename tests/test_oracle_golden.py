@@ -1,0 +1,178 @@
+"""CPU: the oracle (oracle/avec_oracle.py) replayed against golden vectors produced by the REFERENCE
+(tests/golden/make_golden.py).  Tolerance: logits/outputs 1e-5 rel (fp32 CPU both sides), index
+work bit-exact."""
+import math
+
+import pytest
+import torch
+
+from oracle import avec_oracle as O
+from tests.helpers import load_json, load_npz, prefixed, rel_err
+
+TOL = 2e-5
+STRUCT_ZERO = ("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias")
+
+
+def _grad_sd(sd):
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("name", ["block_relpos", "block_patch", "block_strided_patch", "block_strided_relpos"])
+def test_conformer_block(name):
+    g = load_npz(name)
+    D, De, T, stride, patch, H = [int(v) for v in g["meta"]]
+    sd = _grad_sd(prefixed(g["sd"]))
+    x = g["x"].clone().requires_grad_(True)
+    stats = {}
+    y, s = O.conformer_block(sd, "m", x, g["mask"], H, patch, True, stats)
+    assert s == stride
+    assert rel_err(y, g["y"]) < TOL
+    (y * g["w"]).sum().backward()
+    assert rel_err(x.grad, g["dx"]) < 1e-4
+    for k, gr in g["grads"].items():
+        if k.endswith(STRUCT_ZERO):  # analytically zero (softmax shift invariance / bias before BN)
+            assert sd["m." + k].grad.abs().max() < 1e-4 and gr.abs().max() < 1e-4
+            continue
+        assert rel_err(sd["m." + k].grad, gr) < 2e-4, k
+    for k, v in stats.items():
+        assert torch.allclose(v.float(), g["sd_after"][k[2:]].float(), atol=1e-5), k
+    # the mask the oracle builds from lengths is the reference's Mask() bit for bit
+    assert torch.equal(O.key_padding_mask(T, g["lengths"]), g["mask"])
+
+
+def test_interctc_stack():
+    g = load_npz("interctc_stack")
+    sd = prefixed(g["sd"])
+    y, ylen, inter = O.conformer_interctc(sd, "m", g["x"], g["lengths"], [2, 1], [1, 2], "x_ctc", [3, 1], True, {})
+    assert rel_err(y, g["y"]) < TOL
+    assert torch.equal(ylen, g["ylen"])
+    keys = sorted(k[:-7] for k in g["inter"] if k.endswith(".logits"))
+    assert sorted(inter) == keys
+    for k in keys:
+        assert rel_err(inter[k][0], g["inter"][k + ".logits"]) < TOL
+        assert torch.equal(inter[k][1], g["inter"][k + ".len"])
+
+
+@pytest.mark.parametrize("name", ["resnet_block_s1", "resnet_block_s2"])
+def test_resnet_block(name):
+    g = load_npz(name)
+    stride = int(g["meta"][2])
+    sd = _grad_sd(prefixed(g["sd"]))
+    x = g["x"].clone().requires_grad_(True)
+    stats = {}
+    y = O.resnet_block(sd, "m", x, stride, True, stats)
+    assert rel_err(y, g["y"]) < TOL
+    (y * g["w"]).sum().backward()
+    assert rel_err(x.grad, g["dx"]) < 1e-4
+    for k, gr in g["grads"].items():
+        assert rel_err(sd["m." + k].grad, gr) < 2e-4, k
+    for k, v in stats.items():
+        assert torch.allclose(v.float(), g["sd_after"][k[2:]].float(), atol=1e-5), k
+
+
+def test_visual_stem():
+    g = load_npz("visual_stem")
+    # oracle.visual_frontend runs stem + ResNet; check the stem part through its building blocks
+    sd = _grad_sd(prefixed(g["sd"]))
+    import torch.nn.functional as F
+    x = F.pad(g["x"], (3, 3, 3, 3, 2, 2))
+    x = F.conv3d(x, sd["m.0.layers.0.0.weight"], sd["m.0.layers.0.0.bias"], stride=(1, 2, 2))
+    x = F.relu(O.batch_norm(sd, "m.0.layers.0.1", x, True, {}))
+    y = F.max_pool3d(F.pad(x, (1, 1, 1, 1, 0, 0)), (1, 3, 3), (1, 2, 2))
+    assert rel_err(y, g["y"]) < TOL
+    (y * g["w"]).sum().backward()
+    for k, gr in g["grads"].items():
+        if gr.abs().max() < 1e-4:
+            continue
+        assert rel_err(sd["m." + k].grad, gr) < 5e-4, k
+
+
+def test_audio_stem():
+    g = load_npz("audio_stem")
+    sd = {"m.subsampling_module." + k: v for k, v in g["sd"].items()}
+    sd["m.linear.weight"] = torch.eye(7200)[:4]
+    sd["m.linear.bias"] = torch.zeros(4)
+    # reference ConvNeuralNetwork output is (B,180,40,T'); compare through the reshape used by the encoder
+    y, ylen = O.audio_stem(sd, "m", g["x"][:, 0], g["lengths"], True, {})
+    ref = g["y"].reshape(2, 7200, -1).transpose(1, 2)[..., :4]
+    assert rel_err(y, ref) < TOL
+    assert torch.equal(ylen, g["ylen"])
+
+
+def test_mel_frontend():
+    g = load_npz("mel_frontend")
+    y, ylen = O.mel_frontend(g["x"], g["lengths"])
+    assert torch.equal(ylen, g["ylen"])
+    # log-mel: compare in the log domain with an absolute tolerance (values span [-20, 5])
+    assert (y - g["y"]).abs().max() < 2e-3
+    assert rel_err(y.exp(), g["y"].exp()) < 1e-4
+
+
+def test_ctc_loss():
+    g = load_npz("ctc_loss")
+    per = O.ctc_nll(g["logits"], g["logit_len"], g["y"], g["y_len"])
+    assert torch.allclose(per, g["per_utt"], rtol=1e-5, atol=1e-5)
+    assert per[3] == 0.0  # infeasible alignment -> zero_infinity
+    assert abs(per.mean().item() - g["loss"].item()) < 1e-5
+    out = {"outputs": [g["logits"], g["logit_len"]]}
+    l = O.total_loss(out, g["y"], g["y_len"], {"outputs": 1.0})["loss"]
+    assert abs(l.item() - g["loss"].item()) < 1e-5
+
+
+def test_small_modules():
+    g = load_npz("small_modules")
+    sd = prefixed(g["ic_sd"])
+    lg = O.linear(sd, "m.proj_1", g["x"])
+    y = g["x"] + O.linear(sd, "m.proj_2", lg.softmax(-1))
+    assert rel_err(lg, g["ic_logits"]) < TOL and rel_err(y, g["ic_y"]) < TOL
+    sd = prefixed(g["fu_sd"])
+    f = O.linear(sd, "m.layers.2", O.swish(O.linear(sd, "m.layers.0", torch.cat([g["a"], g["v"]], -1))))
+    assert rel_err(f, g["fu_y"]) < TOL
+
+
+def test_int_cases():
+    j = load_json("int_cases")
+    alen = torch.tensor(j["audio_len"])
+    l = O.mel_lengths(alen)
+    assert l.tolist() == j["length_chain"][0]
+    for ref in j["length_chain"][1:]:
+        l = O.strided_lengths(l)
+        assert l.tolist() == ref
+    m = O.key_padding_mask(8, torch.tensor([8, 5, 1]))
+    assert m.tolist() == j["mask_T8"]
+    assert O.patch_pool_mask(m, 3).tolist() == j["patch_mask_T8_P3"]
+    assert j["patch_padding"] == 1
+    for s, v in j["noam_lr"].items():
+        assert math.isclose(O.noam_lr(int(s)), v, rel_tol=1e-12)
+    # Tv = Ta // 640 + 1 meets the audio branch at Ta // 1280 + 1
+    for ta in [16000, 63840, 240000]:
+        tv = O.video_frames_for_audio(ta)
+        a = O.strided_lengths(O.strided_lengths(O.strided_lengths(O.mel_lengths(torch.tensor(ta)))))
+        assert int(O.strided_lengths(torch.tensor(tv))) == int(a)
+
+
+def test_greedy_decode_known_answers():
+    V = 5
+    seq = [0, 1, 1, 0, 1, 2, 2, 2, 0, 0, 3, 4, 4]
+    logits = torch.full((2, len(seq), V), -5.0)
+    for t, s in enumerate(seq):
+        logits[0, t, s] = 5.0
+        logits[1, t, s] = 5.0
+    ids = O.greedy_decode_ids(logits, torch.tensor([len(seq), 6]))
+    assert ids == [[1, 1, 2, 3, 4], [1, 1, 2]]
+
+
+def test_adam_steps():
+    g = load_npz("adam_steps")
+    p = g["p0"].clone()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for s in range(3):
+        p, m, v = O.adam_update(p, g["g"][s], m, v, s + 1, O.noam_lr(s + 1))
+        assert torch.allclose(p, g["p"][s], rtol=1e-6, atol=1e-9)
