@@ -379,8 +379,8 @@ def ctc_nll(logits, logit_len, targets, target_len, blank=0):
         for s in range(2, S):
             can_skip[s] = ext[s] != blank and ext[s] != ext[s - 2]
         for t in range(1, Tb):
-            a1 = torch.cat([alpha.new_full((1,), neg_inf), alpha[:-1]])
-            a2 = torch.cat([alpha.new_full((2,), neg_inf), alpha[:-2]])
+            a1 = torch.cat([alpha.new_full((1,), neg_inf), alpha[:-1]])[:S]
+            a2 = torch.cat([alpha.new_full((2,), neg_inf), alpha[:-2]])[:S]
             a2 = torch.where(can_skip, a2, alpha.new_full((S,), neg_inf))
             alpha = torch.logsumexp(torch.stack([alpha, a1, a2]), dim=0) + lp[b, t, ext_t]
         if Tb == 0:
