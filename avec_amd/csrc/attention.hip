@@ -1,0 +1,297 @@
+// Relative-position multi-head self-attention (RelPos1dMultiHeadAttention.forwardQKV,
+// nnet/attentions.py:280-323) fused per (batch, head):
+//     scores[i][j] = (Q_i.K_j + Q_i.E_{i-j}) / sqrt(d)  (+ -1e9 on masked keys)  -> softmax -> P.V
+// The reference materialises Q.E^T as (B,H,T,2T-1) and re-indexes it with the pad/reshape trick
+// (rel_to_abs, :234-278); here E rows are addressed directly: row r = (T-1) - (i-j).  Keys are
+// streamed in tiles of 64 through LDS with an online softmax, so nothing of size TxT is stored;
+// the backward recomputes probabilities from the saved log-sum-exp.  All arithmetic is fp32 VALU
+// (the attention bmm's are 0.5 % of the model's FLOPs); I/O is the activation dtype.
+//   fwd  : grid (ceil(T/16), B*H), lanes = keys (scores) then lanes = channels (P.V)
+//   bwd1 : dQ, same tiling as fwd
+//   bwd2 : dK, dV, dE; grid (key tiles, B*H, query segments of 64), lanes = keys, register accumulators
+#include "common.h"
+#include "avec_hip.h"
+
+static constexpr int TQ = 16;    // query rows per workgroup (fwd / bwd1): 4 waves x 4 rows
+static constexpr int TK = 64;    // keys per tile = one per lane
+static constexpr int QS = 64;    // query segment per workgroup in bwd2
+static constexpr int QC = 8;     // queries staged per chunk in bwd2
+
+struct AttnArgs {
+  const void *q, *k, *v; long long ld;      // act, row stride (elements); head h occupies columns [h*d, (h+1)*d)
+  const void* e; long long lde;             // act [2T-1][lde]
+  const long long* lens; int len_div;       // key j kept iff j < lens[b] / len_div  (null: all kept)
+  const float* mask; long long mask_bstride; // optional dense mask [Bm][T][T] (1 = keep); overrides lens
+  void* o; long long ldo;                    // act [B*T][ldo]
+  float* lse;                                // [B*H][T]
+  const void* dout;                          // act [B*T][ldo]   (backward)
+  void *dq, *dk, *dv; long long lddq, ldd;   // dq: act, row stride lddq; dk/dv: row stride ldd
+  float* de; long long ldde;                 // fp32 [2T-1][ldde], atomically accumulated
+  int B, H, T, d; float scale;
+};
+
+template <typename T>
+__device__ __forceinline__ bool key_keep(const AttnArgs& a, int b, int i, int j) {
+  if (a.mask) return a.mask[(long long)b * a.mask_bstride + (long long)i * a.T + j] != 0.f;
+  if (a.lens) return j < (int)(a.lens[b] / a.len_div);
+  return true;
+}
+
+// cooperative load of `rows` rows x d channels (act dtype -> fp32 LDS, zero outside [0, limit))
+template <typename T>
+__device__ __forceinline__ void load_rows(float* dst, int DP, const T* src, long long ld, int row0, int rows, int limit, int d) {
+  for (int idx = threadIdx.x; idx < rows * d; idx += 256) {
+    int r = idx / d, c = idx - r * d; int gr = row0 + r;
+    dst[r * DP + c] = (gr >= 0 && gr < limit) ? ldf(src + (long long)gr * ld + c) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int d = a.d, DP = d | 1, Tn = a.T;
+  float* Ks = sm; float* Vs = Ks + TK * DP; float* Es = Vs + TK * DP; float* Qs = Es + (TQ + TK - 1) * DP;
+  float* Gs = Qs + TQ * DP;                  // BWD: dO rows
+  float* Ps = Gs + (BWD ? TQ * DP : 0);      // [4][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int i0 = blockIdx.x * TQ;
+  const T* qp = (const T*)a.q + (long long)b * Tn * a.ld + h * d;
+  const T* kp = (const T*)a.k + (long long)b * Tn * a.ld + h * d;
+  const T* vp = (const T*)a.v + (long long)b * Tn * a.ld + h * d;
+  const T* ep = (const T*)a.e + h * d;
+  load_rows<T>(Qs, DP, qp, a.ld, i0, TQ, Tn, d);
+  if (BWD) load_rows<T>(Gs, DP, (const T*)a.dout + (long long)b * Tn * a.ldo + h * d, a.ldo, i0, TQ, Tn, d);
+  __syncthreads();
+
+  float m_run[4], l_run[4], acc[4][2], Li[4], dl[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; dl[rr] = 0.f; }
+  if (BWD) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int ri = w * 4 + rr, i = i0 + ri;
+      float s = 0.f;
+      if (i < Tn) {
+        const T* op = (const T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
+        for (int c = lane; c < d; c += 64) s += Gs[ri * DP + c] * ldf(op + c);
+        Li[rr] = a.lse[(long long)bh * Tn + i];
+      }
+      dl[rr] = wave_sum(s);
+    }
+  }
+
+  for (int j0 = 0; j0 < Tn; j0 += TK) {
+    __syncthreads();
+    load_rows<T>(Ks, DP, kp, a.ld, j0, TK, Tn, d);
+    load_rows<T>(Vs, DP, vp, a.ld, j0, TK, Tn, d);
+    const int rbase = (Tn - 1) - (i0 + TQ - 1) + j0;
+    load_rows<T>(Es, DP, ep, a.lde, rbase, TQ + TK - 1, 2 * Tn - 1, d);
+    __syncthreads();
+    const int j = j0 + lane;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int ri = w * 4 + rr, i = i0 + ri;
+      const bool iv = i < Tn, jv = j < Tn;
+      const float* qrow = Qs + ri * DP; const float* krow = Ks + lane * DP; const float* erow = Es + (TQ - 1 - ri + lane) * DP;
+      float s = 0.f, dp = 0.f;
+      if (BWD) { const float* grow = Gs + ri * DP; const float* vrow = Vs + lane * DP;
+        for (int c = 0; c < d; ++c) { s += qrow[c] * (krow[c] + erow[c]); dp += grow[c] * vrow[c]; } }
+      else { for (int c = 0; c < d; ++c) s += qrow[c] * (krow[c] + erow[c]); }
+      s *= a.scale;
+      if (iv && jv && !key_keep<T>(a, b, i, j)) s += -1e9f;
+      float pval;
+      if (!BWD) {
+        float sm_ = (iv && jv) ? s : -INFINITY;
+        float tmax = wave_max(sm_);
+        float m_new = fmaxf(m_run[rr], tmax);
+        float alpha = (m_run[rr] == -INFINITY) ? 0.f : __expf(m_run[rr] - m_new);
+        pval = (iv && jv) ? __expf(s - m_new) : 0.f;
+        l_run[rr] = l_run[rr] * alpha + wave_sum(pval);
+        acc[rr][0] *= alpha; acc[rr][1] *= alpha; m_run[rr] = m_new;
+      } else {
+        float p = (iv && jv) ? __expf(s - Li[rr]) : 0.f;
+        pval = p * (dp - dl[rr]) * a.scale;   // dS
+      }
+      Ps[w * 64 + lane] = pval;
+      __syncthreads();
+      if (!BWD) {
+        for (int jj = 0; jj < TK; ++jj) {
+          const float pj = Ps[w * 64 + jj];
+          if (lane < d) acc[rr][0] += pj * Vs[jj * DP + lane];
+          if (lane + 64 < d) acc[rr][1] += pj * Vs[jj * DP + lane + 64];
+        }
+      } else {
+        const float* ebase = Es + (TQ - 1 - ri) * DP;
+        for (int jj = 0; jj < TK; ++jj) {
+          const float dsj = Ps[w * 64 + jj];
+          if (lane < d) acc[rr][0] += dsj * (Ks[jj * DP + lane] + ebase[jj * DP + lane]);
+          if (lane + 64 < d) acc[rr][1] += dsj * (Ks[jj * DP + lane + 64] + ebase[jj * DP + lane + 64]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + w * 4 + rr;
+    if (i >= Tn) continue;
+    if (!BWD) {
+      const float inv = 1.f / l_run[rr];
+      T* op = (T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
+      if (lane < d) stf(op + lane, acc[rr][0] * inv);
+      if (lane + 64 < d) stf(op + lane + 64, acc[rr][1] * inv);
+      if (lane == 0) a.lse[(long long)bh * Tn + i] = m_run[rr] + __logf(l_run[rr]);
+    } else {
+      T* op = (T*)a.dq + ((long long)b * Tn + i) * a.lddq + h * d;
+      if (lane < d) stf(op + lane, acc[rr][0]);
+      if (lane + 64 < d) stf(op + lane + 64, acc[rr][1]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bwd2: dK, dV (per key, register accumulators) and dE (LDS window, flushed with atomics)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DPAD>
+__global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int d = a.d, DP = d | 1, Tn = a.T;
+  float* Ks = sm; float* Vs = Ks + TK * DP; float* dEs = Vs + TK * DP;            // dEs: [QS+TK-1][DP]
+  float* Es = dEs + (QS + TK - 1) * DP;                                            // [QC+TK-1][DP]
+  float* Qs = Es + (QC + TK - 1) * DP; float* Gs = Qs + QC * DP;                   // [QC][DP] each
+  float* Ls = Gs + QC * DP; float* Ds = Ls + QC;                                   // [QC] lse, delta
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int j0 = blockIdx.x * TK, is = blockIdx.z * QS;
+  const int ie = min(is + QS, Tn);
+  const T* qp = (const T*)a.q + (long long)b * Tn * a.ld + h * d;
+  const T* kp = (const T*)a.k + (long long)b * Tn * a.ld + h * d;
+  const T* vp = (const T*)a.v + (long long)b * Tn * a.ld + h * d;
+  const T* gp = (const T*)a.dout + (long long)b * Tn * a.ldo + h * d;
+  const T* op = (const T*)a.o + (long long)b * Tn * a.ldo + h * d;
+  const T* ep = (const T*)a.e + h * d;
+  load_rows<T>(Ks, DP, kp, a.ld, j0, TK, Tn, d);
+  load_rows<T>(Vs, DP, vp, a.ld, j0, TK, Tn, d);
+  for (int idx = threadIdx.x; idx < (QS + TK - 1) * DP; idx += 256) dEs[idx] = 0.f;
+  float dk[DPAD], dv[DPAD];
+#pragma unroll
+  for (int c = 0; c < DPAD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+  const int j = j0 + lane; const bool jv = j < Tn;
+
+  for (int ic = is; ic < ie; ic += QC) {
+    __syncthreads();
+    load_rows<T>(Qs, DP, qp, a.ld, ic, QC, Tn, d);
+    load_rows<T>(Gs, DP, gp, a.ldo, ic, QC, Tn, d);
+    load_rows<T>(Es, DP, ep, a.lde, (Tn - 1) - (ic + QC - 1) + j0, QC + TK - 1, 2 * Tn - 1, d);
+    __syncthreads();
+    // delta_i = dO_i . O_i and lse_i for the chunk: wave w handles queries w, w+4
+    for (int qi = w; qi < QC; qi += 4) {
+      const int i = ic + qi; float s = 0.f;
+      if (i < Tn) for (int c = lane; c < d; c += 64) s += Gs[qi * DP + c] * ldf(op + (long long)i * a.ldo + c);
+      s = wave_sum(s);
+      if (lane == 0) { Ds[qi] = s; Ls[qi] = (i < Tn) ? a.lse[(long long)bh * Tn + i] : 0.f; }
+    }
+    __syncthreads();
+    for (int qi = w; qi < QC; qi += 4) {
+      const int i = ic + qi;
+      if (i >= ie) continue;                                 // wave-uniform
+      const float* qrow = Qs + qi * DP; const float* grow = Gs + qi * DP;
+      const float* krow = Ks + lane * DP; const float* vrow = Vs + lane * DP; const float* erow = Es + (QC - 1 - qi + lane) * DP;
+      float s = 0.f, dp = 0.f;
+      for (int c = 0; c < d; ++c) { s += qrow[c] * (krow[c] + erow[c]); dp += grow[c] * vrow[c]; }
+      s *= a.scale;
+      if (jv && !key_keep<T>(a, b, i, j)) s += -1e9f;
+      const float p = jv ? __expf(s - Ls[qi]) : 0.f;
+      const float ds = p * (dp - Ds[qi]) * a.scale;
+      float* derow = dEs + (is + QS - 1 - i + lane) * DP;
+#pragma unroll
+      for (int c = 0; c < DPAD; ++c) {
+        if (c < d) { const float qv = qrow[c]; dv[c] += p * grow[c]; dk[c] += ds * qv; atomicAdd(derow + c, ds * qv); }
+      }
+    }
+  }
+  __syncthreads();
+  // cross-wave reduction of dk/dv through LDS (Ks/Vs are free now), one wave at a time
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int c = 0; c < DPAD; ++c) if (c < d) {
+        if (ww == 0) { Ks[lane * DP + c] = dk[c]; Vs[lane * DP + c] = dv[c]; }
+        else { Ks[lane * DP + c] += dk[c]; Vs[lane * DP + c] += dv[c]; }
+      }
+    }
+    __syncthreads();
+  }
+  const bool first_seg = (gridDim.z == 1);
+  for (int idx = threadIdx.x; idx < TK * d; idx += 256) {
+    const int r = idx / d, c = idx - r * d; const int jj = j0 + r;
+    if (jj >= Tn) continue;
+    // several query segments contribute to the same key rows: accumulate in fp32 scratch (dk/dv pointers are fp32 when gridDim.z > 1)
+    if (first_seg) { stf((T*)a.dk + ((long long)b * Tn + jj) * a.ldd + h * d + c, Ks[r * DP + c]); stf((T*)a.dv + ((long long)b * Tn + jj) * a.ldd + h * d + c, Vs[r * DP + c]); }
+    else { atomicAdd((float*)a.dk + ((long long)b * Tn + jj) * a.ldd + h * d + c, Ks[r * DP + c]); atomicAdd((float*)a.dv + ((long long)b * Tn + jj) * a.ldd + h * d + c, Vs[r * DP + c]); }
+  }
+  const int rb = (Tn - 1) - (is + QS - 1) + j0;
+  for (int idx = threadIdx.x; idx < (QS + TK - 1) * d; idx += 256) {
+    const int r = idx / d, c = idx - r * d; const int gr = rb + r;
+    if (gr >= 0 && gr < 2 * Tn - 1) { const float v = dEs[r * DP + c]; if (v != 0.f) atomicAdd(a.de + (long long)gr * a.ldde + h * d + c, v); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int fill_args(AttnArgs& a, const avec_attn_t* p) {
+  a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1;
+  a.mask = p->mask; a.mask_bstride = p->mask_bstride; a.o = p->o; a.ldo = p->ldo; a.lse = p->lse; a.dout = p->dout;
+  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde;
+  a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale;
+  AVEC_CHECK_ARG(a.q && a.k && a.v && a.e && a.o && a.lse, "attention: null pointer");
+  AVEC_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.d > 0 && a.d <= 96, "attention: bad dims B=%d H=%d T=%d d=%d (d <= 96 supported)", a.B, a.H, a.T, a.d);
+  return 0;
+}
+template <typename K> static int set_lds(K kern, size_t bytes) {
+  if (bytes > 160 * 1024) { avec_set_error("attention: %zu bytes of LDS requested (> 160 KiB)", bytes); return -1; }
+  static const void* done[16]; static size_t done_bytes[16]; static int ndone = 0;
+  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern && done_bytes[i] >= bytes) return 0;
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { avec_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    if (ndone < 16) { done[ndone] = (const void*)kern; done_bytes[ndone] = bytes; ++ndone; }
+  }
+  return 0;
+}
+
+extern "C" int avec_relpos_attention_fwd(int dtype, const avec_attn_t* p, hipStream_t st) {
+  AttnArgs a; AVEC_CHECK_ARG(p, "attention_fwd: null args"); if (int r = fill_args(a, p)) return r;
+  const int DP = a.d | 1; size_t lds = (size_t)(2 * TK + (TQ + TK - 1) + TQ) * DP * 4 + 4 * 64 * 4;
+  dim3 grid((a.T + TQ - 1) / TQ, a.B * a.H);
+  if (dtype == AVEC_BF16) { if (int r = set_lds(attn_rows_kernel<bf16, false>, lds)) return r; hipLaunchKernelGGL((attn_rows_kernel<bf16, false>), grid, dim3(256), lds, st, a); }
+  else { if (int r = set_lds(attn_rows_kernel<float, false>, lds)) return r; hipLaunchKernelGGL((attn_rows_kernel<float, false>), grid, dim3(256), lds, st, a); }
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
+  const int DP = a.d | 1;
+  size_t lds1 = (size_t)(2 * TK + (TQ + TK - 1) + 2 * TQ) * DP * 4 + 4 * 64 * 4;
+  dim3 grid1((a.T + TQ - 1) / TQ, a.B * a.H);
+  if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
+  hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
+  size_t lds2 = (size_t)(2 * TK + (QS + TK - 1) + (QC + TK - 1) + 2 * QC) * DP * 4 + 2 * QC * 4;
+  dim3 grid2((a.T + TK - 1) / TK, a.B * a.H, (a.T + QS - 1) / QS);
+#define LB(DPAD) do { if (int r = set_lds(attn_bwd_keys_kernel<T, DPAD>, lds2)) return r; hipLaunchKernelGGL((attn_bwd_keys_kernel<T, DPAD>), grid2, dim3(256), lds2, st, a); } while (0)
+  if (a.d <= 48) LB(48); else if (a.d <= 64) LB(64); else LB(96);
+#undef LB
+  return 0;
+}
+
+// dk/dv: act buffers when T <= 64 (single query segment); otherwise fp32 scratch (zeroed by the caller) that the
+// caller converts with avec_cast_rows.  `dkv_f32` must say which.
+extern "C" int avec_relpos_attention_bwd(int dtype, const avec_attn_t* p, int dkv_f32, hipStream_t st) {
+  AttnArgs a; AVEC_CHECK_ARG(p, "attention_bwd: null args"); if (int r = fill_args(a, p)) return r;
+  AVEC_CHECK_ARG(a.dout && a.dq && a.dk && a.dv && a.de, "attention_bwd: null gradient pointer");
+  const int nseg = (a.T + QS - 1) / QS;
+  AVEC_CHECK_ARG((nseg > 1) == (dkv_f32 != 0), "attention_bwd: dkv_f32 must be %d for T=%d", nseg > 1, a.T);
+  int r = (dtype == AVEC_BF16) ? launch_bwd<bf16>(a, st) : launch_bwd<float>(a, st);
+  if (r) return r;
+  AVEC_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,79 @@
+// Shared device helpers for the AVEC gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AVEC_F32 0
+#define AVEC_BF16 1
+
+typedef unsigned short bf16_raw;  // storage type for bfloat16
+
+struct bf16 { bf16_raw v; };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {  // round-to-nearest-even (NaN preserved)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_raw)(u >> 16);
+}
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elt<bf16> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16* p) { return bf16_to_f32(p->v); }
+  __device__ static __forceinline__ void st(bf16* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Elt<T>::ld(p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Elt<T>::st(p, v); }
+
+struct __attribute__((aligned(16))) chunk16 { uint32_t w[4]; };           // 16 B register/LDS chunk (ds_read/write_b128)
+struct __attribute__((packed, aligned(4))) chunk16u { uint32_t w[4]; };  // 16 B global access, only dword alignment assumed
+__device__ __forceinline__ chunk16 ldg16(const void* p) { chunk16u t = *(const chunk16u*)p; chunk16 o; o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3]; return o; }
+
+// ---- wave64 reductions (DPP/shuffle based) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based RNG for dropout / SpecAugment: stateless, reproducible in backward ----
+// u = hash(seed, stream, idx) in [0,1); keep <=> u >= p.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
+  uint32_t a = mix32((uint32_t)idx ^ (uint32_t)seed);
+  uint32_t b = mix32((uint32_t)(idx >> 32) + stream * 0x9e3779b9u + (uint32_t)(seed >> 32));
+  uint32_t h = mix32(a ^ (b + 0x85ebca6bu + (a << 6) + (a >> 2)));
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// dropout scale factor for element idx: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_scale(const unsigned long long* rng, uint32_t stream, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  uint64_t seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
+  return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswishf_(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+// ---- host-side error plumbing (api.hip) ----
+extern "C" const char* avec_last_error();
+void avec_set_error(const char* fmt, ...);
+#define AVEC_CHECK_ARG(cond, ...) do { if (!(cond)) { avec_set_error(__VA_ARGS__); return -1; } } while (0)
+#define AVEC_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { avec_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)

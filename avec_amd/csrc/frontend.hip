@@ -1,0 +1,260 @@
+// Front-end kernels.
+//   audio : framing+Hann window (feeds an exact-fp32 MFMA DFT GEMM), |.|^2 -> 80 HTK mel filters -> log,
+//           SpecAugment masks, Conv2d(1->180,3x3,s2)+BatchNorm2d+Swish stem written directly in the
+//           (B, T', C*F') layout the 7200->180 Linear consumes            (nnet/preprocessing.py:57-130,
+//           nnet/networks.py:356-377, nnet/modules.py:70-130)
+//   video : BatchNorm3d+ReLU+MaxPool3d((1,3,3),s(1,2,2)) fused after the Conv3d stem GEMM, forward and
+//           backward                                                        (nnet/networks.py:459-473)
+#include "vec.h"
+#include "avec_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// mel: frames[m][n] = w[n] * reflect_pad(audio)[f*hop + n + (n_fft-win)/2 - n_fft/2],  n in [0, win)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ audio, const float* __restrict__ window, float* __restrict__ frames,
+                                                         int B, long long L, int F, int n_fft, int win, int hop) {
+  const long long total = (long long)B * F * win;
+  const int off = (n_fft - win) / 2 - n_fft / 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i % win); const long long r = i / win; const int f = (int)(r % F); const long long b = r / F;
+    long long s = (long long)f * hop + n + off;
+    if (s < 0) s = -s; else if (s >= L) s = 2 * (L - 1) - s;   // reflect (no edge repeat)
+    frames[i] = audio[b * L + s] * window[n];
+  }
+}
+// spec[m] = [re(0..nb-1) | im(0..nb-1)];  out[b][mel][f] = log(sum_k (re^2+im^2) fb[k][mel] + 1e-9)
+__global__ __launch_bounds__(128) void mel_power_log_kernel(const float* __restrict__ spec, const float* __restrict__ fb, float* __restrict__ out,
+                                                            int F, int nb, int n_mels) {
+  extern __shared__ float pw[];
+  const long long m = blockIdx.x; const int f = (int)(m % F); const long long b = m / F;
+  for (int k = threadIdx.x; k < nb; k += 128) { const float re = spec[m * 2 * nb + k], im = spec[m * 2 * nb + nb + k]; pw[k] = re * re + im * im; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n_mels; j += 128) {
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += pw[k] * fb[k * n_mels + j];
+    out[(b * n_mels + j) * F + f] = logf(s + 1e-9f);
+  }
+}
+extern "C" int avec_mel_frames(const float* audio, const float* window, float* frames, int B, long long L, int n_fft, int win, int hop, hipStream_t st) {
+  AVEC_CHECK_ARG(audio && window && frames && B > 0 && L > n_fft / 2 && win <= n_fft && hop > 0, "mel_frames: bad arguments");
+  const int F = (int)(L / hop) + 1; long long total = (long long)B * F * win; long long nb = (total + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(mel_frames_kernel, dim3((unsigned)nb), dim3(256), 0, st, audio, window, frames, B, L, F, n_fft, win, hop);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_mel_power_log(const float* spec, const float* fb, float* out, int B, int F, int n_bins, int n_mels, hipStream_t st) {
+  AVEC_CHECK_ARG(spec && fb && out && B > 0 && F > 0 && n_bins > 0 && n_mels > 0, "mel_power_log: bad arguments");
+  hipLaunchKernelGGL(mel_power_log_kernel, dim3((unsigned)((long long)B * F)), dim3(128), n_bins * sizeof(float), st, spec, fb, out, F, n_bins, n_mels);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpecAugment (nnet/preprocessing.py:115-130): mF batch-shared frequency masks (width U[0,Fp)), mT per-sample
+// time masks (width U[0, int(pS*len_b))) inside the valid length; masked bins set to 0.  mel: [B][n_mels][F].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ mel, const long long* __restrict__ lens, int B, int n_mels, int F, int mF, int Fp, int mT, float pS,
+                                                      const unsigned long long* rng, unsigned stream) {
+  const unsigned long long seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
+  const long long total = (long long)B * n_mels * F;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % F); const long long r = i / F; const int m = (int)(r % n_mels); const int b = (int)(r / n_mels);
+    bool masked = false;
+    for (int q = 0; q < mF && !masked; ++q) {
+      const float val = rng_uniform(seed, stream, 2 * q) * Fp; const float mn = rng_uniform(seed, stream, 2 * q + 1) * (n_mels - val);
+      const int s0 = (int)mn, s1 = (int)mn + (int)val; masked = (m >= s0 && m < s1);
+    }
+    const int len = lens ? (int)lens[b] : F; const int Tp = (int)(pS * len);
+    if (f < len) for (int q = 0; q < mT && !masked; ++q) {
+      const unsigned long long id = 1000ull + (unsigned long long)b * 64 + 2 * q;
+      const float val = rng_uniform(seed, stream, id) * Tp; const float mn = rng_uniform(seed, stream, id + 1) * (len - val);
+      const int s0 = (int)mn, s1 = (int)mn + (int)val; masked = (f >= s0 && f < s1);
+    }
+    if (masked) mel[i] = 0.f;
+  }
+}
+extern "C" int avec_specaugment(float* mel, const long long* lens, int B, int n_mels, int F, int mF, int Fparam, int mT, float pS,
+                                const unsigned long long* rng, unsigned rng_stream, hipStream_t st) {
+  AVEC_CHECK_ARG(mel && rng && B > 0 && n_mels > 0 && F > 0, "specaugment: bad arguments");
+  long long total = (long long)B * n_mels * F; long long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(specaug_kernel, dim3((unsigned)nb), dim3(256), 0, st, mel, lens, B, n_mels, F, mF, Fparam, mT, pS, rng, rng_stream);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// audio stem: y[b][to][c*Fo + fo] = bias[c] + sum_{kh,kw} w[c][kh][kw] * mel[b][2fo+kh-1][2to+kw-1]
+// ---------------------------------------------------------------------------------------------
+struct StemA { int B, NM, F, C, Fo, To; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_conv_kernel(const float* __restrict__ mel, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              T* __restrict__ y, float* stats, StemA s) {
+  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  if (j >= J) return;
+  const int c = j / s.Fo, fo = j % s.Fo;
+  float wk[9]; for (int q = 0; q < 9; ++q) wk[q] = w[c * 9 + q];
+  const float bb = bias ? bias[c] : 0.f;
+  float sum = 0.f, sq = 0.f;
+  const long long M = (long long)s.B * s.To;
+  for (long long row = blockIdx.y; row < M; row += gridDim.y) {
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    float acc = bb;
+    for (int kh = 0; kh < 3; ++kh) { const int fi = 2 * fo + kh - 1; if (fi < 0 || fi >= s.NM) continue;
+      for (int kw = 0; kw < 3; ++kw) { const int ti = 2 * to + kw - 1; if (ti < 0 || ti >= s.F) continue;
+        acc += wk[kh * 3 + kw] * mel[(b * s.NM + fi) * s.F + ti]; } }
+    stf(y + row * J + j, acc); sum += acc; sq += acc * acc;
+  }
+  if (stats) { atomicAdd(stats + c, sum); atomicAdd(stats + s.C + c, sq); }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_act_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ a, long long M, int J, int Fo, int C) {
+  const long long total = M * J;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % J) / Fo; stf(a + i, swishf_(ldf(y + i) * ss[c] + ss[C + c]));
+  }
+}
+// pass 1: dstats[c] += sum dr, dstats[C+c] += sum dr*yhat   with dr = da * swish'(pre)
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ ss, float* dstats, StemA s) {
+  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  if (j >= J) return;
+  const int c = j / s.Fo; const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c];
+  float s1 = 0.f, s2 = 0.f; const long long M = (long long)s.B * s.To;
+  for (long long row = blockIdx.y; row < M; row += gridDim.y) {
+    const float yy = ldf(y + row * J + j); const float dr = ldf(da + row * J + j) * dswishf_(yy * sc + sh);
+    s1 += dr; s2 += dr * (yy - mu) * rs;
+  }
+  atomicAdd(dstats + c, s1); atomicAdd(dstats + s.C + c, s2);
+}
+// pass 2: dy = gamma*rstd*(dr - s1/n - yhat*s2/n);  dw[c][kh][kw] += sum dy*mel(patch);  dbias[c] += sum dy; block row 0 adds dgamma/dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_params_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ mel, const float* __restrict__ ss,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
+                                                                    float* dw, float* dbias, float* dgamma, float* dbeta, StemA s) {
+  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  if (j >= J) return;
+  const int c = j / s.Fo, fo = j % s.Fo; const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c], g = gamma[c];
+  const float m1 = dstats[c] * inv_n, m2 = dstats[s.C + c] * inv_n;
+  if (blockIdx.y == 0 && fo == 0 && dgamma) { atomicAdd(dgamma + c, dstats[s.C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  float aw[9]; for (int q = 0; q < 9; ++q) aw[q] = 0.f; float ab = 0.f;
+  const long long M = (long long)s.B * s.To;
+  for (long long row = blockIdx.y; row < M; row += gridDim.y) {
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    const float yy = ldf(y + row * J + j); const float dr = ldf(da + row * J + j) * dswishf_(yy * sc + sh);
+    const float dy = g * rs * (dr - m1 - (yy - mu) * rs * m2);
+    ab += dy;
+    for (int kh = 0; kh < 3; ++kh) { const int fi = 2 * fo + kh - 1; if (fi < 0 || fi >= s.NM) continue;
+      for (int kw = 0; kw < 3; ++kw) { const int ti = 2 * to + kw - 1; if (ti < 0 || ti >= s.F) continue;
+        aw[kh * 3 + kw] += dy * mel[(b * s.NM + fi) * s.F + ti]; } }
+  }
+  for (int q = 0; q < 9; ++q) atomicAdd(dw + c * 9 + q, aw[q]);
+  if (dbias) atomicAdd(dbias + c, ab);
+}
+static StemA stemA(int B, int NM, int F, int C) { StemA s; s.B = B; s.NM = NM; s.F = F; s.C = C; s.Fo = (NM - 1) / 2 + 1; s.To = (F - 1) / 2 + 1; return s; }
+static dim3 stem_grid(const StemA& s) { long long M = (long long)s.B * s.To; unsigned gx = (s.C * s.Fo + 255) / 256; long long gy = 2048 / gx; if (gy > M) gy = M; if (gy < 1) gy = 1; return dim3(gx, (unsigned)gy); }
+
+extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float* w, const float* bias, void* y, float* stats, int B, int n_mels, int F, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(mel && w && y && B > 0 && n_mels > 0 && F > 0 && C > 0, "audio_stem_conv_fwd: bad arguments");
+  StemA s = stemA(B, n_mels, F, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv_kernel<T>, stem_grid(s), dim3(256), 0, st, mel, w, bias, (T*)y, stats, s));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_audio_stem_act_fwd(int dtype, const void* y, const float* ss, void* a, int B, int n_mels, int F, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(y && ss && a, "audio_stem_act_fwd: null pointer");
+  StemA s = stemA(B, n_mels, F, C); long long M = (long long)B * s.To; long long nb = (M * C * s.Fo + 255) / 256; if (nb > 4096) nb = 4096;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_act_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)a, M, C * s.Fo, s.Fo, C));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, const float* mel, const float* ss, const float* gamma, float* dstats,
+                                   const float* count_ptr, float count, int phase, float* dw, float* dbias, float* dgamma, float* dbeta,
+                                   int B, int n_mels, int F, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(da && y && mel && ss && gamma && dstats && (phase == 0 || (dw != nullptr)), "audio_stem_bwd: bad arguments");
+  StemA s = stemA(B, n_mels, F, C);
+  if (phase == 0) { DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce_kernel<T>, stem_grid(s), dim3(256), 0, st, (const T*)da, (const T*)y, ss, dstats, s)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params_kernel<T>, stem_grid(s), dim3(256), 0, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count, dw, dbias, dgamma, dbeta, s)); }
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// video stem tail: a = relu(y*scale+shift) on [Fr][H][W][C]; 3x3 stride-2 max pool with zero pad 1 -> [Fr][H/2][W/2][C]
+// idx (uint8) = window slot kh*3+kw of the maximum (255: the zero padding won / dead ReLU)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ out, unsigned char* __restrict__ idx,
+                                                            long long Fr, int H, int W, int C, int OH, int OW) {
+  const long long n4 = Fr * OH * OW * (C / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (C / 4)) * 4; long long r = i / (C / 4); const int ow = (int)(r % OW); r /= OW; const int oh = (int)(r % OH); const long long fr = r / OH;
+    float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh);
+    float best[4] = {0.f, 0.f, 0.f, 0.f}; unsigned bi[4] = {255u, 255u, 255u, 255u};
+    for (int kh = 0; kh < 3; ++kh) { const int h = 2 * oh + kh - 1; if (h < 0 || h >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) { const int w = 2 * ow + kw - 1; if (w < 0 || w >= W) continue;
+        float v[4]; ld4<T>(y + ((fr * H + h) * W + w) * C + c, v);
+        for (int e = 0; e < 4; ++e) { const float a = v[e] * sc[e] + sh[e]; if (a > best[e]) { best[e] = a; bi[e] = kh * 3 + kw; } } } }
+    st4<T>(out + i * 4, best);
+    *(uint32_t*)(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+  }
+}
+// dr at input position (h,w): sum over the (<=4) windows that selected it
+template <typename T>
+__device__ __forceinline__ void stem_dr(const T* dp, const unsigned char* idx, long long fr, int h, int w, int c, int C, int OH, int OW, float dr[4]) {
+  dr[0] = dr[1] = dr[2] = dr[3] = 0.f;
+  for (int kh = 0; kh < 3; ++kh) { const int t = h + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= OH) continue;
+    for (int kw = 0; kw < 3; ++kw) { const int u = w + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= OW) continue;
+      const long long o = ((fr * OH + oh) * OW + ow) * C + c;
+      const uint32_t sel = *(const uint32_t*)(idx + o); float g[4]; ld4<T>(dp + o, g);
+      for (int e = 0; e < 4; ++e) if (((sel >> (8 * e)) & 255u) == (unsigned)(kh * 3 + kw)) dr[e] += g[e]; } }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
+                                                                   float* dstats, long long Fr, int H, int W, int C, int OH, int OW) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
+  float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const long long M = Fr * H * W;
+  if (col < C) {
+    float mu[4], rs[4]; ld4<float>(ss + 2 * C + col, mu); ld4<float>(ss + 3 * C + col, rs);
+    for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
+      const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+      float dr[4], v[4]; stem_dr<T>(dp, idx, fr, h, w, col, C, OH, OW, dr); ld4<T>(y + row * C + col, v);
+      for (int e = 0; e < 4; ++e) { part[0][e] += dr[e]; part[1][e] += dr[e] * (v[e] - mu[e]) * rs[e]; }
+    }
+  }
+  float* const dst[2] = {dstats, dstats + C};
+  colreduce_atomic<2>(part, dst, col, C);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_apply_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
+                                                                  T* __restrict__ dy, float* dgamma, float* dbeta, long long Fr, int H, int W, int C, int OH, int OW) {
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  const long long n4 = Fr * H * W * (C / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (C / 4)) * 4; const long long row = i / (C / 4);
+    const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+    float dr[4], v[4], mu[4], rs[4], g[4], s1[4], s2[4], o[4];
+    stem_dr<T>(dp, idx, fr, h, w, c, C, OH, OW, dr); ld4<T>(y + row * C + c, v);
+    ld4<float>(ss + 2 * C + c, mu); ld4<float>(ss + 3 * C + c, rs); ld4<float>(gamma + c, g); ld4<float>(dstats + c, s1); ld4<float>(dstats + C + c, s2);
+    for (int e = 0; e < 4; ++e) { const float yh = (v[e] - mu[e]) * rs[e]; o[e] = g[e] * rs[e] * (dr[e] - s1[e] * inv_n - yh * s2[e] * inv_n); }
+    st4<T>(dy + row * C + c, o);
+  }
+}
+extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(y && ss && out && idx && frames > 0 && H > 0 && W > 0 && C % 4 == 0, "stem_pool_fwd: bad arguments");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; long long n4 = frames * OH * OW * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)out, idx, frames, H, W, C, OH, OW));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
+                                  const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dpool && idx && y && ss && gamma && dstats && (phase == 0 || dy) && frames > 0 && C % 4 == 0, "stem_pool_bwd: bad arguments");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  if (phase == 0) {
+    dim3 grid = col_grid(frames * H * W, C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats, frames, H, W, C, OH, OW));
+  } else {
+    long long n4 = frames * H * W * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, gamma, dstats, count_ptr, count,
+                                         (T*)dy, dgamma, dbeta, frames, H, W, C, OH, OW));
+  }
+  AVEC_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,186 @@
+// CTC loss (log-softmax + alpha/beta recursion + gradient) and the flat-arena optimizer step.
+//   CTC      : nnet/losses.py:311-334  (log_softmax -> nn.CTCLoss(blank=0, reduction="none", zero_infinity))
+//   Adam     : nnet/optimizers.py:61-93 over torch.optim.Adam (coupled L2 weight decay), lr from a device scalar
+//   shadows  : compute-dtype copies of the GEMM weights in the two layouts the NT kernels want
+#include "vec.h"
+#include "avec_hip.h"
+
+__device__ __forceinline__ float logaddexpf_(float a, float b) {
+  if (a == -INFINITY) return b; if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b); return m + log1pf(__expf(-fabsf(a - b)));
+}
+
+// one wave per utterance; states s = 0..S-1 (S = 2L+1) strided over lanes.
+// ws: per utterance [T][S] alphas followed by [T] frame log-normalisers.
+__global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+                                                 const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
+                                                 float* __restrict__ ws, int B, int T, int V, int Lmax, int blank, int zero_inf) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int Smax = 2 * Lmax + 1;
+  float* beta0 = sm; float* beta1 = sm + Smax; float* occ = beta1 + Smax;      // occ[V]
+  int* ext = (int*)(occ + V);                                                   // ext[Smax]
+  const int Tb = min((int)in_lens[b], T), L = min((int)tgt_lens[b], Lmax), S = 2 * L + 1;
+  float* alpha = ws + (long long)b * ((long long)T * Smax + T); float* lnorm = alpha + (long long)T * Smax;
+  const float* lg = logits + (long long)b * T * V;
+  float* gr = grad ? grad + (long long)b * T * V : nullptr;
+  for (int s = lane; s < S; s += 64) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
+  // frame log-normalisers
+  for (int t = 0; t < Tb; ++t) {
+    float mx = -INFINITY; for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[t * V + v]);
+    mx = wave_max(mx);
+    float se = 0.f; for (int v = lane; v < V; v += 64) se += __expf(lg[t * V + v] - mx);
+    se = wave_sum(se);
+    if (lane == 0) lnorm[t] = mx + __logf(se);
+  }
+  __syncthreads();
+  // alpha
+  float ll = -INFINITY;
+  if (Tb > 0) {
+    for (int s = lane; s < S; s += 64) alpha[s] = (s < 2) ? lg[ext[s]] - lnorm[0] : -INFINITY;
+    __syncthreads();
+    for (int t = 1; t < Tb; ++t) {
+      const float* ap = alpha + (long long)(t - 1) * Smax; float* an = alpha + (long long)t * Smax;
+      for (int s = lane; s < S; s += 64) {
+        float a = ap[s];
+        if (s >= 1) a = logaddexpf_(a, ap[s - 1]);
+        if (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) a = logaddexpf_(a, ap[s - 2]);
+        an[s] = a + lg[t * V + ext[s]] - lnorm[t];
+      }
+      __syncthreads();
+    }
+    const float* al = alpha + (long long)(Tb - 1) * Smax;
+    ll = al[S - 1]; if (S > 1) ll = logaddexpf_(ll, al[S - 2]);
+  } else if (L == 0) ll = 0.f;
+  float loss = -ll;
+  const bool inf = !(loss < INFINITY);     // inf or nan
+  if (inf && zero_inf) loss = 0.f;
+  if (lane == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); }
+  if (!gr) return;
+  // gradient w.r.t. logits:  softmax - occupancy   (zero where t >= Tb or the alignment is infeasible)
+  for (int i = lane; i < (T - Tb) * V; i += 64) gr[(long long)Tb * V + i] = 0.f;
+  if (inf || Tb == 0) { for (int i = lane; i < Tb * V; i += 64) gr[i] = 0.f; return; }
+  float* bc = beta0; float* bn = beta1;
+  for (int t = Tb - 1; t >= 0; --t) {
+    for (int s = lane; s < S; s += 64) {
+      float bv;
+      if (t == Tb - 1) bv = (s >= S - 2) ? 0.f : -INFINITY;
+      else {
+        bv = bn[s];
+        if (s + 1 < S) bv = logaddexpf_(bv, bn[s + 1]);
+        if (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != ext[s]) bv = logaddexpf_(bv, bn[s + 2]);
+      }
+      bc[s] = bv + lg[t * V + ext[s]] - lnorm[t];
+    }
+    for (int v = lane; v < V; v += 64) occ[v] = 0.f;
+    __syncthreads();
+    const float* at = alpha + (long long)t * Smax;
+    for (int s = lane; s < S; s += 64) {
+      const float lp = lg[t * V + ext[s]] - lnorm[t];
+      const float term = __expf(at[s] + bc[s] - lp - ll);
+      atomicAdd(occ + ext[s], term);
+    }
+    __syncthreads();
+    for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - occ[v];
+    __syncthreads();
+    float* tmp = bc; bc = bn; bn = tmp;
+  }
+}
+
+extern "C" long long avec_ctc_workspace_floats(int B, int T, int Lmax) { return (long long)B * ((long long)T * (2 * Lmax + 1) + T); }
+
+extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
+                             float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
+  AVEC_CHECK_ARG(logits && in_lens && targets && tgt_lens && nll && workspace, "ctc_loss: null pointer");
+  AVEC_CHECK_ARG(B > 0 && T > 0 && V > 0 && Lmax >= 0 && blank >= 0 && blank < V, "ctc_loss: bad dims B=%d T=%d V=%d Lmax=%d", B, T, V, Lmax);
+  size_t lds = (size_t)(2 * (2 * Lmax + 1) + V) * 4 + (size_t)(2 * Lmax + 1) * 4;
+  AVEC_CHECK_ARG(lds <= 60 * 1024, "ctc_loss: label length %d too long for the LDS state buffers", Lmax);
+  hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(64), lds, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, workspace, B, T, V, Lmax, blank, zero_infinity);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// out = g * (*s) * mul    (upstream scalar gradient applied to the saved CTC gradient)
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ g, const float* __restrict__ s, float mul, float* __restrict__ out, long long n) {
+  const float f = (s ? *s : 1.f) * mul;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = g[i] * f;
+}
+extern "C" int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t st) {
+  AVEC_CHECK_ARG(g && out && n > 0, "scale_by_scalar: bad arguments");
+  long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, scalar_dev, mul, out, n);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// argmax over the last dim (greedy CTC decoding, nnet/decoders.py:97-120): first maximal index, like torch.argmax
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long long* __restrict__ out, long long M, int V) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) { const float z = x[row * V + v]; if (z > best || (z == best && v < bi)) { best = z; bi = v; } }
+  for (int o = 32; o > 0; o >>= 1) { const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64); if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
+  if (lane == 0) out[row] = bi;
+}
+extern "C" int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStream_t st) {
+  AVEC_CHECK_ARG(x && out && M > 0 && V > 0, "argmax_rows: bad arguments");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, out, M, V);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over the flat fp32 arenas.  state[0] = step (float, already incremented by the host scheduler mirror), state[1] = lr.
+// g <- g*gscale; g += wd*p; m,v updates; p -= lr * mhat / (sqrt(v)/sqrt(bc2) + eps);  optionally zero the gradient arena.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ state,
+                                                   float beta1, float beta2, float eps, float wd, float gscale, int zero_grad, long long n4) {
+  const float step = state[0], lr = state[1];
+  const float bc1 = 1.f - powf(beta1, step), bc2s = sqrtf(1.f - powf(beta2, step));
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float pp[4], gg[4], mm[4], vv[4]; ld4<float>(p + i * 4, pp); ld4<float>(g + i * 4, gg); ld4<float>(m + i * 4, mm); ld4<float>(v + i * 4, vv);
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale + wd * pp[e];
+      mm[e] = mm[e] + (1.f - beta1) * (gr - mm[e]);            // lerp, as torch's single-tensor Adam
+      vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[e]) / bc2s + eps;
+      pp[e] -= step_size * (mm[e] / denom);
+      gg[e] = 0.f;
+    }
+    st4<float>(p + i * 4, pp); st4<float>(m + i * 4, mm); st4<float>(v + i * 4, vv);
+    if (zero_grad) st4<float>(g + i * 4, gg);
+  }
+}
+extern "C" int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t st) {
+  AVEC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && state_dev && n > 0 && n % 4 == 0, "adam_step: bad arguments (n=%lld must be a multiple of 4)", n);
+  long long n4 = n / 4; long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, state_dev, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, n4);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shadow refresh: for every GEMM weight (master fp32, logical [A][Tm][C]) write
+//   fwd shadow  (act) = same order                         -> NT forward   (rows = A, K = Tm*C)
+//   bwd shadow  (act) [C][Tm][A] (axes 0 and 2 swapped)    -> NT backward-data (rows = C, K = Tm*A)
+// table entry (8 x int64): src_off, fwd_off (-1: none), bwd_off (-1: none), A, Tm, C, first_block, n_blocks
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ master, T* __restrict__ shadow, const long long* __restrict__ table, int n_entries) {
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (table[mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const long long* e = table + lo * 8;
+  const long long src = e[0], fwd = e[1], bwd = e[2]; const long long A = e[3], Tm = e[4], C = e[5];
+  const long long n = A * Tm * C; const long long base = ((long long)blockIdx.x - e[6]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i >= n) break;
+    if (fwd >= 0) stf(shadow + fwd + i, master[src + i]);
+    if (bwd >= 0) { const long long a = i % A; const long long r = i / A; const long long t = r % Tm; const long long c = r / Tm;
+      stf(shadow + bwd + i, master[src + (a * Tm + t) * C + c]); }
+  }
+}
+extern "C" int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t st) {
+  AVEC_CHECK_ARG(master && shadow && table_dev && n_entries > 0 && total_blocks > 0, "shadow_refresh: bad arguments");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(shadow_kernel<T>, dim3((unsigned)total_blocks), dim3(256), 0, st, master, (T*)shadow, table_dev, n_entries));
+  AVEC_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,443 @@
+// Normalisation / elementwise / reduction kernels (HBM-bound; 4-wide vector access, wave64 shuffles).
+//   LayerNorm fwd/bwd (wave per row), BatchNorm (channels-last) stats finalize / apply / backward,
+//   grad_prep (dropout+scale+cast+bias-grad), softmax fwd/bwd, casts, dropout, patch pool / unpool,
+//   global average pool.
+#include "common.h"
+#include "avec_hip.h"
+
+#include "vec.h"
+
+// =============================================================================================
+// LayerNorm: x fp32 [M][D]; one wave per row.   (nn.LayerNorm(eps=1e-6): nnet/modules.py:278,302,373; nnet/blocks.py:267)
+// =============================================================================================
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                     TO* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long long M, int D, float eps) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) { float v[4]; ld4<float>(xr + c, v); s += v[0] + v[1] + v[2] + v[3]; }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+  for (int c = lane * 4; c < D; c += 256) { float v[4]; ld4<float>(xr + c, v); for (int e = 0; e < 4; ++e) { float d = v[e] - mu; q += d * d; } }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  for (int c = lane * 4; c < D; c += 256) {
+    float v[4], gg[4], bb[4], o[4]; ld4<float>(xr + c, v); ld4<float>(g + c, gg); ld4<float>(b + c, bb);
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu) * rs * gg[e] + bb[e];
+    st4<TO>(y + row * D + c, o);
+  }
+}
+
+// dx (+)= LN backward; dgamma/dbeta accumulated with atomics (one partial per wave).
+template <typename TG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx, int accum,
+                                                     float* __restrict__ dg, float* __restrict__ db, long long M, int D) {
+  const int lane = threadIdx.x & 63; const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6); const int nwaves = gridDim.x * 4;
+  // D <= 1536: each lane owns up to 6 groups of 4 columns
+  float pg[6][4], pb[6][4];
+  for (int i = 0; i < 6; ++i) for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
+  for (long long row = wave_id; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int c = lane * 4 + i * 256; if (c >= D) break;
+      float d[4], v[4], gg[4]; ld4<TG>(dy + row * D + c, d); ld4<float>(x + row * D + c, v); ld4<float>(g + c, gg);
+      for (int e = 0; e < 4; ++e) { float xh = (v[e] - mu) * rs; float t = d[e] * gg[e]; s1 += t; s2 += t * xh; pg[i][e] += d[e] * xh; pb[i][e] += d[e]; }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int c = lane * 4 + i * 256; if (c >= D) break;
+      float d[4], v[4], gg[4], o[4]; ld4<TG>(dy + row * D + c, d); ld4<float>(x + row * D + c, v); ld4<float>(g + c, gg);
+      if (accum) ld4<float>(dx + row * D + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+      for (int e = 0; e < 4; ++e) { float xh = (v[e] - mu) * rs; o[e] += rs * (d[e] * gg[e] - s1 - xh * s2); }
+      st4<float>(dx + row * D + c, o);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int c = lane * 4 + i * 256; if (c >= D) break;
+    for (int e = 0; e < 4; ++e) { atomicAdd(dg + c + e, pg[i][e]); atomicAdd(db + c + e, pb[i][e]); }
+  }
+}
+
+extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int y_f32,
+                                  float* mean, float* rstd, long long M, int D, float eps, hipStream_t st) {
+  AVEC_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0, "layernorm_fwd: D=%d must be a positive multiple of 4", D);
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (y_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+  else hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, int dx_accum, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
+  AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
+  long long nb = (M + 3) / 4; if (nb > 512) nb = 512;
+  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, x, mean, rstd, gamma, dx, dx_accum, dgamma, dbeta, M, D);
+  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dx_accum, dgamma, dbeta, M, D);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// =============================================================================================
+// grad_prep: dacc[m][n] = alpha * dropmask * dout[m][n]   (fp32 -> act)   and   dbias[n] += sum_m dacc
+//   backward of   out = res + alpha * Dropout(acc + bias)   (nnet/blocks.py:292-301, nnet/modules.py:286-288)
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void grad_prep_kernel(const float* __restrict__ dout, long long ldd, T* __restrict__ dacc, float alpha, float p,
+                                                        const unsigned long long* rng, unsigned stream, float* dbias, long long M, int N) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + tx) * 4;
+  float part[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+  if (col < N) {
+    for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
+      float v[4]; ld4<float>(dout + row * ldd + col, v);
+      for (int e = 0; e < 4; ++e) { v[e] *= alpha * drop_scale(rng, stream, (unsigned long long)row * N + col + e, p); part[0][e] += v[e]; }
+      st4<T>(dacc + row * N + col, v);
+    }
+  }
+  float* const dst[1] = {dbias};
+  colreduce_atomic<1>(part, dst, col, N);
+}
+
+extern "C" int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
+                              unsigned rng_stream, float* dbias, long long M, int N, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && dacc && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "grad_prep: bad arguments (N=%d ld=%lld)", N, ld);
+  AVEC_CHECK_ARG(!(drop_p > 0.f) || rng, "grad_prep: dropout without rng");
+  dim3 grid = col_grid(M, N);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_kernel<T>, grid, dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, dbias, M, N));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// column sums of an act matrix:  out[n] += sum_m x[m][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, long long M, int N) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
+  float part[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+  if (col < N) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
+    float v[4]; ld4<T>(x + row * N + col, v); for (int e = 0; e < 4; ++e) part[0][e] += v[e];
+  }
+  float* const dst[1] = {out};
+  colreduce_atomic<1>(part, dst, col, N);
+}
+extern "C" int avec_colsum(int dtype, const void* x, float* out, long long M, int N, hipStream_t st) {
+  AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0, "colsum: bad arguments");
+  dim3 grid = col_grid(M, N);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, M, N));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// =============================================================================================
+// BatchNorm over channels-last [M][C]   (nnet/normalizations.py:42-170; SyncBatchNorm :172-249 when the
+// caller all-reduces `stats` across ranks between the statistics pass and bn_finalize)
+//   ss = [scale | shift | mean | rstd], each [C]
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, float* stats, long long M, int C) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
+  float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (col < C) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
+    float v[4]; ld4<T>(y + row * C + col, v); for (int e = 0; e < 4; ++e) { part[0][e] += v[e]; part[1][e] += v[e] * v[e]; }
+  }
+  float* const dst[2] = {stats, stats + C};
+  colreduce_atomic<2>(part, dst, col, C);
+}
+extern "C" int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(y && stats && M > 0 && C > 0 && C % 4 == 0, "bn_stats: bad arguments");
+  dim3 grid = col_grid(M, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), 0, st, (const T*)y, stats, M, C));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+__global__ void bn_finalize_kernel(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   long long* nbt, float momentum, float eps, float* ss, int C, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    const float n = count_ptr ? *count_ptr : count;
+    mean = stats[c] / n; var = fmaxf(stats[C + c] / n - mean * mean, 0.f);
+    if (rmean) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+      if (c == 0 && nbt) *nbt += 1;
+    }
+  } else { mean = rmean[c]; var = rvar[c]; }
+  const float rs = rsqrtf(var + eps);
+  ss[c] = gamma[c] * rs; ss[C + c] = beta[c] - mean * gamma[c] * rs; ss[2 * C + c] = mean; ss[3 * C + c] = rs;
+}
+extern "C" int avec_bn_finalize(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t st) {
+  AVEC_CHECK_ARG(gamma && beta && ss && C > 0 && (training ? (stats != nullptr) : (running_mean && running_var)), "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, count_ptr, count, gamma, beta, running_mean, running_var,
+                     num_batches_tracked, momentum, eps, ss, C, training);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// out = act(y*scale + shift (+ residual))
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,
+                                                       T* __restrict__ out, long long n4, int C) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long off = i * 4; const int c = (int)(off % C);
+    float v[4], sc[4], sh[4]; ld4<T>(y + off, v); ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh);
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (res) { float r[4]; ld4<T>(res + off, r); for (int e = 0; e < 4; ++e) v[e] += r[e]; }
+    if (act == 1) { for (int e = 0; e < 4; ++e) v[e] = swishf_(v[e]); } else if (act == 2) { for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f); }
+    st4<T>(out + off, v);
+  }
+}
+extern "C" int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(y && ss && out && M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: bad arguments");
+  long long n4 = M * C / 4; long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, act, (T*)out, n4, C));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// dr = dout * act'(.)   (ReLU: mask from saved output `out`; Swish: from pre = y*scale+shift)
+template <typename T>
+__device__ __forceinline__ void bn_dr(const T* dout, const T* y, const T* out, const float* ss, int act, long long off, int c, int C, float dr[4], float yh[4]) {
+  float d[4], v[4], mu[4], rs[4]; ld4<T>(dout + off, d); ld4<T>(y + off, v); ld4<float>(ss + 2 * C + c, mu); ld4<float>(ss + 3 * C + c, rs);
+  for (int e = 0; e < 4; ++e) yh[e] = (v[e] - mu[e]) * rs[e];
+  if (act == 2) { float o[4]; ld4<T>(out + off, o); for (int e = 0; e < 4; ++e) dr[e] = o[e] > 0.f ? d[e] : 0.f; }
+  else if (act == 1) { float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh); for (int e = 0; e < 4; ++e) dr[e] = d[e] * dswishf_(v[e] * sc[e] + sh[e]); }
+  else { for (int e = 0; e < 4; ++e) dr[e] = d[e]; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
+                                                            int act, float* dstats, long long M, int C) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
+  float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (col < C) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
+    float dr[4], yh[4]; bn_dr<T>(dout, y, out, ss, act, row * C + col, col, C, dr, yh);
+    for (int e = 0; e < 4; ++e) { part[0][e] += dr[e]; part[1][e] += dr[e] * yh[e]; }
+  }
+  float* const dst[2] = {dstats, dstats + C};
+  colreduce_atomic<2>(part, dst, col, C);
+}
+extern "C" int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && y && ss && dstats && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
+  dim3 grid = col_grid(M, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+// dy = gamma*rstd*(dr - mean(dr) - yhat*mean(dr*yhat)); optional dres = dr; block 0 adds dgamma/dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count, int act,
+                                                           T* __restrict__ dy, T* __restrict__ dres, float* dgamma, float* dbeta, long long n4, int C) {
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long off = i * 4; const int c = (int)(off % C);
+    float dr[4], yh[4], g[4], rs[4], s1[4], s2[4], o[4];
+    bn_dr<T>(dout, y, out, ss, act, off, c, C, dr, yh);
+    ld4<float>(gamma + c, g); ld4<float>(ss + 3 * C + c, rs); ld4<float>(dstats + c, s1); ld4<float>(dstats + C + c, s2);
+    for (int e = 0; e < 4; ++e) o[e] = g[e] * rs[e] * (dr[e] - s1[e] * inv_n - yh[e] * s2[e] * inv_n);
+    st4<T>(dy + off, o);
+    if (dres) st4<T>(dres + off, dr);
+  }
+}
+extern "C" int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
+                                 const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && y && ss && gamma && dstats && dy && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+  long long n4 = M * C / 4; long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, gamma, dstats,
+                                       count_ptr, count, act, (T*)dy, (T*)dres, dgamma, dbeta, n4, C));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// =============================================================================================
+// softmax over the last dim (InterCTC residual, nnet/modules.py:395-400): logits fp32 -> probs act
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, T* __restrict__ p, long long M, int V) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[row * V + c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(x[row * V + c] - mx);
+  s = 1.f / wave_sum(s);
+  for (int c = lane; c < V; c += 64) stf(p + row * V + c, __expf(x[row * V + c] - mx) * s);
+}
+// dlogits (+)= p * (dp - sum(dp*p));  probabilities recomputed from the fp32 logits
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ dp, const float* __restrict__ x, float* __restrict__ dx, int accum, long long M, int V) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, x[row * V + c]);
+  mx = wave_max(mx);
+  float s = 0.f, dot = 0.f;
+  for (int c = lane; c < V; c += 64) { float e = __expf(x[row * V + c] - mx); s += e; dot += e * ldf(dp + row * V + c); }
+  s = wave_sum(s); dot = wave_sum(dot) / s;
+  for (int c = lane; c < V; c += 64) {
+    float pr = __expf(x[row * V + c] - mx) / s; float g = pr * (ldf(dp + row * V + c) - dot);
+    dx[row * V + c] = accum ? dx[row * V + c] + g : g;
+  }
+}
+extern "C" int avec_softmax_fwd(int dtype, const float* logits, void* probs, long long M, int V, hipStream_t st) {
+  AVEC_CHECK_ARG(logits && probs && M > 0 && V > 0, "softmax_fwd: bad arguments");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, logits, (T*)probs, M, V));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, int accum, long long M, int V, hipStream_t st) {
+  AVEC_CHECK_ARG(dprobs && logits && dlogits && M > 0 && V > 0, "softmax_bwd: bad arguments");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)dprobs, logits, dlogits, accum, M, V));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// =============================================================================================
+// casts / copies / dropout on the fp32 stream
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, long long lds_, T* __restrict__ dst, long long ldd, long long M, int N) {
+  const long long n4 = M * (N / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long row = i / (N / 4); const int c = (int)(i % (N / 4)) * 4;
+    float v[4]; ld4<float>(src + row * lds_ + c, v); st4<T>(dst + row * ldd + c, v);
+  }
+}
+extern "C" int avec_cast_rows(int dtype, const float* src, long long ld_src, void* dst, long long ld_dst, long long M, int N, hipStream_t st) {
+  AVEC_CHECK_ARG(src && dst && M > 0 && N > 0 && N % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "cast_rows: bad arguments");
+  long long nb = (M * (N / 4) + 255) / 256; if (nb > 4096) nb = 4096;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_rows_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, src, ld_src, (T*)dst, ld_dst, M, N));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void to_f32_rows_kernel(const T* __restrict__ src, long long lds_, float* __restrict__ dst, long long ldd, long long M, int N, int accum) {
+  const long long n4 = M * (N / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long row = i / (N / 4); const int c = (int)(i % (N / 4)) * 4;
+    float v[4]; ld4<T>(src + row * lds_ + c, v);
+    if (accum) { float o[4]; ld4<float>(dst + row * ldd + c, o); for (int e = 0; e < 4; ++e) v[e] += o[e]; }
+    st4<float>(dst + row * ldd + c, v);
+  }
+}
+extern "C" int avec_to_f32_rows(int dtype, const void* src, long long ld_src, float* dst, long long ld_dst, long long M, int N, int accum, hipStream_t st) {
+  AVEC_CHECK_ARG(src && dst && M > 0 && N > 0 && N % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "to_f32_rows: bad arguments");
+  long long nb = (M * (N / 4) + 255) / 256; if (nb > 4096) nb = 4096;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(to_f32_rows_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)src, ld_src, dst, ld_dst, M, N, accum));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, float p, const unsigned long long* rng, unsigned stream, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * drop_scale(rng, stream, (unsigned long long)i, p);
+}
+extern "C" int avec_dropout_f32(const float* x, float* y, float p, const unsigned long long* rng, unsigned rng_stream, long long n, hipStream_t st) {
+  AVEC_CHECK_ARG(x && y && n > 0 && rng, "dropout_f32: bad arguments");
+  long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, y, p, rng, rng_stream, n);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
+// =============================================================================================
+// patch attention helpers (nnet/attentions.py:348-382): avg-pool by P with zero padding (divisor P),
+// nearest up-sample x P sliced to T fused with dropout + residual add.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void patch_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Tn, int D, int P, int Tp) {
+  const long long n4 = (long long)B * Tp * (D / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (D / 4)) * 4; const long long r = i / (D / 4); const int tp = (int)(r % Tp); const int b = (int)(r / Tp);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < P; ++k) { int t = tp * P + k; if (t < Tn) { float v[4]; ld4<T>(x + ((long long)b * Tn + t) * D + c, v); for (int e = 0; e < 4; ++e) a[e] += v[e]; } }
+    for (int e = 0; e < 4; ++e) a[e] /= P;
+    st4<T>(y + r * D + c, a);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void patch_pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Tn, int D, int P, int Tp) {
+  const long long n4 = (long long)B * Tn * (D / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (D / 4)) * 4; const long long r = i / (D / 4); const int t = (int)(r % Tn); const int b = (int)(r / Tn);
+    float v[4]; ld4<T>(dy + ((long long)b * Tp + t / P) * D + c, v); for (int e = 0; e < 4; ++e) v[e] /= P;
+    st4<T>(dx + r * D + c, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void patch_unpool_add_kernel(const T* __restrict__ o, const float* __restrict__ res, float* __restrict__ out, float p,
+                                                               const unsigned long long* rng, unsigned stream, int B, int Tn, int D, int P, int Tp) {
+  const long long n4 = (long long)B * Tn * (D / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (D / 4)) * 4; const long long r = i / (D / 4); const int t = (int)(r % Tn); const int b = (int)(r / Tn);
+    float v[4], q[4]; ld4<T>(o + ((long long)b * Tp + t / P) * D + c, v); ld4<float>(res + r * D + c, q);
+    for (int e = 0; e < 4; ++e) q[e] += v[e] * drop_scale(rng, stream, (unsigned long long)r * D + c + e, p);
+    st4<float>(out + r * D + c, q);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void patch_unpool_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dob, float p, const unsigned long long* rng, unsigned stream,
+                                                               int B, int Tn, int D, int P, int Tp) {
+  const long long n4 = (long long)B * Tp * (D / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (D / 4)) * 4; const long long r = i / (D / 4); const int tp = (int)(r % Tp); const int b = (int)(r / Tp);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < P; ++k) {
+      int t = tp * P + k; if (t >= Tn) break;
+      const long long rr = (long long)b * Tn + t; float v[4]; ld4<float>(dout + rr * D + c, v);
+      for (int e = 0; e < 4; ++e) a[e] += v[e] * drop_scale(rng, stream, (unsigned long long)rr * D + c + e, p);
+    }
+    st4<T>(dob + r * D + c, a);
+  }
+}
+#define PATCH_LAUNCH(kern, total, ...) do { long long nb = ((total) + 255) / 256; if (nb > 4096) nb = 4096; if (nb < 1) nb = 1; \
+  DISPATCH_T(dtype, hipLaunchKernelGGL(kern<T>, dim3((unsigned)nb), dim3(256), 0, st, __VA_ARGS__)); AVEC_LAUNCH_CHECK(); return 0; } while (0)
+extern "C" int avec_patch_pool_fwd(int dtype, const void* x, void* y, int B, int T_, int D, int P, hipStream_t st) {
+  AVEC_CHECK_ARG(x && y && B > 0 && T_ > 0 && D % 4 == 0 && P > 0, "patch_pool_fwd: bad arguments"); const int Tp = (T_ + P - 1) / P;
+  PATCH_LAUNCH(patch_pool_fwd_kernel, (long long)B * Tp * (D / 4), (const T*)x, (T*)y, B, T_, D, P, Tp);
+}
+extern "C" int avec_patch_pool_bwd(int dtype, const void* dy, void* dx, int B, int T_, int D, int P, hipStream_t st) {
+  AVEC_CHECK_ARG(dy && dx && B > 0 && T_ > 0 && D % 4 == 0 && P > 0, "patch_pool_bwd: bad arguments"); const int Tp = (T_ + P - 1) / P;
+  PATCH_LAUNCH(patch_pool_bwd_kernel, (long long)B * T_ * (D / 4), (const T*)dy, (T*)dx, B, T_, D, P, Tp);
+}
+extern "C" int avec_patch_unpool_add(int dtype, const void* o, const float* res, float* out, float drop_p, const unsigned long long* rng, unsigned rng_stream,
+                                     int B, int T_, int D, int P, hipStream_t st) {
+  AVEC_CHECK_ARG(o && res && out && B > 0 && T_ > 0 && D % 4 == 0 && P > 0 && (drop_p <= 0.f || rng), "patch_unpool_add: bad arguments"); const int Tp = (T_ + P - 1) / P;
+  PATCH_LAUNCH(patch_unpool_add_kernel, (long long)B * T_ * (D / 4), (const T*)o, res, out, drop_p, rng, rng_stream, B, T_, D, P, Tp);
+}
+extern "C" int avec_patch_unpool_bwd(int dtype, const float* dout, void* dob, float drop_p, const unsigned long long* rng, unsigned rng_stream,
+                                     int B, int T_, int D, int P, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && dob && B > 0 && T_ > 0 && D % 4 == 0 && P > 0 && (drop_p <= 0.f || rng), "patch_unpool_bwd: bad arguments"); const int Tp = (T_ + P - 1) / P;
+  PATCH_LAUNCH(patch_unpool_bwd_kernel, (long long)B * Tp * (D / 4), dout, (T*)dob, drop_p, rng, rng_stream, B, T_, D, P, Tp);
+}
+
+// =============================================================================================
+// global average pool over HW (nnet/layers.py:1328-1342), channels-last [N][HW][C] -> [N][C]
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long N, int HW, int C) {
+  const long long n4 = N * (C / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (C / 4)) * 4; const long long n = i / (C / 4);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < HW; ++s) { float v[4]; ld4<T>(x + (n * HW + s) * C + c, v); for (int e = 0; e < 4; ++e) a[e] += v[e]; }
+    for (int e = 0; e < 4; ++e) a[e] /= HW;
+    st4<T>(y + n * C + c, a);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, long long N, int HW, int C) {
+  const long long n4 = N * HW * (C / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (C / 4)) * 4; const long long r = i / (C / 4); const long long n = r / HW;
+    float v[4]; ld4<T>(dy + n * C + c, v); for (int e = 0; e < 4; ++e) v[e] /= HW;
+    st4<T>(dx + r * C + c, v);
+  }
+}
+extern "C" int avec_avgpool_fwd(int dtype, const void* x, void* y, long long N, int HW, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(x && y && N > 0 && HW > 0 && C % 4 == 0, "avgpool_fwd: bad arguments");
+  PATCH_LAUNCH(avgpool_fwd_kernel, N * (C / 4), (const T*)x, (T*)y, N, HW, C);
+}
+extern "C" int avec_avgpool_bwd(int dtype, const void* dy, void* dx, long long N, int HW, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dy && dx && N > 0 && HW > 0 && C % 4 == 0, "avgpool_bwd: bad arguments");
+  PATCH_LAUNCH(avgpool_bwd_kernel, N * HW * (C / 4), (const T*)dy, (T*)dx, N, HW, C);
+}

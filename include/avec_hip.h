@@ -1,0 +1,169 @@
+/* libavec_hip.so -- C ABI of the MI355X (gfx950) hot path for the AV Efficient Conformer.
+ *
+ * Drop-in boundary: the reference reaches its native code through
+ * PyTorch ops emitted by `nn.Module.forward` of the classes registered in
+ *   nnet/layers.py:1372-1396 (layer_dict), nnet/attentions.py:739-746 (att_dict),
+ *   nnet/normalizations.py:306-316 (norm_dict), nnet/activations.py:71-82 (act_dict),
+ *   nnet/blocks.py:312-314 (block_dict), nnet/losses.py:363-366 (loss_dict),
+ *   nnet/optimizers.py:184-189 (optim_dict).
+ * Each entry point below replaces the ATen op group one of those forwards (or its autograd
+ * backward) dispatches; the reference file:line it stands in for is cited per function.
+ *
+ * Conventions
+ *   - plain C symbols, raw device pointers, explicit sizes; no torch types.
+ *   - the library never allocates, frees or retains device memory; outputs/workspaces are the
+ *     caller's.  Every launch goes to the `hipStream_t` argument, asynchronously (graph-capture safe).
+ *   - return 0 on success, <0 for argument errors, >0 = hipError_t; text via avec_last_error().
+ *   - `dtype`: AVEC_F32 (0) = fp32 storage + fp32 MFMA (exact; parity mode),
+ *              AVEC_BF16 (1) = bf16 storage + bf16 MFMA with fp32 accumulate (throughput mode).
+ *     "act" below means a buffer of that dtype; `float*` buffers are fp32 in both modes
+ *     (residual stream, statistics, parameters' gradients).
+ */
+#ifndef AVEC_HIP_H
+#define AVEC_HIP_H
+#include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVEC_F32 0
+#define AVEC_BF16 1
+#define AVEC_ABI_VERSION 1
+
+int avec_version(void);
+const char* avec_last_error(void);
+
+/* ---- row sources for the GEMM family ------------------------------------------------------ */
+enum { AVEC_ROWS_PLAIN = 0, AVEC_ROWS_CONV_FWD = 1, AVEC_ROWS_CONV_BWD = 2, AVEC_ROWS_STEM3D = 3 };
+typedef struct avec_rows {
+  long long ld;                 /* PLAIN: row stride (elements) */
+  int rows_out, rows_in, step;  /* PLAIN: src_row = (m / rows_out) * rows_in + (m % rows_out) * step when step > 1
+                                   (strided time sub-sampling: the k=1 stride-2 conv_res, nnet/blocks.py:273-277) */
+  int H, W, C, KH, KW, stride, pad, OH, OW; /* CONV_*: NHWC geometry; explicit "same" zero padding of nnet/layers.py:250-261 is folded into the loader */
+  int T3;                       /* STEM3D: frames per clip (Conv3d (5,7,7) stride (1,2,2), nnet/networks.py:460-469) */
+} avec_rows_t;
+
+typedef struct avec_epilogue {
+  void* out; long long ldo; int out_f32;       /* final output: act, or fp32 when out_f32 */
+  void* out_pre; long long ldpre;              /* optional: value before activation (act) */
+  const float* bias;                           /* [N] */
+  int act;                                     /* 0 none, 1 Swish (nnet/activations.py:39-45), 2 ReLU */
+  float drop_p; const unsigned long long* rng; unsigned rng_stream;  /* nn.Dropout: counter-based mask, rng = {seed, step} on device */
+  const float* res; long long ldres; float alpha;   /* out = res + alpha * v   (residual connections, nnet/blocks.py:292-301) */
+  const void* dact_z; long long ldz; int dact; /* backward: v *= act'(z) */
+  float* colsum;                               /* += per-column sum of v  (bias gradients) */
+  float* stats;                                /* += [N] sum, [N] sum of squares (BatchNorm batch statistics) */
+} avec_epilogue_t;
+
+/* C[m][n] = epi(sum_k A[m][k] W[n][k]).  Replaces aten::addmm/mm of layers.Linear.forward (nnet/layers.py:64-76),
+ * the k=1 Conv1d of nnet/modules.py:374,379, aten::convolution / convolution_backward(input) of layers.Conv2d
+ * (nnet/layers.py:200-324) and the Conv3d stem (nnet/layers.py:326-503). */
+int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows, int a_mode, int a_f32,
+                 const void* W, long long ldw, long long M, int N, int K,
+                 const avec_epilogue_t* ep, hipStream_t stream);
+
+/* O[i][j] += sum_m P[m][i] Q[m][j]  (fp32 atomics, split over m).  Replaces the weight-gradient aten::mm of
+ * Linear backward and convolution_backward(weight). */
+int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
+                 float* O, long long ldo, long long M, int I, int J, hipStream_t stream);
+
+/* ---- normalisation / elementwise (avec_amd/csrc/norm.hip) ---------------------------------- */
+/* nn.LayerNorm(eps=1e-6) forward/backward: aten::native_layer_norm(_backward) emitted by nnet/modules.py:278,302,373
+ * and nnet/blocks.py:267.  x fp32 [M][D]; y act or fp32; dx optionally accumulated (residual merge). */
+int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int y_f32,
+                       float* mean, float* rstd, long long M, int D, float eps, hipStream_t stream);
+int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, int dx_accum, float* dgamma, float* dbeta, long long M, int D, hipStream_t stream);
+/* backward of out = res + alpha*Dropout(acc + bias): dacc (act) and dbias; nnet/modules.py:286-288 + nnet/blocks.py:292-301 */
+int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
+                   unsigned rng_stream, float* dbias, long long M, int N, hipStream_t stream);
+int avec_colsum(int dtype, const void* x, float* out, long long M, int N, hipStream_t stream);
+/* BatchNorm{1,2,3}d over channels-last [M][C] (aten::native_batch_norm(_backward), nnet/normalizations.py:42-170).
+ * stats = [sum | sumsq]; ss = [scale | shift | mean | rstd]; SyncBatchNorm (:172-249) = all-reduce stats/count/dstats between calls. */
+int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t stream);
+int avec_bn_finalize(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t stream);
+int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t stream);
+int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t stream);
+int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
+                      const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t stream);
+/* softmax of the InterCTC residual (nnet/modules.py:395-400) */
+int avec_softmax_fwd(int dtype, const float* logits, void* probs, long long M, int V, hipStream_t stream);
+int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, int accum, long long M, int V, hipStream_t stream);
+int avec_cast_rows(int dtype, const float* src, long long ld_src, void* dst, long long ld_dst, long long M, int N, hipStream_t stream);
+int avec_to_f32_rows(int dtype, const void* src, long long ld_src, float* dst, long long ld_dst, long long M, int N, int accum, hipStream_t stream);
+int avec_dropout_f32(const float* x, float* y, float p, const unsigned long long* rng, unsigned rng_stream, long long n, hipStream_t stream);
+/* patch attention pooling (layers.AvgPool1d / Upsample, nnet/attentions.py:342-346,365-380) */
+int avec_patch_pool_fwd(int dtype, const void* x, void* y, int B, int T, int D, int P, hipStream_t stream);
+int avec_patch_pool_bwd(int dtype, const void* dy, void* dx, int B, int T, int D, int P, hipStream_t stream);
+int avec_patch_unpool_add(int dtype, const void* o, const float* res, float* out, float drop_p, const unsigned long long* rng, unsigned rng_stream,
+                          int B, int T, int D, int P, hipStream_t stream);
+int avec_patch_unpool_bwd(int dtype, const float* dout, void* dob, float drop_p, const unsigned long long* rng, unsigned rng_stream,
+                          int B, int T, int D, int P, hipStream_t stream);
+/* layers.GlobalAvgPool2d (nnet/layers.py:1328-1342), channels-last */
+int avec_avgpool_fwd(int dtype, const void* x, void* y, long long N, int HW, int C, hipStream_t stream);
+int avec_avgpool_bwd(int dtype, const void* dy, void* dx, long long N, int HW, int C, hipStream_t stream);
+
+/* ---- conformer convolution module middle (avec_amd/csrc/convmod.hip) ----------------------- */
+/* nn.GLU(dim=-1) + depthwise layers.Conv1d(k, groups=C, stride, "same") (nnet/modules.py:375-376); w is tap-major [K][C]. */
+int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
+                        int B, int T, int C, int K, int stride, hipStream_t stream);
+int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
+                        int B, int T, int C, int K, int stride, hipStream_t stream);
+
+/* ---- attention (avec_amd/csrc/attention.hip) ------------------------------------------------ */
+typedef struct avec_attn {
+  const void *q, *k, *v; long long ld;        /* act [B*T][ld]; head h = columns [h*d,(h+1)*d) */
+  const void* e; long long lde;               /* act [2T-1][lde]: pos_layer(sinusoid rows p = T-1 .. -(T-1)) (nnet/embeddings.py:101-158) */
+  const long long* lens; int len_div;         /* key j kept iff j < lens[b]/len_div (Mask.padding_mask, nnet/attentions.py:682-733; patch min-pool :357-362) */
+  const float* mask; long long mask_bstride;  /* optional dense (Bm,T,T) 0/1 mask (1 = keep) instead of lens */
+  void* o; long long ldo; float* lse;         /* outputs: act [B*T][ldo], fp32 [B*H][T] */
+  const void* dout;                           /* backward input, act [B*T][ldo] */
+  void *dq, *dk, *dv; long long lddq, ldd;    /* dq act (stride lddq); dk/dv act (T<=64) or fp32 scratch (stride ldd) */
+  float* de; long long ldde;                  /* fp32 [2T-1][ldde], accumulated */
+  int B, H, T, d; float scale;
+} avec_attn_t;
+/* RelPos1dMultiHeadAttention.forwardQKV core (nnet/attentions.py:299-315): bmm + rel_to_abs + mask + softmax + bmm */
+int avec_relpos_attention_fwd(int dtype, const avec_attn_t* args, hipStream_t stream);
+int avec_relpos_attention_bwd(int dtype, const avec_attn_t* args, int dkv_f32, hipStream_t stream);
+
+/* ---- front-ends (avec_amd/csrc/frontend.hip) ------------------------------------------------ */
+/* AudioPreprocessing (nnet/preprocessing.py:57-85; torchaudio Spectrogram/MelScale restated): frames -> [DFT via avec_gemm_nt fp32] -> power/mel/log */
+int avec_mel_frames(const float* audio, const float* window, float* frames, int B, long long L, int n_fft, int win, int hop, hipStream_t stream);
+int avec_mel_power_log(const float* spec, const float* fb, float* out, int B, int F, int n_bins, int n_mels, hipStream_t stream);
+/* SpecAugment (nnet/preprocessing.py:115-130) */
+int avec_specaugment(float* mel, const long long* lens, int B, int n_mels, int F, int mF, int Fparam, int mT, float pS,
+                     const unsigned long long* rng, unsigned rng_stream, hipStream_t stream);
+/* audio stem Conv2d(1->C,3x3,s2,"same")+BatchNorm2d+Swish (nnet/networks.py:359-368) in (B,T',C*F') layout */
+int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float* w, const float* bias, void* y, float* stats, int B, int n_mels, int F, int C, hipStream_t stream);
+int avec_audio_stem_act_fwd(int dtype, const void* y, const float* ss, void* a, int B, int n_mels, int F, int C, hipStream_t stream);
+int avec_audio_stem_bwd(int dtype, const void* da, const void* y, const float* mel, const float* ss, const float* gamma, float* dstats,
+                        const float* count_ptr, float count, int phase, float* dw, float* dbias, float* dgamma, float* dbeta,
+                        int B, int n_mels, int F, int C, hipStream_t stream);
+/* BatchNorm3d+ReLU+MaxPool3d((1,3,3),(1,2,2),"same") after the Conv3d stem (nnet/networks.py:459-470, nnet/layers.py:839-915) */
+int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t stream);
+int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
+                       const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t stream);
+
+/* ---- loss / optimizer (avec_amd/csrc/loss_optim.hip) ---------------------------------------- */
+/* CTCLoss.forward (nnet/losses.py:311-334): per-utterance -log p, batch mean, and d/dlogits (unscaled) */
+long long avec_ctc_workspace_floats(int B, int T, int Lmax);
+int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
+                  float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
+int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t stream);
+/* CTCGreedySearchDecoder argmax (nnet/decoders.py:97-120) */
+int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStream_t stream);
+/* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */
+int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t stream);
+int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVEC_HIP_H */
