@@ -1,0 +1,5 @@
+"""avec_amd: MI355X-native (gfx950) hot path for the Audio-Visual Efficient Conformer.
+   csrc/   HIP kernels + C ABI (include/avec_hip.h)        lib.py     ctypes binding (no fallback)
+   ops.py  launchers + fused autograd Functions            runtime.py dtype / RNG / weight shadows / flat parameter arena
+   nnet/   host-side mirror of the reference's nnet API"""
+from .runtime import compute_dtype, manual_seed, set_compute_dtype  # noqa: F401

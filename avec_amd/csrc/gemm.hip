@@ -114,7 +114,7 @@ __device__ __forceinline__ chunk16 fetch_chunk(const RowSrc& s, const RowInfo& r
     return out;
   }
   const T* p = (const T*)s.ptr + off;
-  if (k + VEC <= K) return ldg16(p);
+  if (k + VEC <= K && (sizeof(T) == 4 || ((off & 1) == 0))) return ldg16(p);   // vector path needs dword alignment
   if (sizeof(T) == 4) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) if (k + e < K) out.w[e] = ((const uint32_t*)p)[e];
@@ -131,7 +131,7 @@ struct Epi {
   const float* bias;
   int act;                         // 0 none, 1 swish, 2 relu (forward activation)
   float drop_p; const unsigned long long* rng; unsigned stream;
-  const float* res; long long ldres; float alpha;
+  const void* res; long long ldres; float alpha; int res_act;
   const void* dact_z; long long ldz; int dact;   // multiply by act'(z) (1 swish, 2 relu)
   float* colsum;                   // += column sums of v (bias gradient)
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics)
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
         csum[c] += x; csq[c] += x * x;
         x *= e.alpha;
-        if (e.res) x += e.res[row * e.ldres + col + c];
+        if (e.res) x += e.res_act ? ldf((const T*)e.res + row * e.ldres + col + c) : ((const float*)e.res)[row * e.ldres + col + c];
         v[c] = x;
       }
       if (e.out_f32) {
@@ -430,7 +430,7 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   Epi& e = g.e;
   e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
   e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
-  e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
+  e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
   AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt: dropout without rng state");
   if (dtype == AVEC_BF16) launch_nt<bf16>(g, a_mode, a_f32, stream); else launch_nt<float>(g, a_mode, a_f32, stream);

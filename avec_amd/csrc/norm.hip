@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx (+)= LN backward; dgamma/dbeta accumulated with atomics (one partial per wave).
 template <typename TG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx, int accum,
+                                                     const float* __restrict__ rstd, const float* __restrict__ g, float* dx, const float* dres,
                                                      float* __restrict__ dg, float* __restrict__ db, long long M, int D) {
   const int lane = threadIdx.x & 63; const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6); const int nwaves = gridDim.x * 4;
   // D <= 1536: each lane owns up to 6 groups of 4 columns
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
     for (int i = 0; i < 6; ++i) {
       int c = lane * 4 + i * 256; if (c >= D) break;
       float d[4], v[4], gg[4], o[4]; ld4<TG>(dy + row * D + c, d); ld4<float>(x + row * D + c, v); ld4<float>(g + c, gg);
-      if (accum) ld4<float>(dx + row * D + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+      if (dres) ld4<float>(dres + row * D + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
       for (int e = 0; e < 4; ++e) { float xh = (v[e] - mu) * rs; o[e] += rs * (d[e] * gg[e] - s1 - xh * s2); }
       st4<float>(dx + row * D + c, o);
     }
@@ -76,12 +76,12 @@ extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma,
 }
 
 extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                  float* dx, int dx_accum, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
+                                  float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
   long long nb = (M + 3) / 4; if (nb > 512) nb = 512;
-  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, x, mean, rstd, gamma, dx, dx_accum, dgamma, dbeta, M, D);
-  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dx_accum, dgamma, dbeta, M, D);
+  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
+  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -117,19 +117,19 @@ extern "C" int avec_grad_prep(int dtype, const float* dout, long long ld, void* 
 
 // column sums of an act matrix:  out[n] += sum_m x[m][n]
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, long long M, int N) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long long ld, float* out, long long M, int N) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   float part[1][4] = {{0.f, 0.f, 0.f, 0.f}};
   if (col < N) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
-    float v[4]; ld4<T>(x + row * N + col, v); for (int e = 0; e < 4; ++e) part[0][e] += v[e];
+    float v[4]; ld4<T>(x + row * ld + col, v); for (int e = 0; e < 4; ++e) part[0][e] += v[e];
   }
   float* const dst[1] = {out};
   colreduce_atomic<1>(part, dst, col, N);
 }
-extern "C" int avec_colsum(int dtype, const void* x, float* out, long long M, int N, hipStream_t st) {
-  AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0, "colsum: bad arguments");
+extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t st) {
+  AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: bad arguments");
   dim3 grid = col_grid(M, N);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, M, N));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ld, out, M, N));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 }
 // dlogits (+)= p * (dp - sum(dp*p));  probabilities recomputed from the fp32 logits
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ dp, const float* __restrict__ x, float* __restrict__ dx, int accum, long long M, int V) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ dp, const float* __restrict__ x, float* dx, const float* dadd, long long M, int V) {
   const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float mx = -INFINITY;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   s = wave_sum(s); dot = wave_sum(dot) / s;
   for (int c = lane; c < V; c += 64) {
     float pr = __expf(x[row * V + c] - mx) / s; float g = pr * (ldf(dp + row * V + c) - dot);
-    dx[row * V + c] = accum ? dx[row * V + c] + g : g;
+    dx[row * V + c] = dadd ? dadd[row * V + c] + g : g;
   }
 }
 extern "C" int avec_softmax_fwd(int dtype, const float* logits, void* probs, long long M, int V, hipStream_t st) {
@@ -289,9 +289,9 @@ extern "C" int avec_softmax_fwd(int dtype, const float* logits, void* probs, lon
   DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, logits, (T*)probs, M, V));
   AVEC_LAUNCH_CHECK(); return 0;
 }
-extern "C" int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, int accum, long long M, int V, hipStream_t st) {
+extern "C" int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, const float* dadd, long long M, int V, hipStream_t st) {
   AVEC_CHECK_ARG(dprobs && logits && dlogits && M > 0 && V > 0, "softmax_bwd: bad arguments");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)dprobs, logits, dlogits, accum, M, V));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)dprobs, logits, dlogits, dadd, M, V));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -440,4 +440,21 @@ extern "C" int avec_avgpool_fwd(int dtype, const void* x, void* y, long long N, 
 extern "C" int avec_avgpool_bwd(int dtype, const void* dy, void* dx, long long N, int HW, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dy && dx && N > 0 && HW > 0 && C % 4 == 0, "avgpool_bwd: bad arguments");
   PATCH_LAUNCH(avgpool_bwd_kernel, N * HW * (C / 4), (const T*)dy, (T*)dx, N, HW, C);
+}
+
+// dx[b][t*step] += src[b][t]  (backward of the strided k=1 conv_res rows, nnet/blocks.py:273-277)
+__global__ __launch_bounds__(256) void strided_rows_add_kernel(float* __restrict__ dx, const float* __restrict__ src, int B, int Tn, int To, int D, int step) {
+  const long long n4 = (long long)B * To * (D / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % (D / 4)) * 4; const long long r = i / (D / 4); const int to = (int)(r % To); const long long b = r / To;
+    float v[4], o[4]; ld4<float>(src + r * D + c, v); float* dst = dx + (b * Tn + (long long)to * step) * D + c; ld4<float>(dst, o);
+    for (int e = 0; e < 4; ++e) o[e] += v[e];
+    st4<float>(dst, o);
+  }
+}
+extern "C" int avec_strided_rows_add(float* dx, const float* src, int B, int T_, int To, int D, int step, hipStream_t st) {
+  AVEC_CHECK_ARG(dx && src && B > 0 && T_ > 0 && To > 0 && D % 4 == 0 && step > 0 && (long long)(To - 1) * step < T_, "strided_rows_add: bad arguments");
+  long long n4 = (long long)B * To * (D / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(strided_rows_add_kernel, dim3((unsigned)nb), dim3(256), 0, st, dx, src, B, T_, To, D, step);
+  AVEC_LAUNCH_CHECK(); return 0;
 }

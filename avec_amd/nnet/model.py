@@ -1,0 +1,242 @@
+"""Training / evaluation harness (API of nnet/model.py).  Host-side Python like the reference; what differs is what a step launches:
+the forward/backward are fused HIP sequences, the optimizer is one launch over the flat arena, and data parallelism is one process per
+GPU exchanging the flat gradient buffer (and BatchNorm statistics) over RCCL -- no DistributedDataParallel wrapper, no per-step buffer
+broadcast."""
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from .. import runtime as rt
+from .decoders import decoder_dict
+from .losses import loss_dict
+from .metrics import metric_dict
+from .module import Module
+from .normalizations import SyncBatchNorm
+from .optimizers import optim_dict
+from .schedulers import ConstantScheduler, Scheduler
+
+
+class Model(Module):
+    def __init__(self, name="model"):
+        super().__init__()
+        self.is_distributed, self.rank, self.is_parallel = False, 0, False
+        self.compiled, self.built = False, False
+        self.name = name
+        self.ema_model, self.ema_tau, self.grad_max_norm = None, 0.0, None
+        self.arena = None
+        self.world_size = 1
+
+    # -- placement ------------------------------------------------------------------------------
+    def to(self, device):
+        out = super().to(device)
+        if self.device.type == "cuda":
+            self.arena = rt.ParamArena(self)
+            if self.compiled and hasattr(self.optimizer, "attach_arena"):
+                self.optimizer.attach_arena(self.arena)
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        if self.arena is not None:
+            self.arena.mark_dirty()
+        return out
+
+    def distribute_strategy(self, rank, sync_batch_norm=True):
+        """nnet/model.py:59-65.  Parameters/buffers are broadcast once from rank 0; afterwards each step all-reduces the flat gradient
+        arena (and, with sync_batch_norm, the BatchNorm statistic vectors)."""
+        import torch.distributed as dist
+        if sync_batch_norm:
+            SyncBatchNorm.convert_sync_batchnorm(self)
+        self.rank, self.is_distributed = rank, True
+        self.world_size = dist.get_world_size()
+        if self.arena is not None:
+            dist.broadcast(self.arena.master, 0)
+            self.arena.mark_dirty()
+        else:
+            for p in self.parameters():
+                dist.broadcast(p.data, 0)
+        for b in self.buffers():
+            if b.is_floating_point() or b.dtype == torch.int64:
+                dist.broadcast(b, 0)
+
+    def parallel_strategy(self):
+        raise RuntimeError("single-process DataParallel is a legacy path of the reference (nnet/model.py:67-69); use one process per GPU")
+
+    # -- compile / build (nnet/model.py:80-225) --------------------------------------------------
+    def compile(self, losses, loss_weights=None, optimizer="Adam", metrics=None, decoders=None):
+        self.optimizer = optim_dict[optimizer](params=self.parameters()) if isinstance(optimizer, str) else optimizer
+        self.model_step = self.optimizer.scheduler.model_step
+        self.compiled_losses = loss_dict[losses]() if isinstance(losses, str) else ([] if losses is None else losses)
+        if loss_weights is None:
+            self.compiled_loss_weights = ConstantScheduler(1.0)
+        elif isinstance(loss_weights, float):
+            self.compiled_loss_weights = ConstantScheduler(loss_weights)
+        else:
+            assert isinstance(loss_weights, (dict, list))
+            it = loss_weights.items() if isinstance(loss_weights, dict) else enumerate(loss_weights)
+            for k, v in list(it):
+                if not isinstance(v, Scheduler):
+                    loss_weights[k] = ConstantScheduler(v)
+            self.compiled_loss_weights = loss_weights
+        self.compiled_metrics = metric_dict[metrics]() if isinstance(metrics, str) else ([] if metrics is None else metrics)
+        self.compiled_decoders = decoder_dict[decoders]() if isinstance(decoders, str) else ([] if decoders is None else decoders)
+        self.compiled = True
+        if self.arena is not None and hasattr(self.optimizer, "attach_arena"):
+            self.optimizer.attach_arena(self.arena)
+
+    def build(self, outputs):
+        self.losses = self.map_to_outputs(outputs, self.compiled_losses)
+        self.loss_weights = self.map_to_outputs(outputs, self.compiled_loss_weights)
+        self.decoders = self.map_to_outputs(outputs, self.compiled_decoders)
+        self.metrics = self.map_to_outputs(outputs, self.compiled_metrics)
+        self.built = True
+
+    def map_to_outputs(self, outputs, struct):
+        """dict -> fill missing keys with None; list -> positional over the output order; single item -> every output."""
+        if struct is None:
+            return struct
+        if isinstance(struct, dict):
+            for key in struct:
+                if key not in outputs:
+                    raise Exception("Found unexpected dict key: {}. Valid output names are: {}".format(key, outputs.keys()))
+            for key in outputs:
+                struct.setdefault(key, None)
+            return struct
+        if isinstance(struct, list):
+            return {key: (struct[i] if i < len(struct) else None) for i, key in enumerate(outputs)}
+        return {key: struct for key in outputs}
+
+    # -- one forward + losses (nnet/model.py:227-344) ---------------------------------------------
+    def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
+        batch_losses, batch_metrics, batch_truths, batch_preds = {}, {}, {}, {}
+        total_loss = torch.zeros((), device=self.device)
+        outputs = self.forward(inputs)
+        if isinstance(outputs, list):
+            outputs = {"output_" + str(k): v for k, v in enumerate(outputs)}
+        elif not isinstance(outputs, dict):
+            outputs = {"output": outputs}
+        targets = self.map_to_outputs(outputs, targets)
+        if not self.built:
+            self.build(outputs)
+        for key in outputs:
+            if self.losses[key] is not None:
+                l = self.losses[key](targets[key], outputs[key])
+                batch_losses["loss_" + key] = l
+                total_loss = total_loss + l * self.loss_weights[key].get_val_step(self.model_step + 1)
+            if compute_metrics and self.metrics and self.metrics[key] is not None:
+                metric, decoder = self.metrics[key], (self.decoders[key] if self.decoders else None)
+                name = metric.name if metric.name not in batch_metrics else metric.name + "_" + key
+                if decoder is not None:
+                    batch_truths[name] = decoder(targets[key], from_logits=False) if targets[key] is not None else None
+                    batch_preds[name] = decoder(outputs[key])
+                else:
+                    batch_truths[name], batch_preds[name] = targets[key], outputs[key]
+                batch_metrics[name] = metric(batch_truths[name], batch_preds[name])
+        for module in self.modules():
+            if getattr(module, "added_losses", None):
+                for key, value in module.added_losses.items():
+                    batch_losses["loss_" + key] = value["loss"]
+                    total_loss = total_loss + value["loss"] * value["weight"]
+                module.reset_losses()
+        batch_losses = dict({"loss": total_loss}, **batch_losses) if len(batch_losses) > 1 else {"loss": total_loss}
+        return batch_losses, batch_metrics, batch_truths, batch_preds
+
+    # -- one optimisation micro-step (nnet/model.py:346-409) ---------------------------------------
+    def train_step(self, inputs, targets, precision=torch.float32, grad_scaler=None, accumulated_steps=1, acc_step=0, eval_training=False):
+        rt.set_compute_dtype(precision)
+        batch_losses, batch_metrics, _, _ = self.forward_model(inputs, targets, compute_metrics=eval_training)
+        (batch_losses["loss"] / accumulated_steps).backward()
+        rt.advance_rng(self.device)
+        acc_step += 1
+        if acc_step < accumulated_steps:
+            return batch_losses, batch_metrics, acc_step
+        if self.is_distributed:
+            # the reference all-reduces on every micro-batch (no no_sync); summing once per optimizer step is numerically the same
+            self.arena.all_reduce_grads()
+            self.optimizer.grad_scale = 1.0 / self.world_size
+        if self.grad_max_norm is not None:
+            norm = self.arena.grad.norm() * getattr(self.optimizer, "grad_scale", 1.0)
+            self.arena.grad.mul_((self.grad_max_norm / (norm + 1e-6)).clamp(max=1.0))
+            self.add_info("grad_norm", norm)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.add_info("lr", float(self.optimizer.param_groups[0]["lr"]))
+        self.add_info("step", int(self.model_step))
+        return batch_losses, batch_metrics, 0
+
+    def eval_step(self, inputs, targets, verbose=0):
+        with torch.no_grad():
+            return self.forward_model(inputs, targets, verbose=verbose)
+
+    # -- checkpoints (nnet/model.py:499-544) -------------------------------------------------------
+    def save(self, path, save_optimizer=True):
+        torch.save({"model_state_dict": self.state_dict(), "optimizer_state_dict": self.optimizer.state_dict() if save_optimizer else None,
+                    "model_step": self.model_step, "is_distributed": self.is_distributed or self.is_parallel,
+                    "ema_model_state_dict": None, "grad_scaler_state_dict": None}, path)
+
+    def load(self, path, load_optimizer=True, verbose=True, strict=True):
+        ckpt = torch.load(path, map_location=self.device, weights_only=False)
+        sd = ckpt["model_state_dict"]
+        if ckpt.get("is_distributed", False):
+            sd = {k.replace(".module.", ".").replace("module.", "", 1) if k.startswith("module.") else k.replace(".module.", "."): v for k, v in sd.items()}
+        self.load_state_dict({k: v for k, v in sd.items()}, strict=strict)
+        self.model_step.fill_(ckpt["model_step"])
+        if load_optimizer and ckpt.get("optimizer_state_dict") is not None:
+            self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+
+    # -- loops (compact counterparts of nnet/model.py:668-942, 1047-1077) ----------------------------
+    def fit(self, dataset_train, epochs, dataset_eval=None, eval_steps=None, verbose_eval=0, initial_epoch=0, callback_path=None, steps_per_epoch=None,
+            precision=torch.float32, accumulated_steps=1, eval_period_step=None, eval_period_epoch=1, saving_period_epoch=1, log_figure_period_step=None,
+            log_figure_period_epoch=1, step_log_period=100, eval_training=True, grad_init_scale=65536.0, detect_anomaly=False, recompute_metrics=False,
+            wandb_logging=False, verbose_progress_bar=1, keep_last_k=None):
+        if callback_path is not None and self.rank == 0:
+            os.makedirs(callback_path, exist_ok=True)
+        for epoch in range(initial_epoch, epochs):
+            self.train()
+            acc_step, t0, n = 0, time.time(), 0
+            for step, batch in enumerate(dataset_train):
+                inputs = self.transfer_to_device(batch["inputs"])
+                targets = self.transfer_to_device(batch["targets"])
+                losses, _, acc_step = self.train_step(inputs, targets, precision, None, accumulated_steps, acc_step, eval_training)
+                n += 1
+                if self.rank == 0 and step % step_log_period == 0:
+                    print("epoch %d step %d model_step %d loss %.4f" % (epoch + 1, step, int(self.model_step), float(losses["loss"])))
+                if steps_per_epoch is not None and step + 1 >= steps_per_epoch:
+                    break
+            if self.rank == 0:
+                print("epoch %d: %d steps in %.1fs" % (epoch + 1, n, time.time() - t0))
+                if callback_path is not None and (epoch + 1) % saving_period_epoch == 0:
+                    self.save(os.path.join(callback_path, "checkpoints_epoch_{}_step_{}.ckpt".format(epoch + 1, int(self.model_step))))
+            if dataset_eval is not None and (epoch + 1) % eval_period_epoch == 0:
+                self.evaluate(dataset_eval, eval_steps)
+
+    def evaluate(self, dataset_eval, eval_steps=None, verbose=0, eval_loss=True, recompute_metrics=False):
+        self.eval()
+        sums, count = {}, 0
+        for step, batch in enumerate(dataset_eval):
+            inputs = self.transfer_to_device(batch["inputs"])
+            targets = self.transfer_to_device(batch["targets"])
+            losses, metrics, _, _ = self.eval_step(inputs, targets, verbose)
+            for k, v in list(losses.items()) + list(metrics.items()):
+                sums[k] = sums.get(k, 0.0) + float(v)
+            count += 1
+            if eval_steps is not None and step + 1 >= eval_steps:
+                break
+        return {k: v / max(count, 1) for k, v in sums.items()}
+
+    def eval_time(self, dataset_eval, eval_steps=None, **kwargs):
+        self.eval()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for step, batch in enumerate(dataset_eval):
+            with torch.no_grad():
+                self.forward(self.transfer_to_device(batch["inputs"]))
+            if eval_steps is not None and step + 1 >= eval_steps:
+                break
+        torch.cuda.synchronize()
+        return time.time() - t0
+
+    def summary(self, show_dict=False):
+        print(self.name, "Parameters:", sum(p.numel() for p in self.parameters()))

@@ -1,0 +1,193 @@
+"""Encoders (nnet/networks.py): ResNet-18 visual front-end, ConformerInterCTC stack, audio / visual / audio-visual encoders."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import runtime as rt
+from . import attentions, blocks, layers, modules, normalizations, preprocessing, transforms
+
+
+class ResNet(nn.Module):
+    """nnet/networks.py:32-146.  Hot path = ResNet18 without stem; forward_nhwc consumes the stem's channels-last frames."""
+
+    def __init__(self, dim_input=3, dim_output=1000, model="ResNet50", include_stem=True, include_head=True):
+        super().__init__()
+        assert model in ("ResNet18", "ResNet34") and not include_stem, "hot path: basic-block ResNet fed by the Conv3d stem (nnet/networks.py:472)"
+        dim_stem, dim_blocks = 64, [64, 128, 256, 512]
+        num_blocks = [2, 2, 2, 2] if model == "ResNet18" else [3, 4, 6, 3]
+        self.stem = nn.Identity()
+        self.blocks = nn.ModuleList()
+        for stage in range(4):
+            for b in range(num_blocks[stage]):
+                first = b == 0
+                cin = (dim_stem if stage == 0 else dim_blocks[stage - 1]) if first else dim_blocks[stage]
+                stride = (2, 2) if (first and stage > 0) else (1, 1)
+                self.blocks.append(blocks.ResNetBlock(in_features=cin, out_features=dim_blocks[stage], kernel_size=(3, 3), stride=stride,
+                                                      act_fun="ReLU", joined_post_act=True))
+        self.head = nn.Sequential(layers.GlobalAvgPool2d(),
+                                  layers.Linear(dim_blocks[-1], dim_output, weight_init="he_normal", bias_init="zeros")) if include_head else nn.Identity()
+
+    def forward_nhwc(self, x):
+        for blk in self.blocks:
+            x = blk.forward_nhwc(x)
+        if isinstance(self.head, nn.Identity):
+            return x
+        x = ops.AvgPoolFn.apply(x)
+        lin = self.head[1]
+        return ops.linear(x, lin.weight, lin.bias)
+
+    def forward(self, x):
+        return self.forward_nhwc(x.permute(0, 2, 3, 1).to(rt.act_dtype()).contiguous())
+
+
+class ConformerInterCTC(nn.Module):
+    """nnet/networks.py:202-307"""
+
+    def __init__(self, dim_model, num_blocks, interctc_blocks, vocab_size, loss_prefix="ctc", att_params={"class": "MultiHeadAttention", "num_heads": 4},
+                 conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 31}}, ff_ratio=4, drop_rate=0.1, pos_embedding=None,
+                 mask=None, conv_stride=1, batch_norm=True):
+        super().__init__()
+        assert pos_embedding is None
+        self.interctc_blocks, self.loss_prefix = interctc_blocks, loss_prefix
+        dim_model = [dim_model] if isinstance(dim_model, int) else dim_model
+        num_blocks = [num_blocks] if isinstance(num_blocks, int) else num_blocks
+        self.pos_embedding = None
+        self.dropout = layers.Dropout(p=drop_rate)
+        self.mask = mask
+        self.conformer_blocks = nn.ModuleList()
+        self.interctc_modules = nn.ModuleList()
+        i = 1
+        for stage, nb in enumerate(num_blocks):
+            for b in range(nb):
+                down = (b == nb - 1) and (stage < len(num_blocks) - 1)       # last block of every stage but the last: stride + widen
+                d_out = dim_model[stage + 1] if down else dim_model[stage]
+                stride = (conv_stride[stage] if isinstance(conv_stride, list) else conv_stride) if down else 1
+                self.conformer_blocks.append(blocks.ConformerBlock(
+                    dim_model=dim_model[stage], dim_expand=d_out, ff_ratio=ff_ratio, drop_rate=drop_rate,
+                    att_params=att_params[stage] if isinstance(att_params, list) else att_params, conv_stride=stride,
+                    conv_params=conv_params[stage] if isinstance(conv_params, list) else conv_params, batch_norm=batch_norm))
+                if i in interctc_blocks:
+                    self.interctc_modules.append(modules.InterCTCResModule(dim_model=d_out, vocab_size=vocab_size))
+                i += 1
+
+    def forward(self, x, lengths):
+        x = self.dropout(x)
+        mask = modules.LengthMask(lengths) if (self.mask is not None and lengths is not None) else None
+        inter, j = {}, 0
+        for i, block in enumerate(self.conformer_blocks):
+            x = block(x, mask=mask)
+            logits = None
+            if i + 1 in self.interctc_blocks:
+                x, logits = self.interctc_modules[j](x)
+                j += 1
+            if block.stride > 1:
+                if mask is not None:
+                    mask = mask.strided(block.stride)
+                if lengths is not None:
+                    lengths = torch.div(lengths - 1, block.stride, rounding_mode="floor") + 1
+            if logits is not None:
+                inter[self.loss_prefix + "_" + str(i)] = [logits, lengths]
+        return x, lengths, inter
+
+
+def _relpos(num_heads, attn_drop_rate, max_pos, **extra):
+    cls = "RelPosPatch1dMultiHeadAttention" if "patch_size" in extra else "RelPos1dMultiHeadAttention"
+    return {"class": cls, "params": dict(num_heads=num_heads, attn_drop_rate=attn_drop_rate, num_pos_embeddings=max_pos,
+                                         weight_init="default", bias_init="default", **extra)}
+
+
+class AudioEfficientConformerEncoder(nn.Module):
+    """nnet/networks.py:309-440"""
+
+    def __init__(self, include_head=True, vocab_size=256, att_type="patch", interctc_blocks=[3, 6, 10, 13], num_blocks=[5, 6, 5], loss_prefix="ctc"):
+        super().__init__()
+        assert att_type in ("regular", "patch"), "grouped attention: no shipped config selects it (SURVEY a11 / 8f rank 4)"
+        filters, n_mels, dim_model, H = 180, 80, [180, 256, 360], 4
+        self.audio_preprocessing = preprocessing.AudioPreprocessing(16000, 512, 25, 10, n_mels, False, -5.6501, 4.2280)
+        self.spec_augment = preprocessing.SpecAugment(mF=2, F=27, mT=5, pS=0.05)
+        self.unsqueeze = layers.Unsqueeze(dim=1)
+        self.subsampling_module = modules.ConvNeuralNetwork(dim_input=1, dim_layers=filters, kernel_size=3, strides=2, norm="BatchNorm2d", act_fun="Swish",
+                                                            drop_rate=0.0, dim=2)
+        self.reshape = layers.Reshape(shape=(filters * n_mels // 2, -1), include_batch=False)
+        self.transpose = layers.Transpose(1, 2)
+        self.linear = layers.Linear(filters * n_mels // 2, dim_model[0])
+        first = _relpos(H, 0.0, 10000, patch_size=3) if att_type == "patch" else _relpos(H, 0.0, 10000)
+        self.back_end = ConformerInterCTC(dim_model=dim_model, num_blocks=num_blocks, interctc_blocks=interctc_blocks, vocab_size=vocab_size,
+                                          att_params=[first, _relpos(H, 0.0, 10000), _relpos(H, 0.0, 10000)],
+                                          conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}, ff_ratio=4, drop_rate=0.1,
+                                          pos_embedding=None, mask=attentions.Mask(), conv_stride=2, batch_norm=True, loss_prefix=loss_prefix)
+        self.head = layers.Linear(dim_model[-1], vocab_size) if include_head else nn.Identity()
+
+    def forward(self, x, lengths):
+        mel, lengths = self.audio_preprocessing(x, lengths)
+        mel = self.spec_augment(mel, lengths)
+        stem = self.subsampling_module.layers[0]
+        a = ops.AudioStemFn.apply(mel, stem[0], stem[1], stem[1].training and not stem[1].frozen)     # (B, T', 7200) act
+        lengths = torch.div(lengths - 1, 2, rounding_mode="floor") + 1
+        x = ops.linear(a, self.linear.weight, self.linear.bias)
+        x, lengths, inter = self.back_end(x, lengths)
+        if not isinstance(self.head, nn.Identity):
+            x = self.head(x)
+        return x, lengths, inter
+
+
+class VisualEfficientConformerEncoder(nn.Module):
+    """nnet/networks.py:442-512"""
+
+    def __init__(self, include_head=True, vocab_size=256, interctc_blocks=[3, 6, 9], num_blocks=[6, 6], loss_prefix="ctc"):
+        super().__init__()
+        dim_model, H = [256, 360], 4
+        self.front_end = nn.Sequential(
+            modules.ConvNeuralNetwork(dim_input=1, dim_layers=64, kernel_size=(5, 7, 7), strides=(1, 2, 2), norm="BatchNorm3d", act_fun="ReLU", drop_rate=0.0, dim=3),
+            layers.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding="same"),
+            transforms.VideoToImages(),
+            ResNet(include_stem=False, dim_output=dim_model[0], model="ResNet18"))
+        self.expand_time = transforms.ImagesToVideos()
+        self.back_end = ConformerInterCTC(dim_model=dim_model, num_blocks=num_blocks, interctc_blocks=interctc_blocks, vocab_size=vocab_size,
+                                          att_params=_relpos(H, 0.0, 10000), conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}},
+                                          ff_ratio=4, drop_rate=0.1, pos_embedding=None, mask=attentions.Mask(), conv_stride=2, batch_norm=True,
+                                          loss_prefix=loss_prefix)
+        self.head = layers.Linear(dim_model[-1], vocab_size) if include_head else nn.Identity()
+
+    def forward(self, x, lengths):
+        """x: (B, 1, T, H, W)"""
+        B, C, T, H, W = x.shape
+        assert C == 1
+        stem = self.front_end[0].layers[0]
+        bn = stem[1]
+        frames = ops.VideoStemFn.apply(x.reshape(B, T, H, W), stem[0], bn, bn.training and not bn.frozen)     # (B*T, H/4, W/4, 64) act, channels-last
+        feats = self.front_end[3].forward_nhwc(frames)                                                          # (B*T, 256) fp32
+        x = feats.view(B, T, -1)
+        x, lengths, inter = self.back_end(x, lengths)
+        if not isinstance(self.head, nn.Identity):
+            x = self.head(x)
+        return x, lengths, inter
+
+
+class AudioVisualEfficientConformerEncoder(nn.Module):
+    """nnet/networks.py:514-579"""
+
+    def __init__(self, include_head=True, vocab_size=256, v_interctc_blocks=[3, 6], a_interctc_blocks=[8, 11], f_interctc_blocks=[2]):
+        super().__init__()
+        dim_model = 360
+        self.video_encoder = VisualEfficientConformerEncoder(include_head=False, vocab_size=vocab_size, interctc_blocks=v_interctc_blocks,
+                                                             num_blocks=[6, 1], loss_prefix="v_ctc")
+        self.audio_encoder = AudioEfficientConformerEncoder(include_head=False, vocab_size=vocab_size, interctc_blocks=a_interctc_blocks,
+                                                            num_blocks=[5, 6, 1], loss_prefix="a_ctc")
+        self.fusion_module = modules.FusionModule(a_dim_model=dim_model, v_dim_model=dim_model, f_dim_model=dim_model)
+        self.audio_visual_encoder = ConformerInterCTC(dim_model=dim_model, num_blocks=5, interctc_blocks=f_interctc_blocks, vocab_size=vocab_size,
+                                                      att_params=_relpos(4, 0.0, 10000),
+                                                      conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}, ff_ratio=4,
+                                                      drop_rate=0.1, pos_embedding=None, mask=attentions.Mask(), conv_stride=2, batch_norm=True, loss_prefix="f_ctc")
+        self.head = layers.Linear(dim_model, vocab_size) if include_head else nn.Identity()
+
+    def forward(self, video, video_len, audio, audio_len):
+        video, video_len, v_inter = self.video_encoder(video, video_len)
+        audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+        x = self.fusion_module(audio, video)
+        x, lengths, inter = self.audio_visual_encoder(x, audio_len)
+        inter.update(v_inter)
+        inter.update(a_inter)
+        if not isinstance(self.head, nn.Identity):
+            x = self.head(x)
+        return x, lengths, inter

@@ -1,0 +1,831 @@
+"""Launchers over the C ABI (raw pointers + sizes) and the autograd Functions that compose them.
+
+Every Function writes parameter gradients straight into `param.grad` (accumulating; the flat gradient
+arena when the model owns one) and returns None for them, so the backward pass is a fixed sequence of
+HIP launches on the current stream (graph-capturable)."""
+import ctypes
+
+import torch
+
+from . import runtime as rt
+from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, Attn, Epilogue, Rows, lib
+
+_byref = ctypes.byref
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def grad_of(p):
+    """fp32 gradient buffer of a parameter (same physical layout), created on first use."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def empty(shape, dtype, ref):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+def rows_plain(ld, rows_out=1, rows_in=1, step=0):
+    r = Rows()
+    r.ld, r.rows_out, r.rows_in, r.step = ld, rows_out, rows_in, step
+    return r
+
+
+def rows_conv(H, W, C, KH, KW, stride, pad, OH, OW):
+    r = Rows()
+    r.H, r.W, r.C, r.KH, r.KW, r.stride, r.pad, r.OH, r.OW = H, W, C, KH, KW, stride, pad, OH, OW
+    return r
+
+
+def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
+            drop_p=0.0, sid=0, res=None, res_act=False, alpha=1.0, dact_z=None, dact=0, colsum=None, stats=None, out_f32=False,
+            ldo=None, ldres=None, dtype=None):
+    ep = Epilogue()
+    ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
+    if out_pre is not None:
+        ep.out_pre, ep.ldpre = out_pre.data_ptr(), N
+    ep.bias = _p(bias)
+    ep.act = act
+    if drop_p > 0.0:
+        ep.drop_p, ep.rng, ep.rng_stream = drop_p, rt.rng_state(out.device).data_ptr(), sid
+    if res is not None:
+        ep.res, ep.ldres, ep.res_act = res.data_ptr(), (N if ldres is None else ldres), int(res_act)
+    ep.alpha = alpha
+    if dact_z is not None:
+        ep.dact_z, ep.ldz, ep.dact = dact_z.data_ptr(), N, dact
+    ep.colsum, ep.stats = _p(colsum), _p(stats)
+    if rows is None:
+        rows = rows_plain(K)
+    lib.gemm_nt(rt.dt() if dtype is None else dtype, A.data_ptr(), _byref(rows), mode, int(a_f32), W.data_ptr(),
+                K if ldw is None else ldw, M, N, K, _byref(ep), rt.stream())
+    return out
+
+
+def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None):
+    """O[I][J] (fp32) += P[M][I]^T Q[M][J]"""
+    if q_rows is None:
+        q_rows = rows_plain(J)
+    lib.gemm_tn(rt.dt() if dtype is None else dtype, P.data_ptr(), I if ldp is None else ldp, Q.data_ptr(), _byref(q_rows), q_mode,
+                int(q_f32), O.data_ptr(), J if ldo is None else ldo, M, I, J, rt.stream())
+
+
+def layernorm_fwd(x, w, b, M, D, out_f32, eps):
+    y = empty((M, D), torch.float32 if out_f32 else rt.act_dtype(), x)
+    mean = empty((M,), torch.float32, x)
+    rstd = empty((M,), torch.float32, x)
+    lib.layernorm_fwd(rt.dt(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), int(out_f32), mean.data_ptr(), rstd.data_ptr(), M, D, eps,
+                      rt.stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, dy_f32, x, mean, rstd, w, b, M, D, dres=None):
+    dx = empty((M, D), torch.float32, x)
+    lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
+                      grad_of(w).data_ptr(), grad_of(b).data_ptr(), M, D, rt.stream())
+    return dx
+
+
+def grad_prep(dout, M, N, alpha=1.0, drop_p=0.0, sid=0, dbias=None):
+    dacc = empty((M, N), rt.act_dtype(), dout)
+    rng = rt.rng_state(dout.device).data_ptr() if drop_p > 0 else None
+    lib.grad_prep(rt.dt(), dout.data_ptr(), N, dacc.data_ptr(), alpha, drop_p, rng, sid, _p(dbias), M, N, rt.stream())
+    return dacc
+
+
+def colsum(x, ld, out, M, N):
+    lib.colsum(rt.dt(), x.data_ptr(), ld, out.data_ptr(), M, N, rt.stream())
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _sync_stats(stats):
+    if rt.sync_batchnorm():
+        torch.distributed.all_reduce(stats)
+
+
+# ============================================================================================
+# Linear family
+# ============================================================================================
+def linear_fwd(x2d, weight, bias, M, *, in_f32, out_f32, act=ACT_NONE, out_pre=None, drop_p=0.0, sid=0, res=None, alpha=1.0,
+               rows=None, K=None):
+    sh = rt.shadow(weight)
+    N, Kw = sh.A, sh.Tm * sh.C
+    out = empty((M, N), torch.float32 if out_f32 else rt.act_dtype(), x2d)
+    gemm_nt(x2d, sh.fwd, out, M, N, Kw, rows=rows, a_f32=in_f32, bias=bias, act=act, out_pre=out_pre, drop_p=drop_p, sid=sid,
+            res=res, alpha=alpha, out_f32=out_f32)
+    return out
+
+
+def linear_bwd_weight(dacc, x2d, weight, M, *, q_f32=False, q_rows=None, ldp=None):
+    sh = rt.shadow(weight)
+    gemm_tn(dacc, x2d, grad_of(weight), M, sh.A, sh.Tm * sh.C, q_f32=q_f32, q_rows=q_rows, ldp=ldp)
+
+
+def linear_bwd_input(dacc, weight, M, *, out_f32, res=None, res_act=False, dact_z=None, dact=0, drop_p=0.0, sid=0, colsum_to=None, lda=None, out=None):
+    sh = rt.shadow(weight)
+    N, K = sh.Tm * sh.C, sh.A            # bwd shadow is [C*Tm][A]
+    if out is None:
+        out = empty((M, N), torch.float32 if out_f32 else rt.act_dtype(), dacc)
+    gemm_nt(dacc, sh.bwd, out, M, N, K, rows=rows_plain(K if lda is None else lda), res=res, res_act=res_act, dact_z=dact_z, dact=dact,
+            drop_p=drop_p, sid=sid, colsum=colsum_to, out_f32=out_f32)
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """layers.Linear.forward (nnet/layers.py:64-76): y = x W^T + b.  x fp32 or act; y fp32 or act."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_f32, out_f32):
+        rt.require_gpu(x)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M = x2.shape[0]
+        y = linear_fwd(x2, weight, bias, M, in_f32=in_f32, out_f32=out_f32)
+        ctx.saved = (x2, weight, bias, in_f32, out_f32, M, shp)
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, in_f32, out_f32, M, shp = ctx.saved
+        N = weight.shape[0]
+        dy = dy.reshape(M, N)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if out_f32:
+            dacc = grad_prep(dy, M, N, dbias=None if bias is None else grad_of(bias))
+        else:
+            dacc = dy
+            if bias is not None:
+                colsum(dacc, N, grad_of(bias), M, N)
+        linear_bwd_weight(dacc, x2, weight, M, q_f32=in_f32)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_bwd_input(dacc, weight, M, out_f32=in_f32).view(shp)
+        return dx, None, None, None, None
+
+
+def linear(x, weight, bias, out_f32=True):
+    """x fp32 (converted while staging in bf16 mode) or act; returns fp32 by default."""
+    if rt.compute_dtype() == "f32":
+        return LinearFn.apply(x.float(), weight, bias, False, True)
+    if x.dtype == torch.float32:
+        return LinearFn.apply(x, weight, bias, True, out_f32)
+    return LinearFn.apply(x.to(rt.act_dtype()), weight, bias, False, out_f32)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of an fp32 tensor -> fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        rt.require_gpu(x)
+        shp = x.shape
+        x2 = _f32c(x.reshape(-1, shp[-1]))
+        M, D = x2.shape
+        y, mean, rstd = layernorm_fwd(x2, w, b, M, D, True, eps)
+        ctx.saved = (x2, mean, rstd, w, b, M, D, shp)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w, b, M, D, shp = ctx.saved
+        dx = layernorm_bwd(_f32c(dy.reshape(M, D)), True, x2, mean, rstd, w, b, M, D)
+        return dx.view(shp), None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, sid):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        lib.dropout_f32(x.data_ptr(), y.data_ptr(), p, rt.rng_state(x.device).data_ptr(), sid, x.numel(), rt.stream())
+        ctx.saved = (p, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, sid = ctx.saved
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        lib.dropout_f32(dy.data_ptr(), dx.data_ptr(), p, rt.rng_state(dy.device).data_ptr(), sid, dy.numel(), rt.stream())
+        return dx, None, None
+
+
+# ============================================================================================
+# FeedForwardModule (nnet/modules.py:257-289) fused with its macaron residual (nnet/blocks.py:292,301)
+#   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
+# ============================================================================================
+class FeedForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, alpha, drop_p, sid1, sid2):
+        rt.require_gpu(x)
+        shp = x.shape
+        x2 = _f32c(x.reshape(-1, shp[-1]))
+        M, D = x2.shape
+        F = w1.shape[0]
+        adt = rt.act_dtype()
+        h0, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+        z = empty((M, F), adt, x2)
+        h1 = linear_fwd(h0, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z, drop_p=drop_p, sid=sid1)
+        y = linear_fwd(h1, w2, b2, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid2, res=x2, alpha=alpha)
+        ctx.saved = (x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp = ctx.saved
+        dy = _f32c(dy.reshape(M, D))
+        dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2, dbias=grad_of(b2))
+        linear_bwd_weight(dacc, h1, w2, M)
+        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1, colsum_to=grad_of(b1))
+        linear_bwd_weight(dz, h0, w1, M)
+        dh0 = linear_bwd_input(dz, w1, M, out_f32=False)
+        dx = layernorm_bwd(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy)
+        return (dx.view(shp),) + (None,) * 11
+
+
+# ============================================================================================
+# AttentionModule (nnet/modules.py:320-339) with RelPos1d / RelPosPatch1d attention (nnet/attentions.py:280-382)
+#   y = x + Drop(Wo . Attn(LN(x)) + bo)
+# ============================================================================================
+_PE_CACHE = {}
+
+
+def rel_pos_table(T, D, device):
+    """RelativeSinusoidalPositionalEncoding rows p = T-1 .. -(T-1) (nnet/embeddings.py:117-126,152), act dtype."""
+    key = (T, D, str(device), rt.compute_dtype())
+    if key not in _PE_CACHE:
+        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32).unsqueeze(1)
+        inv = 10000 ** (2 * torch.arange(0, D // 2, dtype=torch.float32).unsqueeze(0) / D)
+        ang = pos / inv
+        pe = torch.zeros(2 * T - 1, D)
+        pe[:, 0::2] = ang.sin()
+        pe[:, 1::2] = ang.cos()
+        _PE_CACHE[key] = pe.to(device=device, dtype=rt.act_dtype()).contiguous()
+    return _PE_CACHE[key]
+
+
+def _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D):
+    a = Attn()
+    esz = qkv.element_size()
+    a.q, a.k, a.v, a.ld = qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, 3 * D
+    a.e, a.lde = e.data_ptr(), D
+    a.lens, a.len_div = _p(lens), len_div
+    if mask is not None:
+        a.mask, a.mask_bstride = mask.data_ptr(), (T * T if mask.shape[0] > 1 else 0)
+    a.o, a.ldo, a.lse = o.data_ptr(), D, lse.data_ptr()
+    a.B, a.H, a.T, a.d, a.scale = B, H, T, d, 1.0 / d ** 0.5
+    return a
+
+
+class AttentionModuleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wp, bp, H, patch, eps, drop_p, sid, residual):
+        rt.require_gpu(x)
+        B, T, D = x.shape
+        x2 = _f32c(x.reshape(-1, D))
+        M, d, adt = B * T, D // H, rt.act_dtype()
+        h, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+        if patch > 1:
+            Tp = (T + patch - 1) // patch
+            hp = empty((B * Tp, D), adt, x2)
+            lib.patch_pool_fwd(rt.dt(), h.data_ptr(), hp.data_ptr(), B, T, D, patch, rt.stream())
+        else:
+            Tp, hp = T, h
+        Mp = B * Tp
+        if mask is not None:      # dense (B or 1,1,T,T) float mask as the reference API; patch variant min-pools it on the host side
+            mask = mask.reshape(mask.shape[0], T, T) if patch == 1 else _pool_mask(mask, T, patch)
+            mask = mask.float().contiguous()
+        qkv = empty((Mp, 3 * D), adt, x2)
+        for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+            sh = rt.shadow(w)
+            gemm_nt(hp, sh.fwd, qkv[:, i * D:], Mp, D, D, bias=b, ldo=3 * D)
+        pe = rel_pos_table(Tp, D, x.device)
+        e = linear_fwd(pe, wp, bp, 2 * Tp - 1, in_f32=False, out_f32=False)
+        o = empty((Mp, D), adt, x2)
+        lse = empty((B * H, Tp), torch.float32, x2)
+        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D)
+        lib.relpos_attention_fwd(rt.dt(), _byref(a), rt.stream())
+        res = x2 if residual else None
+        if patch > 1:
+            oo = linear_fwd(o, wo, bo, Mp, in_f32=False, out_f32=False)
+            base = x2 if residual else torch.zeros_like(x2)
+            y = empty((M, D), torch.float32, x2)
+            rng = rt.rng_state(x.device).data_ptr() if drop_p > 0 else None
+            lib.patch_unpool_add(rt.dt(), oo.data_ptr(), base.data_ptr(), y.data_ptr(), drop_p, rng, sid, B, T, D, patch, rt.stream())
+        else:
+            y = linear_fwd(o, wo, bo, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid, res=res, alpha=1.0)
+        ctx.saved = (x2, mean, rstd, h, hp, qkv, pe, e, o, lse, lens, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wp, bp,
+                     H, patch, drop_p, sid, residual, B, T, Tp, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, mean, rstd, h, hp, qkv, pe, e, o, lse, lens, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wp, bp,
+         H, patch, drop_p, sid, residual, B, T, Tp, D) = ctx.saved
+        M, Mp, d, adt = B * T, B * Tp, D // H, rt.act_dtype()
+        dy = _f32c(dy.reshape(M, D))
+        if patch > 1:
+            doo = empty((Mp, D), adt, dy)
+            rng = rt.rng_state(dy.device).data_ptr() if drop_p > 0 else None
+            lib.patch_unpool_bwd(rt.dt(), dy.data_ptr(), doo.data_ptr(), drop_p, rng, sid, B, T, D, patch, rt.stream())
+            colsum(doo, D, grad_of(bo), Mp, D)
+        else:
+            doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid, dbias=grad_of(bo))
+        linear_bwd_weight(doo, o, wo, Mp)
+        do = linear_bwd_input(doo, wo, Mp, out_f32=False)
+        dqkv = empty((Mp, 3 * D), adt, dy)
+        de = torch.zeros((2 * Tp - 1, D), dtype=torch.float32, device=dy.device)
+        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D)
+        a.dout = do.data_ptr()
+        esz = dqkv.element_size()
+        a.dq, a.lddq = dqkv.data_ptr(), 3 * D
+        nseg = (Tp + 63) // 64
+        if nseg > 1:
+            dkv32 = torch.zeros((Mp, 2 * D), dtype=torch.float32, device=dy.device)
+            a.dk, a.dv, a.ldd = dkv32.data_ptr(), dkv32.data_ptr() + D * 4, 2 * D
+        else:
+            a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
+        a.de, a.ldde = de.data_ptr(), D
+        lib.relpos_attention_bwd(rt.dt(), _byref(a), int(nseg > 1), rt.stream())
+        if nseg > 1:
+            lib.cast_rows(rt.dt(), dkv32.data_ptr(), 2 * D, dqkv.data_ptr() + D * esz, 3 * D, Mp, 2 * D, rt.stream())
+        dhp = None
+        for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+            g = dqkv[:, i * D:]
+            colsum(g, 3 * D, grad_of(b), Mp, D)
+            linear_bwd_weight(g, hp, w, Mp, ldp=3 * D)
+            dhp = linear_bwd_input(g, w, Mp, out_f32=False, lda=3 * D, res=dhp, res_act=True, out=dhp)
+        dea = empty((2 * Tp - 1, D), adt, dy)
+        lib.cast_rows(rt.dt(), de.data_ptr(), D, dea.data_ptr(), D, 2 * Tp - 1, D, rt.stream())
+        colsum(dea, D, grad_of(bp), 2 * Tp - 1, D)
+        linear_bwd_weight(dea, pe, wp, 2 * Tp - 1)
+        if patch > 1:
+            dh = empty((M, D), adt, dy)
+            lib.patch_pool_bwd(rt.dt(), dhp.data_ptr(), dh.data_ptr(), B, T, D, patch, rt.stream())
+        else:
+            dh = dhp
+        dx = layernorm_bwd(dh, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy if residual else None)
+        return (dx.view(B, T, D),) + (None,) * 20
+
+
+def _pool_mask(mask, T, P):
+    """reference min-pool of the padded (B,1,T,T) mask (nnet/attentions.py:140-171,357-362) -- exact 0/1 index work on the host side API path"""
+    pad = (P - T % P) % P
+    m = torch.nn.functional.pad(mask.reshape(mask.shape[0], 1, T, T).float(), (0, pad, 0, pad), value=0.0)
+    Tp = (T + pad) // P
+    return m.reshape(m.shape[0], Tp, P, Tp, P).amin(dim=(2, 4))
+
+
+# ============================================================================================
+# ConvolutionModule (nnet/modules.py:341-385) fused with the block's conv residual (nnet/blocks.py:273-277,298)
+#   y = R(x) + Drop(PW2(Swish(BN(DW(GLU(PW1(LN(x))))))))     R = identity | strided k=1 conv
+# ============================================================================================
+class BNState:
+    """scratch for one BatchNorm application: stats [2C+1] (sum | sumsq | count) and ss [4C]"""
+
+    def __init__(self, C, ref):
+        self.stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=ref.device)
+        self.ss = torch.empty(4 * C, dtype=torch.float32, device=ref.device)
+        self.C = C
+
+
+def bn_finalize(bn, st, count, training):
+    """bn: module with weight/bias/running_mean/running_var/num_batches_tracked/momentum/eps"""
+    C = st.C
+    cptr = None
+    if training:
+        if rt.sync_batchnorm():
+            st.stats[2 * C] = float(count)
+            _sync_stats(st.stats)
+            cptr = st.stats.data_ptr() + 2 * C * 4
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats and bn.running_mean is not None
+    lib.bn_finalize(st.stats.data_ptr(), cptr, float(count), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                    bn.num_batches_tracked.data_ptr() if (track and training) else None, mom, bn.eps, st.ss.data_ptr(), C, int(training), rt.stream())
+    return cptr
+
+
+def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
+    C = st.C
+    adt = rt.act_dtype()
+    dstats = torch.zeros(2 * C, dtype=torch.float32, device=dout.device)
+    lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
+    _sync_stats(dstats)
+    dy = empty((M, C), adt, dout)
+    dres = empty((M, C), adt, dout) if want_dres else None
+    lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count), act,
+                     dy.data_ptr(), _p(dres), grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), M, C, rt.stream())
+    return dy, dres
+
+
+class ConvModuleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, res_conv, drop_p, sid, training):
+        """mod: ConvolutionModule (layers: 0 LN, 1 pw1, 3 dw, 4 BN, 6 pw2);  res_conv: strided k=1 Conv1d or None"""
+        rt.require_gpu(x)
+        B, T, D = x.shape
+        ln, pw1, dw, bn, pw2 = mod.layers[0], mod.layers[1], mod.layers[3], mod.layers[4], mod.layers[6]
+        Dp, K, stride = dw.weight.shape[0], dw.weight.shape[2], dw.stride[0]
+        To = (T - 1) // stride + 1
+        M, Mo, adt = B * T, B * To, rt.act_dtype()
+        x2 = _f32c(x.reshape(M, D))
+        h, mean, rstd = layernorm_fwd(x2, ln.weight, ln.bias, M, D, False, ln.eps)
+        u = linear_fwd(h, pw1.weight, pw1.bias, M, in_f32=False, out_f32=False)
+        c = empty((Mo, Dp), adt, x2)
+        st = BNState(Dp, x2)
+        use_batch = training and not getattr(bn, "frozen", False)
+        lib.glu_dwconv_fwd(rt.dt(), u.data_ptr(), dw.weight.data_ptr(), _p(dw.bias), c.data_ptr(), st.stats.data_ptr() if use_batch else None,
+                           B, T, Dp, K, stride, rt.stream())
+        cptr = bn_finalize(bn, st, Mo, use_batch)
+        a = empty((Mo, Dp), adt, x2)
+        lib.bn_apply_fwd(rt.dt(), c.data_ptr(), st.ss.data_ptr(), None, ACT_SWISH, a.data_ptr(), Mo, Dp, rt.stream())
+        if res_conv is not None:
+            rs = res_conv.stride[0]
+            R = linear_fwd(x2, res_conv.weight, res_conv.bias, Mo, in_f32=(adt != torch.float32), out_f32=True,
+                           rows=rows_plain(D, To, T, rs) if rs > 1 else None)
+        else:
+            R = x2
+        y = linear_fwd(a, pw2.weight, pw2.bias, Mo, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid, res=R, alpha=1.0)
+        ctx.saved = (x2, mean, rstd, h, u, c, a, st, cptr, use_batch, mod, res_conv, drop_p, sid, B, T, To, D, Dp, K, stride)
+        return y.view(B, To, Dp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, h, u, c, a, st, cptr, use_batch, mod, res_conv, drop_p, sid, B, T, To, D, Dp, K, stride = ctx.saved
+        ln, pw1, dw, bn, pw2 = mod.layers[0], mod.layers[1], mod.layers[3], mod.layers[4], mod.layers[6]
+        M, Mo, adt = B * T, B * To, rt.act_dtype()
+        dy = _f32c(dy.reshape(Mo, Dp))
+        dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid, dbias=grad_of(pw2.bias))
+        linear_bwd_weight(dacc, a, pw2.weight, Mo)
+        da = linear_bwd_input(dacc, pw2.weight, Mo, out_f32=False)
+        if use_batch:
+            dc, _ = bn_backward(bn, st, cptr, Mo, da, c, None, ACT_SWISH, Mo)
+        else:   # eval / frozen statistics: dc = da * swish'(pre) * scale  -> reuse the apply kernel with zero batch terms
+            dc = _bn_eval_backward(bn, st, da, c, ACT_SWISH, Mo)
+        du = empty((M, 2 * Dp), adt, dy)
+        lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), dw.weight.data_ptr(), du.data_ptr(), grad_of(dw.weight).data_ptr(),
+                           None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, rt.stream())
+        colsum(du, 2 * Dp, grad_of(pw1.bias), M, 2 * Dp)
+        linear_bwd_weight(du, h, pw1.weight, M)
+        dh = linear_bwd_input(du, pw1.weight, M, out_f32=False)
+        if res_conv is None:
+            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D, dres=dy)
+        else:
+            rs = res_conv.stride[0]
+            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D)
+            dracc = grad_prep(dy, Mo, Dp, dbias=grad_of(res_conv.bias))
+            linear_bwd_weight(dracc, x2, res_conv.weight, Mo, q_f32=(adt != torch.float32), q_rows=rows_plain(D, To, T, rs) if rs > 1 else None)
+            dxr = linear_bwd_input(dracc, res_conv.weight, Mo, out_f32=True)
+            lib.strided_rows_add(dx.data_ptr(), dxr.data_ptr(), B, T, To, D, rs, rt.stream())
+        return dx.view(B, T, D), None, None, None, None, None
+
+
+def _bn_eval_backward(bn, st, dout, y, act, M, out=None):
+    """BatchNorm backward with fixed (running) statistics: dy = dr * scale; the batch-mean terms vanish (dstats = 0)."""
+    C = st.C
+    dstats = torch.zeros(2 * C, dtype=torch.float32, device=dout.device)
+    dstats2 = torch.zeros(2 * C, dtype=torch.float32, device=dout.device)
+    lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats2.data_ptr(), M, C, rt.stream())
+    dy = empty((M, C), rt.act_dtype(), dout)
+    lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), None, 1.0, act,
+                     dy.data_ptr(), None, None, None, M, C, rt.stream())
+    # parameter gradients from the true sums
+    grad_of(bn.weight).add_(dstats2[C:])
+    grad_of(bn.bias).add_(dstats2[:C])
+    return dy
+
+
+# ============================================================================================
+# InterCTCResModule (nnet/modules.py:395-400):  logits = P1 x;  y = x + P2 softmax(logits)
+# ============================================================================================
+class InterCTCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        rt.require_gpu(x)
+        B, T, D = x.shape
+        M, V = B * T, w1.shape[0]
+        x2 = _f32c(x.reshape(M, D))
+        conv = rt.act_dtype() != torch.float32
+        logits = linear_fwd(x2, w1, b1, M, in_f32=conv, out_f32=True)
+        probs = empty((M, V), rt.act_dtype(), x2)
+        lib.softmax_fwd(rt.dt(), logits.data_ptr(), probs.data_ptr(), M, V, rt.stream())
+        y = linear_fwd(probs, w2, b2, M, in_f32=False, out_f32=True, res=x2, alpha=1.0)
+        ctx.saved = (x2, logits, probs, w1, b1, w2, b2, B, T, D, V, conv)
+        return y.view(B, T, D), logits.view(B, T, V)
+
+    @staticmethod
+    def backward(ctx, dy, dlogits_ext):
+        x2, logits, probs, w1, b1, w2, b2, B, T, D, V, conv = ctx.saved
+        M = B * T
+        dy = _f32c(dy.reshape(M, D))
+        dacc = grad_prep(dy, M, D, dbias=grad_of(b2))
+        linear_bwd_weight(dacc, probs, w2, M)
+        dprobs = linear_bwd_input(dacc, w2, M, out_f32=False)
+        dl = empty((M, V), torch.float32, dy)
+        dext = None if dlogits_ext is None else _f32c(dlogits_ext.reshape(M, V))
+        lib.softmax_bwd(rt.dt(), dprobs.data_ptr(), logits.data_ptr(), dl.data_ptr(), _p(dext), M, V, rt.stream())
+        dla = grad_prep(dl, M, V, dbias=grad_of(b1))
+        linear_bwd_weight(dla, x2, w1, M, q_f32=conv)
+        dx = linear_bwd_input(dla, w1, M, out_f32=True, res=dy)
+        return dx.view(B, T, D), None, None, None, None
+
+
+# ============================================================================================
+# FusionModule (nnet/modules.py:421-426): cat -> Linear -> Swish -> Linear
+# ============================================================================================
+class FusionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, v, w1, b1, w2, b2):
+        rt.require_gpu(a)
+        B, T, Da = a.shape
+        Dv = v.shape[-1]
+        M, F, adt = B * T, w1.shape[0], rt.act_dtype()
+        a2, v2 = _f32c(a.reshape(M, Da)), _f32c(v.reshape(M, Dv))
+        xc = empty((M, Da + Dv), adt, a2)
+        lib.cast_rows(rt.dt(), a2.data_ptr(), Da, xc.data_ptr(), Da + Dv, M, Da, rt.stream())
+        lib.cast_rows(rt.dt(), v2.data_ptr(), Dv, xc.data_ptr() + Da * xc.element_size(), Da + Dv, M, Dv, rt.stream())
+        z = empty((M, F), adt, a2)
+        h = linear_fwd(xc, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z)
+        y = linear_fwd(h, w2, b2, M, in_f32=False, out_f32=True)
+        ctx.saved = (xc, z, h, w1, b1, w2, b2, B, T, Da, Dv, F)
+        return y.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, z, h, w1, b1, w2, b2, B, T, Da, Dv, F = ctx.saved
+        M, N = B * T, w2.shape[0]
+        dy = _f32c(dy.reshape(M, N))
+        dacc = grad_prep(dy, M, N, dbias=grad_of(b2))
+        linear_bwd_weight(dacc, h, w2, M)
+        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, colsum_to=grad_of(b1))
+        linear_bwd_weight(dz, xc, w1, M)
+        sh = rt.shadow(w1)                     # bwd shadow [Da+Dv][F]: rows 0..Da-1 -> d(audio), rest -> d(video)
+        da = empty((M, Da), torch.float32, dy)
+        dv = empty((M, Dv), torch.float32, dy)
+        gemm_nt(dz, sh.bwd, da, M, Da, F, out_f32=True)
+        gemm_nt(dz, sh.bwd[Da * F:], dv, M, Dv, F, out_f32=True)
+        return da.view(B, T, Da), dv.view(B, T, Dv), None, None, None, None
+
+
+# ============================================================================================
+# CTC loss (nnet/losses.py:311-334) -> batch mean
+# ============================================================================================
+class CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, logit_len, targets, target_len, blank, zero_infinity):
+        rt.require_gpu(logits)
+        B, T, V = logits.shape
+        lg = _f32c(logits)
+        tg = targets.to(device=lg.device, dtype=torch.int64).contiguous()
+        if tg.dim() == 1:
+            tg = tg.view(B, -1)
+        Lmax = tg.shape[1]
+        il = logit_len.to(device=lg.device, dtype=torch.int64).contiguous()
+        tl = target_len.to(device=lg.device, dtype=torch.int64).contiguous()
+        nll = empty((B,), torch.float32, lg)
+        mean = torch.zeros((), dtype=torch.float32, device=lg.device)
+        need_grad = ctx.needs_input_grad[0]
+        grad = empty((B, T, V), torch.float32, lg) if need_grad else None
+        ws = empty((lib.raw("avec_ctc_workspace_floats")(B, T, max(Lmax, 1)),), torch.float32, lg)
+        lib.ctc_loss(lg.data_ptr(), il.data_ptr(), tg.data_ptr(), tl.data_ptr(), nll.data_ptr(), mean.data_ptr(), _p(grad), ws.data_ptr(),
+                     B, T, V, Lmax, blank, int(zero_infinity), rt.stream())
+        ctx.saved = (grad, B)
+        ctx.nll = nll
+        return mean
+
+    @staticmethod
+    def backward(ctx, dloss):
+        grad, B = ctx.saved
+        out = torch.empty_like(grad)
+        dl = dloss.float().contiguous()
+        lib.scale_by_scalar(grad.data_ptr(), dl.data_ptr(), 1.0 / B, out.data_ptr(), grad.numel(), rt.stream())
+        return out, None, None, None, None, None
+
+
+# ============================================================================================
+# convolutions on channels-last activations (ResNet-18 front-end, nnet/blocks.py:29-91, nnet/networks.py:32-146)
+# ============================================================================================
+def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
+    """x: act [N,H,W,Cin] (contiguous NHWC); weight: Conv2d param (physical [Cout][KH][KW][Cin]); 'same' zero padding ((k-1)//2)."""
+    Cout, KH, KW = weight.shape[0], weight.shape[2], weight.shape[3]
+    pad = (KH - 1) // 2
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M = N * OH * OW
+    sh = rt.shadow(weight)
+    y = empty((M, Cout), rt.act_dtype(), x)
+    gemm_nt(x, sh.fwd, y, M, Cout, KH * KW * Cin, rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_FWD, stats=stats)
+    return y, OH, OW
+
+
+def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None):
+    Cout, KH, KW = weight.shape[0], weight.shape[2], weight.shape[3]
+    pad = (KH - 1) // 2
+    M = N * OH * OW
+    sh = rt.shadow(weight)
+    gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD)
+    if not need_dx:
+        return None
+    dx = empty((N * H * W, Cin), rt.act_dtype(), dy)
+    gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
+            res=dx_res, res_act=True)
+    return dx
+
+
+class ResNetBlockFn(torch.autograd.Function):
+    """x: act NHWC [N,H,W,Cin] -> act NHWC [N,OH,OW,Cout]"""
+
+    @staticmethod
+    def forward(ctx, x, blk, training):
+        rt.require_gpu(x)
+        N, H, W, Cin = x.shape
+        conv1, bn1, conv2, bn2 = blk.layers[0], blk.layers[1], blk.layers[3], blk.layers[4]
+        stride = conv1.stride[0]
+        Cout = conv1.weight.shape[0]
+        adt = rt.act_dtype()
+        x = x.contiguous()
+        st1, st2 = BNState(Cout, x), BNState(Cout, x)
+        y1, OH, OW = conv2d_fwd(x, conv1.weight, N, H, W, Cin, stride, stats=st1.stats if training else None)
+        Mo = N * OH * OW
+        c1 = bn_finalize(bn1, st1, Mo, training)
+        a1 = empty((Mo, Cout), adt, x)
+        lib.bn_apply_fwd(rt.dt(), y1.data_ptr(), st1.ss.data_ptr(), None, ACT_RELU, a1.data_ptr(), Mo, Cout, rt.stream())
+        y2, _, _ = conv2d_fwd(a1, conv2.weight, N, OH, OW, Cout, 1, stats=st2.stats if training else None)
+        c2 = bn_finalize(bn2, st2, Mo, training)
+        has_proj = not isinstance(blk.residual, torch.nn.Identity)
+        yr = str_ = cr = None
+        if has_proj:
+            convr, bnr = blk.residual[0], blk.residual[1]
+            str_ = BNState(Cout, x)
+            yr, _, _ = conv2d_fwd(x, convr.weight, N, H, W, Cin, stride, stats=str_.stats if training else None)
+            cr = bn_finalize(bnr, str_, Mo, training)
+            r = empty((Mo, Cout), adt, x)
+            lib.bn_apply_fwd(rt.dt(), yr.data_ptr(), str_.ss.data_ptr(), None, ACT_NONE, r.data_ptr(), Mo, Cout, rt.stream())
+        else:
+            r = x
+        out = empty((Mo, Cout), adt, x)
+        lib.bn_apply_fwd(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), ACT_RELU, out.data_ptr(), Mo, Cout, rt.stream())
+        ctx.saved = (x, y1, a1, y2, yr, out, st1, st2, str_, c1, c2, cr, blk, training, N, H, W, Cin, Cout, OH, OW, stride, has_proj)
+        return out.view(N, OH, OW, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, a1, y2, yr, out, st1, st2, str_, c1, c2, cr, blk, training, N, H, W, Cin, Cout, OH, OW, stride, has_proj = ctx.saved
+        conv1, bn1, conv2, bn2 = blk.layers[0], blk.layers[1], blk.layers[3], blk.layers[4]
+        Mo = N * OH * OW
+        dout = dout.reshape(Mo, Cout).to(rt.act_dtype()).contiguous()
+        assert training, "ResNetBlock backward is implemented for training-mode BatchNorm"
+        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True)
+        da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW)
+        dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, a1, ACT_RELU, Mo)
+        need_dx = ctx.needs_input_grad[0]
+        if has_proj:
+            convr, bnr = blk.residual[0], blk.residual[1]
+            dyr, _ = bn_backward(bnr, str_, cr, Mo, dres, yr, None, ACT_NONE, Mo)
+            dx = conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx)
+            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx)
+        else:
+            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres)
+        return (dx.view(N, H, W, Cin) if dx is not None else None), None, None
+
+
+class VideoStemFn(torch.autograd.Function):
+    """Conv3d(1->C,(5,7,7),s(1,2,2),'same',bias) + BatchNorm3d + ReLU + MaxPool3d((1,3,3),s(1,2,2),'same')
+    video fp32 [B,T,H,W] -> act NHWC [B*T, H/4, W/4, C]      (nnet/networks.py:459-470)"""
+
+    @staticmethod
+    def forward(ctx, video, conv, bn, training):
+        rt.require_gpu(video)
+        B, T, H, W = video.shape
+        C = conv.weight.shape[0]
+        v = _f32c(video)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        M = B * T * OH * OW
+        sh = rt.shadow(conv.weight)
+        st = BNState(C, v)
+        r = Rows()
+        r.H, r.W, r.OH, r.OW, r.T3 = H, W, OH, OW, T
+        y = empty((M, C), rt.act_dtype(), v)
+        K = sh.Tm * sh.C
+        gemm_nt(v, sh.fwd, y, M, C, K, rows=r, mode=ROWS_STEM3D, a_f32=True, bias=conv.bias, stats=st.stats if training else None)
+        cp = bn_finalize(bn, st, M, training)
+        PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+        out = empty((B * T, PH, PW, C), rt.act_dtype(), v)
+        idx = torch.empty((B * T, PH, PW, C), dtype=torch.uint8, device=v.device)
+        lib.stem_pool_fwd(rt.dt(), y.data_ptr(), st.ss.data_ptr(), out.data_ptr(), idx.data_ptr(), B * T, OH, OW, C, rt.stream())
+        ctx.saved = (v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpool):
+        v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training = ctx.saved
+        assert training, "VideoStem backward is implemented for training-mode BatchNorm"
+        dpool = dpool.to(rt.act_dtype()).contiguous()
+        dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
+        args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
+        lib.stem_pool_bwd(rt.dt(), *args, 0, None, None, None, B * T, OH, OW, C, rt.stream())
+        _sync_stats(dstats)
+        dy = empty((M, C), rt.act_dtype(), v)
+        lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B * T, OH, OW, C, rt.stream())
+        gemm_tn(dy, v, grad_of(conv.weight), M, C, K, q_rows=r, q_mode=ROWS_STEM3D, q_f32=True)
+        if conv.bias is not None:
+            grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
+        return None, None, None, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """GlobalAvgPool2d on act NHWC [N,H,W,C] -> act [N,C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        x = x.contiguous()
+        y = empty((N, C), x.dtype, x)
+        lib.avgpool_fwd(rt.dt(), x.data_ptr(), y.data_ptr(), N, H * W, C, rt.stream())
+        ctx.saved = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.saved
+        dy = dy.to(rt.act_dtype()).contiguous()
+        dx = empty((N, H, W, C), dy.dtype, dy)
+        lib.avgpool_bwd(rt.dt(), dy.data_ptr(), dx.data_ptr(), N, H * W, C, rt.stream())
+        return dx
+
+
+class AudioStemFn(torch.autograd.Function):
+    """Conv2d(1->C,3x3,s2,'same') + BatchNorm2d + Swish on mel [B,80,F] -> act [B, T', C*40]   (nnet/networks.py:359-377)"""
+
+    @staticmethod
+    def forward(ctx, mel, conv, bn, training):
+        rt.require_gpu(mel)
+        B, NM, F = mel.shape
+        C = conv.weight.shape[0]
+        mel = _f32c(mel)
+        Fo, To = (NM - 1) // 2 + 1, (F - 1) // 2 + 1
+        adt = rt.act_dtype()
+        y = empty((B * To, C * Fo), adt, mel)
+        st = BNState(C, mel)
+        lib.audio_stem_conv_fwd(rt.dt(), mel.data_ptr(), conv.weight.data_ptr(), _p(conv.bias), y.data_ptr(), st.stats.data_ptr() if training else None,
+                                B, NM, F, C, rt.stream())
+        count = B * To * Fo
+        cp = bn_finalize(bn, st, count, training)
+        a = empty((B, To, C * Fo), adt, mel)
+        lib.audio_stem_act_fwd(rt.dt(), y.data_ptr(), st.ss.data_ptr(), a.data_ptr(), B, NM, F, C, rt.stream())
+        ctx.saved = (mel, y, st, cp, count, conv, bn, B, NM, F, C, training)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        mel, y, st, cp, count, conv, bn, B, NM, F, C, training = ctx.saved
+        assert training, "AudioStem backward is implemented for training-mode BatchNorm"
+        da = da.to(rt.act_dtype()).contiguous()
+        dstats = torch.zeros(2 * C, dtype=torch.float32, device=mel.device)
+        base = (da.data_ptr(), y.data_ptr(), mel.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(count))
+        lib.audio_stem_bwd(rt.dt(), *base, 0, None, None, None, None, B, NM, F, C, rt.stream())
+        _sync_stats(dstats)
+        lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
+                           grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B, NM, F, C, rt.stream())
+        return None, None, None, None
+
+
+# ============================================================================================
+# mel front-end (no gradient): AudioPreprocessing.forward (nnet/preprocessing.py:57-85)
+# ============================================================================================
+def mel_spectrogram(audio, window, dft, fb, n_fft, win, hop, n_mels):
+    """audio fp32 [B,L]; window [win]; dft fp32 [2*nb][win] (cos rows then -sin rows); fb [nb][n_mels] -> [B,n_mels,L//hop+1] fp32"""
+    rt.require_gpu(audio)
+    from .lib import F32
+    B, L = audio.shape
+    audio = _f32c(audio)
+    F = L // hop + 1
+    nb = n_fft // 2 + 1
+    frames = empty((B * F, win), torch.float32, audio)
+    lib.mel_frames(audio.data_ptr(), window.data_ptr(), frames.data_ptr(), B, L, n_fft, win, hop, rt.stream())
+    spec = empty((B * F, 2 * nb), torch.float32, audio)
+    gemm_nt(frames, dft, spec, B * F, 2 * nb, win, out_f32=True, dtype=F32)
+    out = empty((B, n_mels, F), torch.float32, audio)
+    lib.mel_power_log(spec.data_ptr(), fb.data_ptr(), out.data_ptr(), B, F, nb, n_mels, rt.stream())
+    return out
+
+
+def spec_augment_(mel, lens, mF, Fp, mT, pS, sid):
+    B, NM, F = mel.shape
+    lens_ = None if lens is None else lens.to(device=mel.device, dtype=torch.int64).contiguous()
+    lib.specaugment(mel.data_ptr(), _p(lens_), B, NM, F, mF, Fp, mT, pS, rt.rng_state(mel.device).data_ptr(), sid, rt.stream())
+    return mel
+
+
+def argmax_rows(logits):
+    B, T, V = logits.shape
+    lg = _f32c(logits)
+    out = torch.empty((B, T), dtype=torch.int64, device=lg.device)
+    lib.argmax_rows(lg.data_ptr(), out.data_ptr(), B * T, V, rt.stream())
+    return out

@@ -1,0 +1,216 @@
+"""Engine state shared by the host-side modules: compute dtype, dropout RNG state, weight shadows and the
+flat parameter arena (one fp32 master / gradient buffer per model => one Adam launch, one RCCL all-reduce).
+
+PyTorch is used here for device memory, streams and torch.distributed only."""
+import os
+
+import torch
+
+from .lib import BF16, F32, lib
+
+_STATE = {"dtype": None, "rng": {}, "stream_id": 0, "seed": 0x5EED5EED, "sync_bn": False}
+
+
+def set_compute_dtype(name):
+    """'f32' : fp32 storage + fp32 MFMA (exact, parity mode);  'bf16' : bf16 storage + bf16 MFMA, fp32 accumulate."""
+    name = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "bf16"}.get(name, name)
+    assert name in ("f32", "bf16"), name
+    _STATE["dtype"] = name
+
+
+def compute_dtype():
+    if _STATE["dtype"] is None:
+        _STATE["dtype"] = os.environ.get("AVEC_DTYPE", "f32")
+    return _STATE["dtype"]
+
+
+def dt():
+    return BF16 if compute_dtype() == "bf16" else F32
+
+
+def act_dtype():
+    return torch.bfloat16 if compute_dtype() == "bf16" else torch.float32
+
+
+def new_stream_id():
+    _STATE["stream_id"] += 1
+    return _STATE["stream_id"]
+
+
+def manual_seed(seed):
+    _STATE["seed"] = int(seed)
+    for t in _STATE["rng"].values():
+        t[0] = int(seed)
+        t[1] = 0
+
+
+def rng_state(device):
+    """int64[2] = {seed, step} on `device`; kernels derive per-site masks from (seed, step, site id, element)."""
+    key = str(device)
+    if key not in _STATE["rng"]:
+        _STATE["rng"][key] = torch.tensor([_STATE["seed"], 0], dtype=torch.int64, device=device)
+    return _STATE["rng"][key]
+
+
+def advance_rng(device):
+    rng_state(device)[1] += 1
+
+
+def set_sync_batchnorm(flag):
+    _STATE["sync_bn"] = bool(flag)
+
+
+def sync_batchnorm():
+    return _STATE["sync_bn"] and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("avec_amd: the HIP path needs tensors on a GPU (got %s); there is no CPU fallback -- "
+                           "the CPU restatement lives in oracle/ and is test infrastructure only" % t.device)
+
+
+# --------------------------------------------------------------------------------------------
+# weight shadows
+# --------------------------------------------------------------------------------------------
+class Shadow:
+    """Compute-dtype copies of one GEMM weight: `fwd` = physical order [A][Tm][C], `bwd` = [C][Tm][A]."""
+    __slots__ = ("A", "Tm", "C", "need_bwd", "fwd", "bwd", "stamp", "arena", "_table")
+
+    def __init__(self, A, Tm, C, need_bwd=True):
+        self.A, self.Tm, self.C, self.need_bwd = A, Tm, C, need_bwd
+        self.fwd = self.bwd = None
+        self.stamp = None
+        self.arena = None
+        self._table = None
+
+
+def register_weight(param, A, Tm, C, need_bwd=True):
+    param._avec_shadow = Shadow(A, Tm, C, need_bwd)
+    return param
+
+
+def _refresh_single(param, sh):
+    n = sh.A * sh.Tm * sh.C
+    adt = act_dtype()
+    buf = torch.empty(n * (2 if sh.need_bwd else 1), dtype=adt, device=param.device)
+    blocks = (n + 1023) // 1024
+    table = torch.tensor([0, 0, n if sh.need_bwd else -1, sh.A, sh.Tm, sh.C, 0, blocks], dtype=torch.int64, device=param.device)
+    src = param.detach()
+    assert src.is_non_overlapping_and_dense()
+    lib.shadow_refresh(dt(), src.data_ptr(), buf.data_ptr(), table.data_ptr(), 1, blocks, stream())
+    sh.fwd = buf[:n]
+    sh.bwd = buf[n:] if sh.need_bwd else None
+    sh._table = table  # keep alive until the kernel ran
+
+
+def shadow(param):
+    sh = param._avec_shadow
+    if sh.arena is not None:
+        sh.arena.ensure_fresh()
+        return sh
+    stamp = (param._version, param.data_ptr(), compute_dtype())
+    if sh.stamp != stamp:
+        _refresh_single(param, sh)
+        sh.stamp = stamp
+    return sh
+
+
+
+# --------------------------------------------------------------------------------------------
+# flat parameter arena
+# --------------------------------------------------------------------------------------------
+class ParamArena:
+    def __init__(self, module):
+        params = []
+        seen = set()
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        assert params and all(p.is_cuda for p in params), "ParamArena needs the model on a GPU"
+        dev = params[0].device
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(params, self.offsets):
+            assert p.dtype == torch.float32 and p.is_non_overlapping_and_dense(), "unsupported parameter layout"
+            new = self.master[o:o + p.numel()].as_strided(p.shape, p.stride())
+            new.copy_(p.data)
+            p.data = new
+            p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+        self.device = dev
+        self._shadow_dtype = None
+        self.dirty = True
+        self._build_shadows()
+
+    def _build_shadows(self):
+        adt = act_dtype()
+        rows, soff, blocks = [], 0, 0
+        for p, o in zip(self.params, self.offsets):
+            sh = getattr(p, "_avec_shadow", None)
+            if sh is None:
+                continue
+            n = sh.A * sh.Tm * sh.C
+            fwd = soff
+            soff += (n + 7) // 8 * 8
+            bwd = -1
+            if sh.need_bwd:
+                bwd = soff
+                soff += (n + 7) // 8 * 8
+            nb = (n + 1023) // 1024
+            rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb])
+            blocks += nb
+        self.shadow = torch.empty(max(soff, 8), dtype=adt, device=self.device)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self.n_entries, self.total_blocks = len(rows), blocks
+        i = 0
+        for p in self.params:
+            sh = getattr(p, "_avec_shadow", None)
+            if sh is None:
+                continue
+            _, fwd, bwd, A, Tm, C, _, _ = rows[i]
+            n = A * Tm * C
+            sh.fwd = self.shadow[fwd:fwd + n]
+            sh.bwd = self.shadow[bwd:bwd + n] if bwd >= 0 else None
+            sh.arena = self
+            i += 1
+        self._shadow_dtype = compute_dtype()
+        self.dirty = True
+
+    def ensure_fresh(self):
+        if self._shadow_dtype != compute_dtype():
+            self._build_shadows()
+        if self.dirty:
+            lib.shadow_refresh(dt(), self.master.data_ptr(), self.shadow.data_ptr(), self.table.data_ptr(), self.n_entries,
+                               self.total_blocks, stream())
+            self.dirty = False
+
+    def mark_dirty(self):
+        self.dirty = True
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def all_reduce_grads(self, bucket_bytes=64 << 20):
+        """DDP gradient averaging: sum over ranks in large contiguous buckets (RCCL over xGMI); the 1/world factor is
+        folded into the Adam kernel's grad_scale."""
+        import torch.distributed as dist
+        n = self.numel
+        step = max(bucket_bytes // 4, 1)
+        works = []
+        for s in range(0, n, step):
+            works.append(dist.all_reduce(self.grad[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()

@@ -54,7 +54,7 @@ typedef struct avec_epilogue {
   const float* bias;                           /* [N] */
   int act;                                     /* 0 none, 1 Swish (nnet/activations.py:39-45), 2 ReLU */
   float drop_p; const unsigned long long* rng; unsigned rng_stream;  /* nn.Dropout: counter-based mask, rng = {seed, step} on device */
-  const float* res; long long ldres; float alpha;   /* out = res + alpha * v   (residual connections, nnet/blocks.py:292-301) */
+  const void* res; long long ldres; float alpha; int res_act; /* out = res + alpha * v (res fp32, or act when res_act; residuals nnet/blocks.py:292-301) */
   const void* dact_z; long long ldz; int dact; /* backward: v *= act'(z) */
   float* colsum;                               /* += per-column sum of v  (bias gradients) */
   float* stats;                                /* += [N] sum, [N] sum of squares (BatchNorm batch statistics) */
@@ -78,11 +78,12 @@ int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const a
 int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int y_f32,
                        float* mean, float* rstd, long long M, int D, float eps, hipStream_t stream);
 int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
-                       float* dx, int dx_accum, float* dgamma, float* dbeta, long long M, int D, hipStream_t stream);
+                       float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t stream);
 /* backward of out = res + alpha*Dropout(acc + bias): dacc (act) and dbias; nnet/modules.py:286-288 + nnet/blocks.py:292-301 */
 int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
                    unsigned rng_stream, float* dbias, long long M, int N, hipStream_t stream);
-int avec_colsum(int dtype, const void* x, float* out, long long M, int N, hipStream_t stream);
+int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t stream);
+int avec_strided_rows_add(float* dx, const float* src, int B, int T, int To, int D, int step, hipStream_t stream);
 /* BatchNorm{1,2,3}d over channels-last [M][C] (aten::native_batch_norm(_backward), nnet/normalizations.py:42-170).
  * stats = [sum | sumsq]; ss = [scale | shift | mean | rstd]; SyncBatchNorm (:172-249) = all-reduce stats/count/dstats between calls. */
 int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t stream);
@@ -94,7 +95,7 @@ int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* ou
                       const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t stream);
 /* softmax of the InterCTC residual (nnet/modules.py:395-400) */
 int avec_softmax_fwd(int dtype, const float* logits, void* probs, long long M, int V, hipStream_t stream);
-int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, int accum, long long M, int V, hipStream_t stream);
+int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, const float* dadd, long long M, int V, hipStream_t stream);
 int avec_cast_rows(int dtype, const float* src, long long ld_src, void* dst, long long ld_dst, long long M, int N, hipStream_t stream);
 int avec_to_f32_rows(int dtype, const void* src, long long ld_src, float* dst, long long ld_dst, long long M, int N, int accum, hipStream_t stream);
 int avec_dropout_f32(const float* x, float* y, float p, const unsigned long long* rng, unsigned rng_stream, long long n, hipStream_t stream);
