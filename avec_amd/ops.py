@@ -290,7 +290,12 @@ class AttentionModuleFn(torch.autograd.Function):
         B, T, D = x.shape
         x2 = _f32c(x.reshape(-1, D))
         M, d, adt = B * T, D // H, rt.act_dtype()
-        h, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+        if ln_w is not None:
+            h, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+        else:                      # bare attention layer (forwardQKV called directly): no pre-norm
+            mean = rstd = None
+            h = empty((M, D), adt, x2)
+            lib.cast_rows(rt.dt(), x2.data_ptr(), D, h.data_ptr(), D, M, D, rt.stream())
         if patch > 1:
             Tp = (T + patch - 1) // patch
             hp = empty((B * Tp, D), adt, x2)
@@ -370,7 +375,11 @@ class AttentionModuleFn(torch.autograd.Function):
             lib.patch_pool_bwd(rt.dt(), dhp.data_ptr(), dh.data_ptr(), B, T, D, patch, rt.stream())
         else:
             dh = dhp
-        dx = layernorm_bwd(dh, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy if residual else None)
+        if ln_w is not None:
+            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy if residual else None)
+        else:
+            dx = dy.clone() if residual else torch.zeros_like(dy)
+            lib.to_f32_rows(rt.dt(), dh.data_ptr(), D, dx.data_ptr(), D, M, D, 1, rt.stream())
         return (dx.view(B, T, D),) + (None,) * 20
 
 
