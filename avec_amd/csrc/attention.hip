@@ -21,9 +21,10 @@ struct AttnArgs {
   const void *q, *k, *v; long long ld;      // act, row stride (elements); head h occupies columns [h*d, (h+1)*d)
   const void* e; long long lde;             // act [2T-1][lde]
   const long long* lens; int len_div;       // key j kept iff j < lens[b] / len_div  (null: all kept)
+  int q_full;                               // query rows i >= q_full see every key masked (the zero-padded last patch, nnet/attentions.py:152-154,357-362)
   const float* mask; long long mask_bstride; // optional dense mask [Bm][T][T] (1 = keep); overrides lens
   void* o; long long ldo;                    // act [B*T][ldo]
-  float* lse;                                // [B*H][T]
+  float* lse;                                // [B*H][T][2] = (row max m, row sum l): kept apart, m + log l loses log l when every key is masked (m = -1e9)
   const void* dout;                          // act [B*T][ldo]   (backward)
   void *dq, *dk, *dv; long long lddq, ldd;   // dq: act, row stride lddq; dk/dv: row stride ldd
   float* de; long long ldde;                 // fp32 [2T-1][ldde], atomically accumulated
@@ -33,6 +34,7 @@ struct AttnArgs {
 template <typename T>
 __device__ __forceinline__ bool key_keep(const AttnArgs& a, int b, int i, int j) {
   if (a.mask) return a.mask[(long long)b * a.mask_bstride + (long long)i * a.T + j] != 0.f;
+  if (i >= a.q_full) return false;
   if (a.lens) return j < (int)(a.lens[b] / a.len_div);
   return true;
 }
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
   if (BWD) load_rows<T>(Gs, DP, (const T*)a.dout + (long long)b * Tn * a.ldo + h * d, a.ldo, i0, TQ, Tn, d);
   __syncthreads();
 
-  float m_run[4], l_run[4], acc[4][2], Li[4], dl[4];
+  float m_run[4], l_run[4], acc[4][2], Li[4], Il[4], dl[4];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; dl[rr] = 0.f; }
+  for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; Il[rr] = 0.f; dl[rr] = 0.f; }
   if (BWD) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
       if (i < Tn) {
         const T* op = (const T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
         for (int c = lane; c < d; c += 64) s += Gs[ri * DP + c] * ldf(op + c);
-        Li[rr] = a.lse[(long long)bh * Tn + i];
+        Li[rr] = a.lse[((long long)bh * Tn + i) * 2]; Il[rr] = 1.f / a.lse[((long long)bh * Tn + i) * 2 + 1];
       }
       dl[rr] = wave_sum(s);
     }
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
         l_run[rr] = l_run[rr] * alpha + wave_sum(pval);
         acc[rr][0] *= alpha; acc[rr][1] *= alpha; m_run[rr] = m_new;
       } else {
-        float p = (iv && jv) ? __expf(s - Li[rr]) : 0.f;
+        float p = (iv && jv) ? __expf(s - Li[rr]) * Il[rr] : 0.f;
         pval = p * (dp - dl[rr]) * a.scale;   // dS
       }
       Ps[w * 64 + lane] = pval;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
       T* op = (T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
       if (lane < d) stf(op + lane, acc[rr][0] * inv);
       if (lane + 64 < d) stf(op + lane + 64, acc[rr][1] * inv);
-      if (lane == 0) a.lse[(long long)bh * Tn + i] = m_run[rr] + __logf(l_run[rr]);
+      if (lane == 0) { a.lse[((long long)bh * Tn + i) * 2] = m_run[rr]; a.lse[((long long)bh * Tn + i) * 2 + 1] = l_run[rr]; }
     } else {
       T* op = (T*)a.dq + ((long long)b * Tn + i) * a.lddq + h * d;
       if (lane < d) stf(op + lane, acc[rr][0]);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
   float* Ks = sm; float* Vs = Ks + TK * DP; float* dEs = Vs + TK * DP;            // dEs: [QS+TK-1][DP]
   float* Es = dEs + (QS + TK - 1) * DP;                                            // [QC+TK-1][DP]
   float* Qs = Es + (QC + TK - 1) * DP; float* Gs = Qs + QC * DP;                   // [QC][DP] each
-  float* Ls = Gs + QC * DP; float* Ds = Ls + QC;                                   // [QC] lse, delta
+  float* Ls = Gs + QC * DP; float* Ds = Ls + QC; float* Is = Ds + QC;              // [QC] row max, delta, 1/row sum
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int j0 = blockIdx.x * TK, is = blockIdx.z * QS;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
       const int i = ic + qi; float s = 0.f;
       if (i < Tn) for (int c = lane; c < d; c += 64) s += Gs[qi * DP + c] * ldf(op + (long long)i * a.ldo + c);
       s = wave_sum(s);
-      if (lane == 0) { Ds[qi] = s; Ls[qi] = (i < Tn) ? a.lse[(long long)bh * Tn + i] : 0.f; }
+      if (lane == 0) { Ds[qi] = s; Ls[qi] = (i < Tn) ? a.lse[((long long)bh * Tn + i) * 2] : 0.f; Is[qi] = (i < Tn) ? 1.f / a.lse[((long long)bh * Tn + i) * 2 + 1] : 0.f; }
     }
     __syncthreads();
     for (int qi = w; qi < QC; qi += 4) {
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
       for (int c = 0; c < d; ++c) { s += qrow[c] * (krow[c] + erow[c]); dp += grow[c] * vrow[c]; }
       s *= a.scale;
       if (jv && !key_keep<T>(a, b, i, j)) s += -1e9f;
-      const float p = jv ? __expf(s - Ls[qi]) : 0.f;
+      const float p = jv ? __expf(s - Ls[qi]) * Is[qi] : 0.f;
       const float ds = p * (dp - Ds[qi]) * a.scale;
       float* derow = dEs + (is + QS - 1 - i + lane) * DP;
 #pragma unroll
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 static int fill_args(AttnArgs& a, const avec_attn_t* p) {
-  a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1;
+  a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1; a.q_full = p->q_full > 0 ? p->q_full : p->T;
   a.mask = p->mask; a.mask_bstride = p->mask_bstride; a.o = p->o; a.ldo = p->ldo; a.lse = p->lse; a.dout = p->dout;
   a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde;
   a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale;

@@ -35,7 +35,7 @@ class Epilogue(ctypes.Structure):
 class Attn(ctypes.Structure):
     _fields_ = [("q", ctypes.c_void_p), ("k", ctypes.c_void_p), ("v", ctypes.c_void_p), ("ld", ctypes.c_longlong),
                 ("e", ctypes.c_void_p), ("lde", ctypes.c_longlong),
-                ("lens", ctypes.c_void_p), ("len_div", ctypes.c_int),
+                ("lens", ctypes.c_void_p), ("len_div", ctypes.c_int), ("q_full", ctypes.c_int),
                 ("mask", ctypes.c_void_p), ("mask_bstride", ctypes.c_longlong),
                 ("o", ctypes.c_void_p), ("ldo", ctypes.c_longlong), ("lse", ctypes.c_void_p),
                 ("dout", ctypes.c_void_p),

@@ -28,7 +28,7 @@ class ResNetBlock(nn.Module):
             self.residual = nn.Identity()
 
     def forward_nhwc(self, x):
-        return ops.ResNetBlockFn.apply(x, self, self.training)
+        return ops.ResNetBlockFn.apply(x, self.layers[0].weight, self, self.training)
 
     def forward(self, x):
         """logical NCHW in / out (reference interface)"""

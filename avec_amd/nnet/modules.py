@@ -123,7 +123,7 @@ class ConvolutionModule(nn.Module):
     def residual_forward(self, x, res_conv):
         """R(x) + ConvModule(x) with R = identity or the strided k=1 conv of the block (nnet/blocks.py:273-277,298)."""
         p = self.layers[7].p if self.training else 0.0
-        return ops.ConvModuleFn.apply(x, self, res_conv, p, self.sid, self.training)
+        return ops.ConvModuleFn.apply(x, self.layers[1].weight, self, res_conv, p, self.sid, self.training)
 
     def forward(self, x):
         assert self.layers[3].stride[0] == 1 and self.layers[1].in_channels == self.layers[6].out_channels

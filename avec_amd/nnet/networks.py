@@ -122,7 +122,7 @@ class AudioEfficientConformerEncoder(nn.Module):
         mel, lengths = self.audio_preprocessing(x, lengths)
         mel = self.spec_augment(mel, lengths)
         stem = self.subsampling_module.layers[0]
-        a = ops.AudioStemFn.apply(mel, stem[0], stem[1], stem[1].training and not stem[1].frozen)     # (B, T', 7200) act
+        a = ops.AudioStemFn.apply(mel, stem[0].weight, stem[0], stem[1], stem[1].training and not stem[1].frozen)     # (B, T', 7200) act
         lengths = torch.div(lengths - 1, 2, rounding_mode="floor") + 1
         x = ops.linear(a, self.linear.weight, self.linear.bias)
         x, lengths, inter = self.back_end(x, lengths)
@@ -155,7 +155,7 @@ class VisualEfficientConformerEncoder(nn.Module):
         assert C == 1
         stem = self.front_end[0].layers[0]
         bn = stem[1]
-        frames = ops.VideoStemFn.apply(x.reshape(B, T, H, W), stem[0], bn, bn.training and not bn.frozen)     # (B*T, H/4, W/4, 64) act, channels-last
+        frames = ops.VideoStemFn.apply(x.reshape(B, T, H, W), stem[0].weight, stem[0], bn, bn.training and not bn.frozen)     # (B*T, H/4, W/4, 64) act, channels-last
         feats = self.front_end[3].forward_nhwc(frames)                                                          # (B*T, 256) fp32
         x = feats.view(B, T, -1)
         x, lengths, inter = self.back_end(x, lengths)

@@ -13,6 +13,53 @@ from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, ROWS_CONV_BWD, ROWS_CONV_FWD, RO
 _byref = ctypes.byref
 
 
+class KernelTimer:
+    """HIP-event timing of the GEMM-family launches (bench.py roofline): events are recorded on the launch stream around each
+    launch while enabled; durations are read after the timed region."""
+    NAMES = {(0, ROWS_CONV_FWD): "gemm_nt<conv_fwd>", (0, ROWS_CONV_BWD): "gemm_nt<conv_bwd_data>", (0, ROWS_STEM3D): "gemm_nt<stem3d>",
+             (0, ROWS_PLAIN): "gemm_nt<plain>", (1, ROWS_CONV_FWD): "gemm_tn<conv_wgrad>", (1, ROWS_STEM3D): "gemm_tn<stem3d_wgrad>",
+             (1, ROWS_PLAIN): "gemm_tn<plain>"}
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled):
+        self.enabled, self.records = enabled, []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, key, flops):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+
+    def summary(self, peak_tflops):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += 1
+        key = max(agg, key=lambda k: agg[k][0])
+        t, fl, n = agg[key]
+        achieved = fl / t / 1e12
+        return {"bound": "mfma", "kernel": self.NAMES.get(key, str(key)), "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
+                "alg_gflop_per_launch": round(fl / n / 1e9, 3),
+                "families": {self.NAMES.get(k, str(k)): {"ms_total": round(1e3 * v[0], 3), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2]}
+                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+
+
+KERNEL_TIMER = KernelTimer()
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -59,8 +106,11 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     ep.colsum, ep.stats = _p(colsum), _p(stats)
     if rows is None:
         rows = rows_plain(K)
+    ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     lib.gemm_nt(rt.dt() if dtype is None else dtype, A.data_ptr(), _byref(rows), mode, int(a_f32), W.data_ptr(),
                 K if ldw is None else ldw, M, N, K, _byref(ep), rt.stream())
+    if ev is not None:
+        KERNEL_TIMER.stop(ev, (0, mode), 2.0 * M * N * K)
     return out
 
 
@@ -68,8 +118,11 @@ def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32
     """O[I][J] (fp32) += P[M][I]^T Q[M][J]"""
     if q_rows is None:
         q_rows = rows_plain(J)
+    ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     lib.gemm_tn(rt.dt() if dtype is None else dtype, P.data_ptr(), I if ldp is None else ldp, Q.data_ptr(), _byref(q_rows), q_mode,
                 int(q_f32), O.data_ptr(), J if ldo is None else ldo, M, I, J, rt.stream())
+    if ev is not None:
+        KERNEL_TIMER.stop(ev, (1, q_mode), 2.0 * M * I * J)
 
 
 def layernorm_fwd(x, w, b, M, D, out_f32, eps):
@@ -270,8 +323,9 @@ def rel_pos_table(T, D, device):
     return _PE_CACHE[key]
 
 
-def _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D):
+def _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D, q_full=0):
     a = Attn()
+    a.q_full = q_full
     esz = qkv.element_size()
     a.q, a.k, a.v, a.ld = qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, 3 * D
     a.e, a.lde = e.data_ptr(), D
@@ -313,8 +367,9 @@ class AttentionModuleFn(torch.autograd.Function):
         pe = rel_pos_table(Tp, D, x.device)
         e = linear_fwd(pe, wp, bp, 2 * Tp - 1, in_f32=False, out_f32=False)
         o = empty((Mp, D), adt, x2)
-        lse = empty((B * H, Tp), torch.float32, x2)
-        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D)
+        lse = empty((B * H, Tp, 2), torch.float32, x2)
+        q_full = T // patch if (patch > 1 and mask is None) else 0
+        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D, q_full)
         lib.relpos_attention_fwd(rt.dt(), _byref(a), rt.stream())
         res = x2 if residual else None
         if patch > 1:
@@ -346,7 +401,7 @@ class AttentionModuleFn(torch.autograd.Function):
         do = linear_bwd_input(doo, wo, Mp, out_f32=False)
         dqkv = empty((Mp, 3 * D), adt, dy)
         de = torch.zeros((2 * Tp - 1, D), dtype=torch.float32, device=dy.device)
-        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D)
+        a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D, T // patch if (patch > 1 and mask is None) else 0)
         a.dout = do.data_ptr()
         esz = dqkv.element_size()
         a.dq, a.lddq = dqkv.data_ptr(), 3 * D
@@ -436,7 +491,7 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
 
 class ConvModuleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mod, res_conv, drop_p, sid, training):
+    def forward(ctx, x, _anchor, mod, res_conv, drop_p, sid, training):
         """mod: ConvolutionModule (layers: 0 LN, 1 pw1, 3 dw, 4 BN, 6 pw2);  res_conv: strided k=1 Conv1d or None"""
         rt.require_gpu(x)
         B, T, D = x.shape
@@ -493,7 +548,7 @@ class ConvModuleFn(torch.autograd.Function):
             linear_bwd_weight(dracc, x2, res_conv.weight, Mo, q_f32=(adt != torch.float32), q_rows=rows_plain(D, To, T, rs) if rs > 1 else None)
             dxr = linear_bwd_input(dracc, res_conv.weight, Mo, out_f32=True)
             lib.strided_rows_add(dx.data_ptr(), dxr.data_ptr(), B, T, To, D, rs, rt.stream())
-        return dx.view(B, T, D), None, None, None, None, None
+        return dx.view(B, T, D), None, None, None, None, None, None
 
 
 def _bn_eval_backward(bn, st, dout, y, act, M, out=None):
@@ -651,7 +706,7 @@ class ResNetBlockFn(torch.autograd.Function):
     """x: act NHWC [N,H,W,Cin] -> act NHWC [N,OH,OW,Cout]"""
 
     @staticmethod
-    def forward(ctx, x, blk, training):
+    def forward(ctx, x, _anchor, blk, training):
         rt.require_gpu(x)
         N, H, W, Cin = x.shape
         conv1, bn1, conv2, bn2 = blk.layers[0], blk.layers[1], blk.layers[3], blk.layers[4]
@@ -701,7 +756,7 @@ class ResNetBlockFn(torch.autograd.Function):
             dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx)
         else:
             dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres)
-        return (dx.view(N, H, W, Cin) if dx is not None else None), None, None
+        return (dx.view(N, H, W, Cin) if dx is not None else None), None, None, None
 
 
 class VideoStemFn(torch.autograd.Function):
@@ -709,7 +764,7 @@ class VideoStemFn(torch.autograd.Function):
     video fp32 [B,T,H,W] -> act NHWC [B*T, H/4, W/4, C]      (nnet/networks.py:459-470)"""
 
     @staticmethod
-    def forward(ctx, video, conv, bn, training):
+    def forward(ctx, video, _anchor, conv, bn, training):
         rt.require_gpu(video)
         B, T, H, W = video.shape
         C = conv.weight.shape[0]
@@ -745,7 +800,7 @@ class VideoStemFn(torch.autograd.Function):
         gemm_tn(dy, v, grad_of(conv.weight), M, C, K, q_rows=r, q_mode=ROWS_STEM3D, q_f32=True)
         if conv.bias is not None:
             grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):
@@ -773,7 +828,7 @@ class AudioStemFn(torch.autograd.Function):
     """Conv2d(1->C,3x3,s2,'same') + BatchNorm2d + Swish on mel [B,80,F] -> act [B, T', C*40]   (nnet/networks.py:359-377)"""
 
     @staticmethod
-    def forward(ctx, mel, conv, bn, training):
+    def forward(ctx, mel, _anchor, conv, bn, training):
         rt.require_gpu(mel)
         B, NM, F = mel.shape
         C = conv.weight.shape[0]
@@ -802,7 +857,7 @@ class AudioStemFn(torch.autograd.Function):
         _sync_stats(dstats)
         lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
                            grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B, NM, F, C, rt.stream())
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 # ============================================================================================

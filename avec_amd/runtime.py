@@ -69,6 +69,16 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def is_dense(t):
+    """non-overlapping and dense: the strides are a permutation of a contiguous layout"""
+    exp = 1
+    for st, sz in sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1):
+        if st != exp:
+            return False
+        exp *= sz
+    return True
+
+
 def require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError("avec_amd: the HIP path needs tensors on a GPU (got %s); there is no CPU fallback -- "
@@ -102,7 +112,7 @@ def _refresh_single(param, sh):
     blocks = (n + 1023) // 1024
     table = torch.tensor([0, 0, n if sh.need_bwd else -1, sh.A, sh.Tm, sh.C, 0, blocks], dtype=torch.int64, device=param.device)
     src = param.detach()
-    assert src.is_non_overlapping_and_dense()
+    assert is_dense(src)
     lib.shadow_refresh(dt(), src.data_ptr(), buf.data_ptr(), table.data_ptr(), 1, blocks, stream())
     sh.fwd = buf[:n]
     sh.bwd = buf[n:] if sh.need_bwd else None
@@ -145,7 +155,7 @@ class ParamArena:
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         for p, o in zip(params, self.offsets):
-            assert p.dtype == torch.float32 and p.is_non_overlapping_and_dense(), "unsupported parameter layout"
+            assert p.dtype == torch.float32 and is_dense(p), "unsupported parameter layout"
             new = self.master[o:o + p.numel()].as_strided(p.shape, p.stride())
             new.copy_(p.data)
             p.data = new

@@ -1,0 +1,140 @@
+"""Benchmark of the hot path: AV Efficient Conformer training step (forward + 6 CTC losses + backward + gradient all-reduce + Adam)
+on synthetic LRS2-shaped batches: B=32 per GPU, audio 63 840 samples (400 mel frames), video 100x88x88, 20 labels.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Prints ONE JSON line (rank 0): whole-job utterances/s, plus `roofline` for the dominant kernel (implicit-GEMM convolution family,
+timed live with HIP events inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_UTT = 214.16          # fwd+bwd, conv/linear/bmm only
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def synthetic_batch(B, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(B, 100, 88, 88, 1, generator=g)
+    audio = 0.1 * torch.randn(B, 63840, generator=g)
+    labels = torch.randint(1, 256, (B, 20), generator=g)
+    vlen, alen, llen = torch.full((B,), 100), torch.full((B,), 63840), torch.full((B,), 20)
+    return [t.to(device) for t in (video, vlen, audio, alen)], (labels.to(device), llen.to(device))
+
+
+def cpu_baseline(budget_s=20.0):
+    """CPU oracle (oracle/avec_oracle.py, a restatement shown equal to the reference) fwd+bwd at B=2, all host cores."""
+    import nnet
+    from oracle import avec_oracle as O
+    torch.manual_seed(0)
+    model = nnet.AudioVisualEfficientConformerInterCTC()
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in model.state_dict().items()}
+    del model
+    B = 2
+    g = torch.Generator().manual_seed(0)
+    video, audio = torch.randn(B, 100, 88, 88, 1, generator=g), 0.1 * torch.randn(B, 63840, generator=g)
+    vlen, alen = torch.full((B,), 100), torch.full((B,), 63840)
+    labels, llen = torch.randint(1, 256, (B, 20), generator=g), torch.full((B,), 20)
+    times = []
+    t_start = time.time()
+    while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 8):
+        t0 = time.time()
+        out = O.av_forward(sd, video, vlen, audio, alen, train=True, stats_out={})
+        O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)["loss"].backward()
+        times.append(time.time() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B / best, 3), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle fwd+bwd, B=2 x %d iterations (best), fp32, %d host cores visible" % (len(times), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+
+    import avec_amd
+    import nnet
+    from avec_amd import ops
+    avec_amd.set_compute_dtype(args.dtype)
+    avec_amd.manual_seed(1234 + rank)
+    torch.manual_seed(0)
+    model = nnet.AudioVisualEfficientConformerInterCTC(vocab_size=256, v_interctc_blocks=[3, 6], a_interctc_blocks=[8, 11], f_interctc_blocks=[2])
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
+    model = model.to(device).train()
+    if world > 1:
+        model.distribute_strategy(local_rank)
+    inputs, targets = synthetic_batch(args.batch, device, seed=rank)
+    precision = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last, _, _ = model.train_step(inputs, targets, precision=precision)
+    barrier()
+    ops.KERNEL_TIMER.reset(enabled=(rank == 0 and not args.no_kernel_timing))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last, _, _ = model.train_step(inputs, targets, precision=precision)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(last["loss"])
+    assert loss == loss and abs(loss) < 1e6, "training step produced a non-finite loss"
+
+    if rank == 0:
+        utt = world * args.batch * args.steps
+        value = utt / elapsed
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        roof = ops.KERNEL_TIMER.summary(peak)
+        out = {
+            "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "AV EffConfInterCTC (LRS23/AV) training step: fwd + 6 CTC losses + bwd + grad all-reduce + Adam; "
+                                   "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "params": 61738836, "loss": round(loss, 4),
+                       "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

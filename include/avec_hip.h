@@ -122,8 +122,9 @@ typedef struct avec_attn {
   const void *q, *k, *v; long long ld;        /* act [B*T][ld]; head h = columns [h*d,(h+1)*d) */
   const void* e; long long lde;               /* act [2T-1][lde]: pos_layer(sinusoid rows p = T-1 .. -(T-1)) (nnet/embeddings.py:101-158) */
   const long long* lens; int len_div;         /* key j kept iff j < lens[b]/len_div (Mask.padding_mask, nnet/attentions.py:682-733; patch min-pool :357-362) */
+  int q_full;                                 /* query rows >= q_full are fully masked (zero-padded last patch); 0 = T */
   const float* mask; long long mask_bstride;  /* optional dense (Bm,T,T) 0/1 mask (1 = keep) instead of lens */
-  void* o; long long ldo; float* lse;         /* outputs: act [B*T][ldo], fp32 [B*H][T] */
+  void* o; long long ldo; float* lse;         /* outputs: act [B*T][ldo], fp32 [B*H][T][2] = softmax row (max, sum) */
   const void* dout;                           /* backward input, act [B*T][ldo] */
   void *dq, *dk, *dv; long long lddq, ldd;    /* dq act (stride lddq); dk/dv act (T<=64) or fp32 scratch (stride ldd) */
   float* de; long long ldde;                  /* fp32 [2T-1][ldde], accumulated */
