@@ -14,8 +14,7 @@
 
 static constexpr int TQ = 16;    // query rows per workgroup (fwd / bwd1): 4 waves x 4 rows
 static constexpr int TK = 64;    // keys per tile = one per lane
-static constexpr int QS = 64;    // query segment per workgroup in bwd2
-static constexpr int QC = 8;     // queries staged per chunk in bwd2
+static constexpr int QC = 32;    // queries staged per chunk in the column pass (dK/dV/dE)
 
 struct AttnArgs {
   const void *q, *k, *v; long long ld;      // act, row stride (elements); head h occupies columns [h*d, (h+1)*d)
@@ -28,6 +27,7 @@ struct AttnArgs {
   const void* dout;                          // act [B*T][ldo]   (backward)
   void *dq, *dk, *dv; long long lddq, ldd;   // dq: act, row stride lddq; dk/dv: row stride ldd
   float* de; long long ldde;                 // fp32 [2T-1][ldde], atomically accumulated
+  float *pbuf, *dsbuf;                       // backward scratch [B*H][T][T] fp32: probabilities and dS (written by the dQ pass)
   int B, H, T, d; float scale;
 };
 
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
       } else {
         float p = (iv && jv) ? __expf(s - Li[rr]) * Il[rr] : 0.f;
         pval = p * (dp - dl[rr]) * a.scale;   // dS
+        if (iv && jv) { const long long o = ((long long)bh * Tn + i) * Tn + j; a.pbuf[o] = p; a.dsbuf[o] = pval; }
       }
       Ps[w * 64 + lane] = pval;
       __syncthreads();
@@ -154,90 +155,68 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// bwd2: dK, dV (per key, register accumulators) and dE (LDS window, flushed with atomics)
+// column pass of the backward: from the stored P / dS matrices,
+//   key tiles   (blockIdx.x <  ktiles): lane = key j     dK_j = sum_i dS_ij q_i,   dV_j = sum_i P_ij dO_i
+//   rel tiles   (blockIdx.x >= ktiles): lane = E row r   dE_r = sum_i dS_{i, i-(T-1)+r} q_i        (the skewed sum of rel_to_abs)
+// register accumulators per lane, q_i / dO_i broadcast from LDS, 4 waves split the queries; no atomics in the loop.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DPAD>
-__global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnArgs a, int ktiles) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int d = a.d, DP = d | 1, Tn = a.T;
-  float* Ks = sm; float* Vs = Ks + TK * DP; float* dEs = Vs + TK * DP;            // dEs: [QS+TK-1][DP]
-  float* Es = dEs + (QS + TK - 1) * DP;                                            // [QC+TK-1][DP]
-  float* Qs = Es + (QC + TK - 1) * DP; float* Gs = Qs + QC * DP;                   // [QC][DP] each
-  float* Ls = Gs + QC * DP; float* Ds = Ls + QC; float* Is = Ds + QC;              // [QC] row max, delta, 1/row sum
+  float* Qs = sm; float* Gs = Qs + QC * DP; float* R0 = Gs + QC * DP; float* R1 = R0 + 64 * DP;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int j0 = blockIdx.x * TK, is = blockIdx.z * QS;
-  const int ie = min(is + QS, Tn);
+  const bool rel = (int)blockIdx.x >= ktiles;
+  const int c0 = (rel ? (int)blockIdx.x - ktiles : (int)blockIdx.x) * 64;
+  const int col = c0 + lane;
   const T* qp = (const T*)a.q + (long long)b * Tn * a.ld + h * d;
-  const T* kp = (const T*)a.k + (long long)b * Tn * a.ld + h * d;
-  const T* vp = (const T*)a.v + (long long)b * Tn * a.ld + h * d;
   const T* gp = (const T*)a.dout + (long long)b * Tn * a.ldo + h * d;
-  const T* op = (const T*)a.o + (long long)b * Tn * a.ldo + h * d;
-  const T* ep = (const T*)a.e + h * d;
-  load_rows<T>(Ks, DP, kp, a.ld, j0, TK, Tn, d);
-  load_rows<T>(Vs, DP, vp, a.ld, j0, TK, Tn, d);
-  for (int idx = threadIdx.x; idx < (QS + TK - 1) * DP; idx += 256) dEs[idx] = 0.f;
-  float dk[DPAD], dv[DPAD];
+  const float* P = a.pbuf + (long long)bh * Tn * Tn; const float* S = a.dsbuf + (long long)bh * Tn * Tn;
+  float acc0[DPAD], acc1[DPAD];
 #pragma unroll
-  for (int c = 0; c < DPAD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
-  const int j = j0 + lane; const bool jv = j < Tn;
-
-  for (int ic = is; ic < ie; ic += QC) {
+  for (int c = 0; c < DPAD; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
+  for (int ic = 0; ic < Tn; ic += QC) {
     __syncthreads();
     load_rows<T>(Qs, DP, qp, a.ld, ic, QC, Tn, d);
-    load_rows<T>(Gs, DP, gp, a.ldo, ic, QC, Tn, d);
-    load_rows<T>(Es, DP, ep, a.lde, (Tn - 1) - (ic + QC - 1) + j0, QC + TK - 1, 2 * Tn - 1, d);
-    __syncthreads();
-    // delta_i = dO_i . O_i and lse_i for the chunk: wave w handles queries w, w+4
-    for (int qi = w; qi < QC; qi += 4) {
-      const int i = ic + qi; float s = 0.f;
-      if (i < Tn) for (int c = lane; c < d; c += 64) s += Gs[qi * DP + c] * ldf(op + (long long)i * a.ldo + c);
-      s = wave_sum(s);
-      if (lane == 0) { Ds[qi] = s; Ls[qi] = (i < Tn) ? a.lse[((long long)bh * Tn + i) * 2] : 0.f; Is[qi] = (i < Tn) ? 1.f / a.lse[((long long)bh * Tn + i) * 2 + 1] : 0.f; }
-    }
+    if (!rel) load_rows<T>(Gs, DP, gp, a.ldo, ic, QC, Tn, d);
     __syncthreads();
     for (int qi = w; qi < QC; qi += 4) {
       const int i = ic + qi;
-      if (i >= ie) continue;                                 // wave-uniform
-      const float* qrow = Qs + qi * DP; const float* grow = Gs + qi * DP;
-      const float* krow = Ks + lane * DP; const float* vrow = Vs + lane * DP; const float* erow = Es + (QC - 1 - qi + lane) * DP;
-      float s = 0.f, dp = 0.f;
-      for (int c = 0; c < d; ++c) { s += qrow[c] * (krow[c] + erow[c]); dp += grow[c] * vrow[c]; }
-      s *= a.scale;
-      if (jv && !key_keep<T>(a, b, i, j)) s += -1e9f;
-      const float p = jv ? __expf(s - Ls[qi]) * Is[qi] : 0.f;
-      const float ds = p * (dp - Ds[qi]) * a.scale;
-      float* derow = dEs + (is + QS - 1 - i + lane) * DP;
+      if (i >= Tn) break;                                   // wave-uniform
+      const float* qrow = Qs + qi * DP;
+      if (!rel) {
+        float ds = 0.f, p = 0.f;
+        if (col < Tn) { ds = S[(long long)i * Tn + col]; p = P[(long long)i * Tn + col]; }
+        const float* grow = Gs + qi * DP;
 #pragma unroll
-      for (int c = 0; c < DPAD; ++c) {
-        if (c < d) { const float qv = qrow[c]; dv[c] += p * grow[c]; dk[c] += ds * qv; atomicAdd(derow + c, ds * qv); }
+        for (int c = 0; c < DPAD; ++c) if (c < d) { acc0[c] += ds * qrow[c]; acc1[c] += p * grow[c]; }
+      } else {
+        const int j = i - (Tn - 1) + col;
+        const float ds = (col < 2 * Tn - 1 && j >= 0 && j < Tn) ? S[(long long)i * Tn + j] : 0.f;
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) if (c < d) acc0[c] += ds * qrow[c];
       }
     }
   }
   __syncthreads();
-  // cross-wave reduction of dk/dv through LDS (Ks/Vs are free now), one wave at a time
   for (int ww = 0; ww < 4; ++ww) {
     if (w == ww) {
 #pragma unroll
       for (int c = 0; c < DPAD; ++c) if (c < d) {
-        if (ww == 0) { Ks[lane * DP + c] = dk[c]; Vs[lane * DP + c] = dv[c]; }
-        else { Ks[lane * DP + c] += dk[c]; Vs[lane * DP + c] += dv[c]; }
+        if (ww == 0) { R0[lane * DP + c] = acc0[c]; R1[lane * DP + c] = acc1[c]; }
+        else { R0[lane * DP + c] += acc0[c]; R1[lane * DP + c] += acc1[c]; }
       }
     }
     __syncthreads();
   }
-  const bool first_seg = (gridDim.z == 1);
-  for (int idx = threadIdx.x; idx < TK * d; idx += 256) {
-    const int r = idx / d, c = idx - r * d; const int jj = j0 + r;
-    if (jj >= Tn) continue;
-    // several query segments contribute to the same key rows: accumulate in fp32 scratch (dk/dv pointers are fp32 when gridDim.z > 1)
-    if (first_seg) { stf((T*)a.dk + ((long long)b * Tn + jj) * a.ldd + h * d + c, Ks[r * DP + c]); stf((T*)a.dv + ((long long)b * Tn + jj) * a.ldd + h * d + c, Vs[r * DP + c]); }
-    else { atomicAdd((float*)a.dk + ((long long)b * Tn + jj) * a.ldd + h * d + c, Ks[r * DP + c]); atomicAdd((float*)a.dv + ((long long)b * Tn + jj) * a.ldd + h * d + c, Vs[r * DP + c]); }
-  }
-  const int rb = (Tn - 1) - (is + QS - 1) + j0;
-  for (int idx = threadIdx.x; idx < (QS + TK - 1) * d; idx += 256) {
-    const int r = idx / d, c = idx - r * d; const int gr = rb + r;
-    if (gr >= 0 && gr < 2 * Tn - 1) { const float v = dEs[r * DP + c]; if (v != 0.f) atomicAdd(a.de + (long long)gr * a.ldde + h * d + c, v); }
+  for (int idx = threadIdx.x; idx < 64 * d; idx += 256) {
+    const int r = idx / d, c = idx - r * d; const int cc = c0 + r;
+    if (!rel) {
+      if (cc < Tn) { stf((T*)a.dk + ((long long)b * Tn + cc) * a.ldd + h * d + c, R0[r * DP + c]); stf((T*)a.dv + ((long long)b * Tn + cc) * a.ldd + h * d + c, R1[r * DP + c]); }
+    } else if (cc < 2 * Tn - 1) {
+      atomicAdd(a.de + (long long)cc * a.ldde + h * d + c, R0[r * DP + c]);
+    }
   }
 }
 
@@ -245,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_kernel(AttnArgs a) {
 static int fill_args(AttnArgs& a, const avec_attn_t* p) {
   a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1; a.q_full = p->q_full > 0 ? p->q_full : p->T;
   a.mask = p->mask; a.mask_bstride = p->mask_bstride; a.o = p->o; a.ldo = p->ldo; a.lse = p->lse; a.dout = p->dout;
-  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde;
+  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde; a.pbuf = p->pbuf; a.dsbuf = p->dsbuf;
   a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale;
   AVEC_CHECK_ARG(a.q && a.k && a.v && a.e && a.o && a.lse, "attention: null pointer");
   AVEC_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.d > 0 && a.d <= 96, "attention: bad dims B=%d H=%d T=%d d=%d (d <= 96 supported)", a.B, a.H, a.T, a.d);
@@ -278,21 +257,18 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
   dim3 grid1((a.T + TQ - 1) / TQ, a.B * a.H);
   if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
   hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
-  size_t lds2 = (size_t)(2 * TK + (QS + TK - 1) + (QC + TK - 1) + 2 * QC) * DP * 4 + 2 * QC * 4;
-  dim3 grid2((a.T + TK - 1) / TK, a.B * a.H, (a.T + QS - 1) / QS);
-#define LB(DPAD) do { if (int r = set_lds(attn_bwd_keys_kernel<T, DPAD>, lds2)) return r; hipLaunchKernelGGL((attn_bwd_keys_kernel<T, DPAD>), grid2, dim3(256), lds2, st, a); } while (0)
+  size_t lds2 = (size_t)(2 * QC + 2 * 64) * DP * 4;
+  const int ktiles = (a.T + 63) / 64, rtiles = (2 * a.T - 1 + 63) / 64;
+  dim3 grid2(ktiles + rtiles, a.B * a.H);
+#define LB(DPAD) do { if (int r = set_lds(attn_bwd_cols_kernel<T, DPAD>, lds2)) return r; hipLaunchKernelGGL((attn_bwd_cols_kernel<T, DPAD>), grid2, dim3(256), lds2, st, a, ktiles); } while (0)
   if (a.d <= 48) LB(48); else if (a.d <= 64) LB(64); else LB(96);
 #undef LB
   return 0;
 }
 
-// dk/dv: act buffers when T <= 64 (single query segment); otherwise fp32 scratch (zeroed by the caller) that the
-// caller converts with avec_cast_rows.  `dkv_f32` must say which.
-extern "C" int avec_relpos_attention_bwd(int dtype, const avec_attn_t* p, int dkv_f32, hipStream_t st) {
+extern "C" int avec_relpos_attention_bwd(int dtype, const avec_attn_t* p, hipStream_t st) {
   AttnArgs a; AVEC_CHECK_ARG(p, "attention_bwd: null args"); if (int r = fill_args(a, p)) return r;
-  AVEC_CHECK_ARG(a.dout && a.dq && a.dk && a.dv && a.de, "attention_bwd: null gradient pointer");
-  const int nseg = (a.T + QS - 1) / QS;
-  AVEC_CHECK_ARG((nseg > 1) == (dkv_f32 != 0), "attention_bwd: dkv_f32 must be %d for T=%d", nseg > 1, a.T);
+  AVEC_CHECK_ARG(a.dout && a.dq && a.dk && a.dv && a.de && a.pbuf && a.dsbuf, "attention_bwd: null gradient / scratch pointer");
   int r = (dtype == AVEC_BF16) ? launch_bwd<bf16>(a, st) : launch_bwd<float>(a, st);
   if (r) return r;
   AVEC_LAUNCH_CHECK(); return 0;

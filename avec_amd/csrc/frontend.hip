@@ -238,6 +238,36 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_apply_kernel(const T* __res
     st4<T>(dy + row * C + c, o);
   }
 }
+// im2col for the Cin=1 Conv3d stem: one thread = 8 consecutive k of one output pixel
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ video, T* __restrict__ A, long long M, int T3, int H, int W, int OH, int OW, int ldk) {
+  const int cpr = ldk / 8; const long long total = M * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i % cpr); const long long m = i / cpr;
+    const int ow = (int)(m % OW); long long t = m / OW; const int oh = (int)(t % OH); const long long ft = t / OH;
+    const int fr = (int)(ft % T3); const long long clip = ft / T3;
+    const float* src = video + clip * (long long)T3 * H * W;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = q * 8 + e; float x = 0.f;
+      if (kk < 245) {
+        const int kw = kk % 7, t2 = kk / 7, kh = t2 % 7, kd = t2 / 7;
+        const int it = fr + kd - 2, ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
+        if (it >= 0 && it < T3 && ih >= 0 && ih < H && iw >= 0 && iw < W) x = src[((long long)it * H + ih) * W + iw];
+      }
+      v[e] = x;
+    }
+    st4<T>(A + m * ldk + q * 8, v); st4<T>(A + m * ldk + q * 8 + 4, v + 4);
+  }
+}
+extern "C" int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, int T_, int H, int W, int ldk, hipStream_t st) {
+  AVEC_CHECK_ARG(video && A && clips > 0 && T_ > 0 && H > 0 && W > 0 && ldk >= 248 && ldk % 8 == 0, "stem_im2col: bad arguments");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; const long long M = clips * T_ * OH * OW;
+  long long nb = (M * (ldk / 8) + 255) / 256; if (nb > 65536) nb = 65536;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, video, (T*)A, M, T_, H, W, OH, OW, ldk));
+  AVEC_LAUNCH_CHECK(); return 0;
+}
 extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && idx && frames > 0 && H > 0 && W > 0 && C % 4 == 0, "stem_pool_fwd: bad arguments");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; long long n4 = frames * OH * OW * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;

@@ -280,12 +280,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
   if (e.colsum || e.stats) {
+    // workgroup-level reduction in LDS (the staged C tile is dead now), then ONE atomic per column per workgroup;
+    // BatchNorm statistics additionally spread over AVEC_STAT_REPLICAS copies to cut same-address contention.
+    float* red = (float*)smem;                 // [2][BN]
+    for (int c = tid; c < 2 * BN; c += 256) red[c] = 0.f;
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      for (int o = TPR; o < 64; o <<= 1) { csum[c] += __shfl_xor(csum[c], o, 64); csq[c] += __shfl_xor(csq[c], o, 64); }
-      if (lane < TPR && col + c < g.N) {
-        if (e.colsum) atomicAdd(e.colsum + col + c, csum[c]);
-        if (e.stats) { atomicAdd(e.stats + col + c, csum[c]); atomicAdd(e.stats + g.N + col + c, csq[c]); }
+    for (int c = 0; c < 4; ++c) { atomicAdd(red + cg + c, csum[c]); atomicAdd(red + BN + cg + c, csq[c]); }
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      if (e.colsum) atomicAdd(e.colsum + n0 + tid, red[tid]);
+      if (e.stats) {
+        float* rep = e.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 2 * g.N;
+        atomicAdd(rep + n0 + tid, red[tid]); atomicAdd(rep + g.N + n0 + tid, red[BN + tid]);
       }
     }
   }

@@ -161,20 +161,20 @@ extern "C" int avec_adam_step(float* params, float* grads, float* exp_avg, float
 // shadow refresh: for every GEMM weight (master fp32, logical [A][Tm][C]) write
 //   fwd shadow  (act) = same order                         -> NT forward   (rows = A, K = Tm*C)
 //   bwd shadow  (act) [C][Tm][A] (axes 0 and 2 swapped)    -> NT backward-data (rows = C, K = Tm*A)
-// table entry (8 x int64): src_off, fwd_off (-1: none), bwd_off (-1: none), A, Tm, C, first_block, n_blocks
+// table entry (10 x int64): src_off, fwd_off (-1: none), bwd_off (-1: none), A, Tm, C, first_block, n_blocks, C_pad, reserved
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ master, T* __restrict__ shadow, const long long* __restrict__ table, int n_entries) {
   int lo = 0, hi = n_entries - 1;
-  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (table[mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
-  const long long* e = table + lo * 8;
-  const long long src = e[0], fwd = e[1], bwd = e[2]; const long long A = e[3], Tm = e[4], C = e[5];
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (table[mid * 10 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const long long* e = table + lo * 10;
+  const long long src = e[0], fwd = e[1], bwd = e[2]; const long long A = e[3], Tm = e[4], C = e[5], Cp = e[8];
   const long long n = A * Tm * C; const long long base = ((long long)blockIdx.x - e[6]) * 1024;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const long long i = base + u * 256 + threadIdx.x;
     if (i >= n) break;
-    if (fwd >= 0) stf(shadow + fwd + i, master[src + i]);
+    if (fwd >= 0) stf(shadow + fwd + ((Cp > C && Tm == 1) ? (i / C) * Cp + (i % C) : i), master[src + i]);
     if (bwd >= 0) { const long long a = i % A; const long long r = i / A; const long long t = r % Tm; const long long c = r / Tm;
       stf(shadow + bwd + i, master[src + (a * Tm + t) * C + c]); }
   }

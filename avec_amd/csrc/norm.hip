@@ -58,11 +58,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
       st4<float>(dx + row * D + c, o);
     }
   }
+  // block-level reduction of the 4 waves' partials through LDS, then one atomic per column per block
+  extern __shared__ float lnred[];           // [2][D]
+  for (int c = threadIdx.x; c < 2 * D; c += 256) lnred[c] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     int c = lane * 4 + i * 256; if (c >= D) break;
-    for (int e = 0; e < 4; ++e) { atomicAdd(dg + c + e, pg[i][e]); atomicAdd(db + c + e, pb[i][e]); }
+    for (int e = 0; e < 4; ++e) { atomicAdd(lnred + c + e, pg[i][e]); atomicAdd(lnred + D + c + e, pb[i][e]); }
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) { atomicAdd(dg + c, lnred[c]); atomicAdd(db + c, lnred[D + c]); }
 }
 
 extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int y_f32,
@@ -79,9 +85,10 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
                                   float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
-  long long nb = (M + 3) / 4; if (nb > 512) nb = 512;
-  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
-  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
+  long long nb = (M + 15) / 16; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+  const size_t lds = (size_t)2 * D * sizeof(float);
+  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
+  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), lds, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -155,14 +162,16 @@ extern "C" int avec_bn_stats(int dtype, const void* y, float* stats, long long M
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
+__global__ void bn_finalize_kernel(const float* stats, int nrep, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    long long* nbt, float momentum, float eps, float* ss, int C, int training) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, var;
   if (training) {
     const float n = count_ptr ? *count_ptr : count;
-    mean = stats[c] / n; var = fmaxf(stats[C + c] / n - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nrep; ++r) { s1 += stats[(long long)r * 2 * C + c]; s2 += stats[(long long)r * 2 * C + C + c]; }   // replicated partial sums (GEMM epilogue)
+    mean = s1 / n; var = fmaxf(s2 / n - mean * mean, 0.f);
     if (rmean) {
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
@@ -172,10 +181,10 @@ __global__ void bn_finalize_kernel(const float* stats, const float* count_ptr, f
   const float rs = rsqrtf(var + eps);
   ss[c] = gamma[c] * rs; ss[C + c] = beta[c] - mean * gamma[c] * rs; ss[2 * C + c] = mean; ss[3 * C + c] = rs;
 }
-extern "C" int avec_bn_finalize(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
+extern "C" int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t st) {
   AVEC_CHECK_ARG(gamma && beta && ss && C > 0 && (training ? (stats != nullptr) : (running_mean && running_var)), "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, count_ptr, count, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, n_replicas > 0 ? n_replicas : 1, count_ptr, count, gamma, beta, running_mean, running_var,
                      num_batches_tracked, momentum, eps, ss, C, training);
   AVEC_LAUNCH_CHECK(); return 0;
 }

@@ -101,7 +101,8 @@ class Conv3d(nn.Conv3d):
         self.register_buffer("mask", mask)
         if in_channels == 1:
             k = self.kernel_size
-            rt.register_weight(self.weight, out_channels, 1, k[0] * k[1] * k[2], need_bwd=False)
+            kk = k[0] * k[1] * k[2]
+            rt.register_weight(self.weight, out_channels, 1, kk, need_bwd=False, c_pad=(kk + 7) // 8 * 8)
 
     def forward(self, x):
         raise RuntimeError("standalone Conv3d is not part of the HIP hot path; the (5,7,7) stem runs fused in VisualEfficientConformerEncoder.front_end")

@@ -405,16 +405,11 @@ class AttentionModuleFn(torch.autograd.Function):
         a.dout = do.data_ptr()
         esz = dqkv.element_size()
         a.dq, a.lddq = dqkv.data_ptr(), 3 * D
-        nseg = (Tp + 63) // 64
-        if nseg > 1:
-            dkv32 = torch.zeros((Mp, 2 * D), dtype=torch.float32, device=dy.device)
-            a.dk, a.dv, a.ldd = dkv32.data_ptr(), dkv32.data_ptr() + D * 4, 2 * D
-        else:
-            a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
+        a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
         a.de, a.ldde = de.data_ptr(), D
-        lib.relpos_attention_bwd(rt.dt(), _byref(a), int(nseg > 1), rt.stream())
-        if nseg > 1:
-            lib.cast_rows(rt.dt(), dkv32.data_ptr(), 2 * D, dqkv.data_ptr() + D * esz, 3 * D, Mp, 2 * D, rt.stream())
+        scratch = empty((2, B * H, Tp, Tp), torch.float32, dy)       # P and dS of every (batch, head)
+        a.pbuf, a.dsbuf = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * 4
+        lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())
         dhp = None
         for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
             g = dqkv[:, i * D:]
@@ -453,8 +448,11 @@ def _pool_mask(mask, T, P):
 class BNState:
     """scratch for one BatchNorm application: stats [2C+1] (sum | sumsq | count) and ss [4C]"""
 
+    NREP = 64      # AVEC_STAT_REPLICAS: the GEMM epilogue spreads its statistic atomics over this many [2C] copies
+
     def __init__(self, C, ref):
-        self.stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=ref.device)
+        self.stats = torch.zeros(self.NREP * 2 * C, dtype=torch.float32, device=ref.device)
+        self.red = None
         self.ss = torch.empty(4 * C, dtype=torch.float32, device=ref.device)
         self.C = C
 
@@ -463,14 +461,15 @@ def bn_finalize(bn, st, count, training):
     """bn: module with weight/bias/running_mean/running_var/num_batches_tracked/momentum/eps"""
     C = st.C
     cptr = None
-    if training:
-        if rt.sync_batchnorm():
-            st.stats[2 * C] = float(count)
-            _sync_stats(st.stats)
-            cptr = st.stats.data_ptr() + 2 * C * 4
+    sptr, nrep = st.stats.data_ptr(), st.NREP
+    if training and rt.sync_batchnorm():
+        # SyncBatchNorm: collapse the replicas, append the local count, sum over ranks (one small RCCL all-reduce)
+        st.red = torch.cat([st.stats.view(st.NREP, 2 * C).sum(0), torch.full((1,), float(count), device=st.stats.device)])
+        _sync_stats(st.red)
+        sptr, nrep, cptr = st.red.data_ptr(), 1, st.red.data_ptr() + 2 * C * 4
     mom = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats and bn.running_mean is not None
-    lib.bn_finalize(st.stats.data_ptr(), cptr, float(count), bn.weight.data_ptr(), bn.bias.data_ptr(),
+    lib.bn_finalize(sptr, nrep, cptr, float(count), bn.weight.data_ptr(), bn.bias.data_ptr(),
                     bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                     bn.num_batches_tracked.data_ptr() if (track and training) else None, mom, bn.eps, st.ss.data_ptr(), C, int(training), rt.stream())
     return cptr
@@ -773,11 +772,13 @@ class VideoStemFn(torch.autograd.Function):
         M = B * T * OH * OW
         sh = rt.shadow(conv.weight)
         st = BNState(C, v)
-        r = Rows()
-        r.H, r.W, r.OH, r.OW, r.T3 = H, W, OH, OW, T
+        K, Kp = sh.Tm * sh.C, sh.Cp
+        # im2col once (shared by the forward GEMM and the weight-gradient GEMM), then a plain MFMA GEMM with K padded to Kp
+        A = empty((M, Kp), rt.act_dtype(), v)
+        lib.stem_im2col(rt.dt(), v.data_ptr(), A.data_ptr(), B, T, H, W, Kp, rt.stream())
         y = empty((M, C), rt.act_dtype(), v)
-        K = sh.Tm * sh.C
-        gemm_nt(v, sh.fwd, y, M, C, K, rows=r, mode=ROWS_STEM3D, a_f32=True, bias=conv.bias, stats=st.stats if training else None)
+        gemm_nt(A, sh.fwd, y, M, C, Kp, bias=conv.bias, stats=st.stats if training else None)
+        r = A
         cp = bn_finalize(bn, st, M, training)
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         out = empty((B * T, PH, PW, C), rt.act_dtype(), v)
@@ -797,7 +798,7 @@ class VideoStemFn(torch.autograd.Function):
         _sync_stats(dstats)
         dy = empty((M, C), rt.act_dtype(), v)
         lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B * T, OH, OW, C, rt.stream())
-        gemm_tn(dy, v, grad_of(conv.weight), M, C, K, q_rows=r, q_mode=ROWS_STEM3D, q_f32=True)
+        gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]))
         if conv.bias is not None:
             grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
         return None, None, None, None, None

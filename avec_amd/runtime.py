@@ -90,32 +90,35 @@ def require_gpu(t):
 # --------------------------------------------------------------------------------------------
 class Shadow:
     """Compute-dtype copies of one GEMM weight: `fwd` = physical order [A][Tm][C], `bwd` = [C][Tm][A]."""
-    __slots__ = ("A", "Tm", "C", "need_bwd", "fwd", "bwd", "stamp", "arena", "_table")
+    __slots__ = ("A", "Tm", "C", "Cp", "need_bwd", "fwd", "bwd", "stamp", "arena", "_table")
 
-    def __init__(self, A, Tm, C, need_bwd=True):
+    def __init__(self, A, Tm, C, need_bwd=True, c_pad=None):
         self.A, self.Tm, self.C, self.need_bwd = A, Tm, C, need_bwd
+        self.Cp = C if c_pad is None else c_pad          # row stride of the fwd shadow (zero padded), Tm == 1 only
+        assert self.Cp == C or Tm == 1
         self.fwd = self.bwd = None
         self.stamp = None
         self.arena = None
         self._table = None
 
 
-def register_weight(param, A, Tm, C, need_bwd=True):
-    param._avec_shadow = Shadow(A, Tm, C, need_bwd)
+def register_weight(param, A, Tm, C, need_bwd=True, c_pad=None):
+    param._avec_shadow = Shadow(A, Tm, C, need_bwd, c_pad)
     return param
 
 
 def _refresh_single(param, sh):
     n = sh.A * sh.Tm * sh.C
+    nf = sh.A * sh.Tm * sh.Cp
     adt = act_dtype()
-    buf = torch.empty(n * (2 if sh.need_bwd else 1), dtype=adt, device=param.device)
+    buf = torch.zeros(nf + (n if sh.need_bwd else 0), dtype=adt, device=param.device)
     blocks = (n + 1023) // 1024
-    table = torch.tensor([0, 0, n if sh.need_bwd else -1, sh.A, sh.Tm, sh.C, 0, blocks], dtype=torch.int64, device=param.device)
+    table = torch.tensor([0, 0, nf if sh.need_bwd else -1, sh.A, sh.Tm, sh.C, 0, blocks, sh.Cp, 0], dtype=torch.int64, device=param.device)
     src = param.detach()
     assert is_dense(src)
     lib.shadow_refresh(dt(), src.data_ptr(), buf.data_ptr(), table.data_ptr(), 1, blocks, stream())
-    sh.fwd = buf[:n]
-    sh.bwd = buf[n:] if sh.need_bwd else None
+    sh.fwd = buf[:nf]
+    sh.bwd = buf[nf:] if sh.need_bwd else None
     sh._table = table  # keep alive until the kernel ran
 
 
@@ -174,15 +177,15 @@ class ParamArena:
                 continue
             n = sh.A * sh.Tm * sh.C
             fwd = soff
-            soff += (n + 7) // 8 * 8
+            soff += (sh.A * sh.Tm * sh.Cp + 7) // 8 * 8
             bwd = -1
             if sh.need_bwd:
                 bwd = soff
                 soff += (n + 7) // 8 * 8
             nb = (n + 1023) // 1024
-            rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb])
+            rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb, sh.Cp, 0])
             blocks += nb
-        self.shadow = torch.empty(max(soff, 8), dtype=adt, device=self.device)
+        self.shadow = torch.zeros(max(soff, 8), dtype=adt, device=self.device)
         self.table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self.n_entries, self.total_blocks = len(rows), blocks
         i = 0
@@ -190,9 +193,9 @@ class ParamArena:
             sh = getattr(p, "_avec_shadow", None)
             if sh is None:
                 continue
-            _, fwd, bwd, A, Tm, C, _, _ = rows[i]
+            _, fwd, bwd, A, Tm, C, _, _, Cp, _ = rows[i]
             n = A * Tm * C
-            sh.fwd = self.shadow[fwd:fwd + n]
+            sh.fwd = self.shadow[fwd:fwd + A * Tm * Cp]
             sh.bwd = self.shadow[bwd:bwd + n] if bwd >= 0 else None
             sh.arena = self
             i += 1

@@ -34,6 +34,7 @@ extern "C" {
 #define AVEC_F32 0
 #define AVEC_BF16 1
 #define AVEC_ABI_VERSION 1
+#define AVEC_STAT_REPLICAS 64   /* `stats` buffers handed to avec_gemm_nt hold this many [2N] replicas (block b adds to replica b % 64) */
 
 int avec_version(void);
 const char* avec_last_error(void);
@@ -85,9 +86,9 @@ int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float
 int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t stream);
 int avec_strided_rows_add(float* dx, const float* src, int B, int T, int To, int D, int step, hipStream_t stream);
 /* BatchNorm{1,2,3}d over channels-last [M][C] (aten::native_batch_norm(_backward), nnet/normalizations.py:42-170).
- * stats = [sum | sumsq]; ss = [scale | shift | mean | rstd]; SyncBatchNorm (:172-249) = all-reduce stats/count/dstats between calls. */
+ * stats = n_replicas x [sum | sumsq] (the GEMM epilogue spreads its atomics over AVEC_STAT_REPLICAS copies); ss = [scale | shift | mean | rstd]; SyncBatchNorm (:172-249) = all-reduce stats/count/dstats between calls. */
 int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t stream);
-int avec_bn_finalize(const float* stats, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
+int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t stream);
 int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t stream);
 int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t stream);
@@ -126,13 +127,14 @@ typedef struct avec_attn {
   const float* mask; long long mask_bstride;  /* optional dense (Bm,T,T) 0/1 mask (1 = keep) instead of lens */
   void* o; long long ldo; float* lse;         /* outputs: act [B*T][ldo], fp32 [B*H][T][2] = softmax row (max, sum) */
   const void* dout;                           /* backward input, act [B*T][ldo] */
-  void *dq, *dk, *dv; long long lddq, ldd;    /* dq act (stride lddq); dk/dv act (T<=64) or fp32 scratch (stride ldd) */
+  void *dq, *dk, *dv; long long lddq, ldd;    /* act gradients: dq (row stride lddq), dk / dv (row stride ldd) */
   float* de; long long ldde;                  /* fp32 [2T-1][ldde], accumulated */
+  float *pbuf, *dsbuf;                        /* backward scratch, fp32 [B*H][T][T] each (probabilities, dS) */
   int B, H, T, d; float scale;
 } avec_attn_t;
 /* RelPos1dMultiHeadAttention.forwardQKV core (nnet/attentions.py:299-315): bmm + rel_to_abs + mask + softmax + bmm */
 int avec_relpos_attention_fwd(int dtype, const avec_attn_t* args, hipStream_t stream);
-int avec_relpos_attention_bwd(int dtype, const avec_attn_t* args, int dkv_f32, hipStream_t stream);
+int avec_relpos_attention_bwd(int dtype, const avec_attn_t* args, hipStream_t stream);
 
 /* ---- front-ends (avec_amd/csrc/frontend.hip) ------------------------------------------------ */
 /* AudioPreprocessing (nnet/preprocessing.py:57-85; torchaudio Spectrogram/MelScale restated): frames -> [DFT via avec_gemm_nt fp32] -> power/mel/log */
@@ -148,6 +150,8 @@ int avec_audio_stem_bwd(int dtype, const void* da, const void* y, const float* m
                         const float* count_ptr, float count, int phase, float* dw, float* dbias, float* dgamma, float* dbeta,
                         int B, int n_mels, int F, int C, hipStream_t stream);
 /* BatchNorm3d+ReLU+MaxPool3d((1,3,3),(1,2,2),"same") after the Conv3d stem (nnet/networks.py:459-470, nnet/layers.py:839-915) */
+/* im2col of the Cin=1 (5,7,7)/(1,2,2) stem: video fp32 [clips][T][H][W] -> A act [clips*T*OH*OW][ldk] (k = (kd*7+kh)*7+kw, zero padded to ldk) */
+int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, int T, int H, int W, int ldk, hipStream_t stream);
 int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t stream);
 int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                        const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t stream);
@@ -163,6 +167,7 @@ int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStre
 /* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */
 int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t stream);
+/* table entry = 10 x int64: src_off, fwd_off|-1, bwd_off|-1, A, Tm, C, first_block, n_blocks, C_pad (row stride of the fwd shadow when Tm==1), 0 */
 int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t stream);
 
 #ifdef __cplusplus
