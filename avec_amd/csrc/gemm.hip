@@ -3,12 +3,16 @@
 //   gemm_nt :  C[m][n] = epi( sum_k A[m][k] * W[n][k] )          (Linear fwd / dX, conv fwd / bwd-data)
 //   gemm_tn :  O[i][j] += sum_m P[m][i] * Q[m][j]                 (weight gradients, split over m, fp32 atomics)
 //
-// A / Q operands are produced by "row loaders": plain row-major (with optional strided row remap and
-// fp32->bf16 conversion), NHWC implicit-GEMM im2col (forward and transposed/backward-data), and the
-// Cin=1 Conv3d stem gather.  One LDS image serves both dtypes: each tile row holds 128 bytes of K
-// (64 bf16 / 32 fp32) + 16 bytes padding (row stride 144 B = 9 x 16 B => ds_read_b128 conflict-free).
-// MFMA: v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fp32 for parity tests).
-#include "common.h"
+// A / Q operands come from "row loaders": plain row-major (optional strided row remap, optional fp32->bf16
+// conversion while staging) and NHWC implicit-GEMM im2col (forward, and transposed = backward-data).
+// One LDS image serves both dtypes: each tile row holds 128 bytes of K (64 bf16 / 32 fp32) + 16 bytes padding
+// (row stride 144 B = 9 x 16 B => ds_read_b128 conflict-free).  Two LDS buffers: the global loads of tile k+1
+// are issued before the MFMAs of tile k and land in registers; they are written to the other buffer after the
+// MFMAs => one barrier per K-step and the HBM/L2 latency hides under the matrix work.
+// Every global load is UNCONDITIONAL (invalid rows/taps read a clamped address and are zeroed when staged):
+// hipcc otherwise puts `s_waitcnt vmcnt(0)` behind each load issued under a divergent branch and serialises them.
+// MFMA: v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fp32 for the parity tests).
+#include "vec.h"
 #include "avec_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -17,14 +21,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 static constexpr int BKB = 128;      // bytes of K per LDS tile row
 static constexpr int LDS_ROW = 144;  // padded LDS row stride in bytes
 
-enum { MODE_PLAIN = 0, MODE_CONV_FWD = 1, MODE_CONV_BWD = 2, MODE_STEM3D = 3 };
+enum { MODE_PLAIN = 0, MODE_CONV_FWD = 1, MODE_CONV_BWD = 2 };
 
 struct RowSrc {
   const void* ptr;
   long long ld;                       // plain: row stride in elements
   int rows_out, rows_in, step;        // plain: src_row = (m / rows_out) * rows_in + (m % rows_out) * step  (step<=1: identity)
-  int H, W, C, KH, KW, stride, pad, OH, OW;  // conv geometry (see loaders)
-  int T3;                             // stem: frames per clip
+  int H, W, C, KH, KW, stride, pad, OH, OW;  // conv geometry
 };
 
 struct RowInfo { long long base; int a, b; int valid; };
@@ -41,88 +44,80 @@ __device__ __forceinline__ RowInfo row_info(const RowSrc& s, long long m, long l
   } else if (MODE == MODE_CONV_FWD) {      // m -> (img, oh, ow); source x[img][H][W][C]
     int ow = (int)(m % s.OW); long long t = m / s.OW; int oh = (int)(t % s.OH); long long img = t / s.OH;
     r.base = img * (long long)s.H * s.W * s.C; r.a = oh * s.stride - s.pad; r.b = ow * s.stride - s.pad;
-  } else if (MODE == MODE_CONV_BWD) {      // m -> (img, ih, iw) over HxW; source dy[img][OH][OW][C]
+  } else {                                  // CONV_BWD: m -> (img, ih, iw) over HxW; source dy[img][OH][OW][C]
     int iw = (int)(m % s.W); long long t = m / s.W; int ih = (int)(t % s.H); long long img = t / s.H;
     r.base = img * (long long)s.OH * s.OW * s.C; r.a = ih + s.pad; r.b = iw + s.pad;
-  } else {                                  // stem: m -> (clip*T3 + t, oh, ow); source video[clip][T3][H][W] fp32
-    int ow = (int)(m % s.OW); long long t = m / s.OW; int oh = (int)(t % s.OH); long long ft = t / s.OH;
-    int fr = (int)(ft % s.T3); long long clip = ft / s.T3;
-    r.base = clip * (long long)s.T3 * s.H * s.W; r.a = oh * 2 - 3; r.b = ow * 2 - 3; r.valid = 1 + fr;  // frame index kept in valid-1
   }
   return r;
 }
 
-// ---- fetch VEC consecutive K-elements of row r starting at k (zero outside) as one 16-byte chunk ----
-template <typename T, int MODE, bool SRC_F32>
-__device__ __forceinline__ chunk16 fetch_chunk(const RowSrc& s, const RowInfo& r, int k, int K) {
-  constexpr int VEC = Elt<T>::VEC;
-  chunk16 out; out.w[0] = out.w[1] = out.w[2] = out.w[3] = 0u;
-  if (!r.valid || k >= K) return out;
-  if (MODE == MODE_STEM3D) {
-    const float* src = (const float*)s.ptr + r.base;
-    int fr = r.valid - 1;
-    float v[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      int kk = k + e; float x = 0.f;
-      if (kk < K) {
-        int kw = kk % 7; int t2 = kk / 7; int kh = t2 % 7; int kd = t2 / 7;
-        int it = fr + kd - 2, ih = r.a + kh, iw = r.b + kw;
-        if (it >= 0 && it < s.T3 && ih >= 0 && ih < s.H && iw >= 0 && iw < s.W)
-          x = src[((long long)it * s.H + ih) * s.W + iw];
-      }
-      v[e] = x;
-    }
-    if (sizeof(T) == 4) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) out.w[e] = __float_as_uint(v[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC / 2; ++e) out.w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
-    }
-    return out;
-  }
-  long long off;
-  if (MODE == MODE_PLAIN) {
-    off = r.base + k;
-  } else if (MODE == MODE_CONV_FWD) {
-    int tap = k / s.C, c = k - tap * s.C; int kh = tap / s.KW, kw = tap - kh * s.KW;
-    int ih = r.a + kh, iw = r.b + kw;
-    if (ih < 0 || ih >= s.H || iw < 0 || iw >= s.W) return out;
-    off = r.base + ((long long)ih * s.W + iw) * s.C + c;
-  } else {  // MODE_CONV_BWD
-    int tap = k / s.C, c = k - tap * s.C; int kh = tap / s.KW, kw = tap - kh * s.KW;
-    int th = r.a - kh, tw = r.b - kw;
-    if (th < 0 || tw < 0) return out;
-    int oh = th / s.stride, ow = tw / s.stride;
-    if (oh * s.stride != th || ow * s.stride != tw || oh >= s.OH || ow >= s.OW) return out;
-    off = r.base + ((long long)oh * s.OW + ow) * s.C + c;
-  }
-  if (SRC_F32 && sizeof(T) == 2) {      // fp32 source converted to bf16 while staging
-    const float* p = (const float*)s.ptr + off;
-    float v[8];
-    if (k + 8 <= K) {
-      chunk16 lo = ldg16(p), hi = ldg16(p + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(lo.w[e]); v[4 + e] = __uint_as_float(hi.w[e]); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? p[e] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) out.w[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
-    return out;
-  }
-  const T* p = (const T*)s.ptr + off;
-  if (k + VEC <= K && (sizeof(T) == 4 || ((off & 1) == 0))) return ldg16(p);   // vector path needs dword alignment
-  if (sizeof(T) == 4) {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) if (k + e < K) out.w[e] = ((const uint32_t*)p)[e];
+// ---- pending chunk: raw loaded words + how to finish them when they are staged into LDS ----
+struct Pend { chunk16 lo, hi; int flags; };   // flags bit0: valid, bit1: only the first half of the chunk is inside K (tail)
+
+// element offset of (row r, K index k) or -1;  conv: (kh, kw, c) precomputed by the caller
+template <int MODE>
+__device__ __forceinline__ long long conv_offset(const RowSrc& s, const RowInfo& r, int kh, int kw, int c) {
+  if (MODE == MODE_CONV_FWD) {
+    const int ih = r.a + kh, iw = r.b + kw;
+    const bool ok = r.valid && ih >= 0 && ih < s.H && iw >= 0 && iw < s.W;
+    return ok ? r.base + ((long long)ih * s.W + iw) * s.C + c : -1;
   } else {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) if (k + e < K) out.w[e >> 1] |= ((uint32_t)((const bf16_raw*)p)[e]) << (16 * (e & 1));
+    const int th = r.a - kh, tw = r.b - kw;
+    int oh = th, ow = tw; bool ok = r.valid && th >= 0 && tw >= 0;
+    if (s.stride == 2) { ok = ok && !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
+    else if (s.stride != 1) { oh = th / s.stride; ow = tw / s.stride; ok = ok && oh * s.stride == th && ow * s.stride == tw; }
+    ok = ok && oh < s.OH && ow < s.OW;
+    return ok ? r.base + ((long long)oh * s.OW + ow) * s.C + c : -1;
   }
-  return out;
+}
+
+// issue the (unconditional) loads of one chunk.  Requirements checked on the host: bf16 element offsets are even (every access
+// dword aligned) and K >= VEC.  A chunk is whole, a tail (nvalid < VEC elements inside K) or empty.  A tail reads the LAST full
+// 16 bytes of the row (in bounds) and is shifted down when staged; flags = valid | (elements to shift) << 4.
+template <typename T, bool SRC_F32, bool A16>
+__device__ __forceinline__ Pend issue_load(const void* base, long long off, int k, int K) {
+  constexpr int VEC = Elt<T>::VEC;
+  Pend p;
+  const bool valid = off >= 0 && k < K;
+  const int sh = (valid && k + VEC > K) ? (k + VEC - K) : 0;        // elements of the chunk beyond K
+  p.flags = (valid ? 1 : 0) | (sh << 4);
+  if (SRC_F32 && sizeof(T) == 2) {                  // 8 fp32 source elements -> one bf16 chunk (host guarantees K % 4 == 0: sh in {0, 4})
+    const float* q = (const float*)base + (valid ? off : 0);
+    if (A16) { p.lo = *(const chunk16*)q; p.hi = *(const chunk16*)(q + ((sh || !valid) ? 0 : 4)); }
+    else { p.lo = ldg16(q); p.hi = ldg16(q + ((sh || !valid) ? 0 : 4)); }
+  } else {
+    const T* q = (const T*)base + (valid ? off - sh : 0);
+    if (A16) p.lo = *(const chunk16*)q; else p.lo = ldg16(q);     // A16: the host proved every chunk address 16-byte aligned -> one dwordx4
+    p.hi = p.lo;
+  }
+  return p;
+}
+
+template <typename T, bool SRC_F32>
+__device__ __forceinline__ chunk16 finish_load(const Pend& p) {
+  chunk16 o;
+  const int sh = p.flags >> 4;
+  if (SRC_F32 && sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      o.w[e] = (uint32_t)f32_to_bf16(__uint_as_float(p.lo.w[2 * e])) | ((uint32_t)f32_to_bf16(__uint_as_float(p.lo.w[2 * e + 1])) << 16);
+      o.w[2 + e] = (uint32_t)f32_to_bf16(__uint_as_float(p.hi.w[2 * e])) | ((uint32_t)f32_to_bf16(__uint_as_float(p.hi.w[2 * e + 1])) << 16);
+    }
+    if (sh) { o.w[2] = 0u; o.w[3] = 0u; }
+  } else {
+    o = p.lo;
+    if (sh) {                                        // shift the 128-bit chunk down by `sh` elements (rare: only the K tail)
+      int ws = (sizeof(T) == 4) ? sh : (sh >> 1);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) if (ws > t) { o.w[0] = o.w[1]; o.w[1] = o.w[2]; o.w[2] = o.w[3]; o.w[3] = 0u; }
+      if (sizeof(T) == 2 && (sh & 1)) {
+        o.w[0] = (o.w[0] >> 16) | (o.w[1] << 16); o.w[1] = (o.w[1] >> 16) | (o.w[2] << 16);
+        o.w[2] = (o.w[2] >> 16) | (o.w[3] << 16); o.w[3] = o.w[3] >> 16;
+      }
+    }
+  }
+  if (!(p.flags & 1)) { o.w[0] = o.w[1] = o.w[2] = o.w[3] = 0u; }
+  return o;
 }
 
 struct Epi {
@@ -134,7 +129,7 @@ struct Epi {
   const void* res; long long ldres; float alpha; int res_act;
   const void* dact_z; long long ldz; int dact;   // multiply by act'(z) (1 swish, 2 relu)
   float* colsum;                   // += column sums of v (bias gradient)
-  float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics)
+  float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
 };
 
 struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; };
@@ -153,14 +148,30 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BM, int BN, int MODE, bool SRC_F32>
+template <typename T, int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wm, int wn, int frag_off, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    chunk16 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + (wm * (BM / 2) + i * 32) * LDS_ROW + frag_off + kk * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + (wn * (BN / 2) + j * 32) * LDS_ROW + frag_off + kk * 32);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+  }
+}
+
+template <typename T, int BM, int BN, int MODE, bool SRC_F32, bool A16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = BKB / (int)sizeof(T);   // K elements per tile
   constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
   constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int TILE = (BM + BN) * LDS_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem; char* Bs = smem + BM * LDS_ROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
@@ -182,39 +193,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  chunk16 ca[NCA], cb[NCB];
+  Pend pa[NCA], pb[NCB];
   const int KT = (g.K + KE - 1) / KE;
+  auto issue = [&](int kt) {
+    const int k = kt * KE + kc;
+    if (MODE == MODE_PLAIN) {
 #pragma unroll
-  for (int i = 0; i < NCA; ++i) ca[i] = fetch_chunk<T, MODE, SRC_F32>(g.a, ra[i], kc, g.K);
+      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, SRC_F32, A16>(g.a.ptr, ra[i].valid ? ra[i].base + k : -1, k, g.K);
+    } else {
+      int tap, c;
+      if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + kc; }   // whole K-step inside one tap: wave-uniform
+      else { tap = k / g.a.C; c = k - tap * g.a.C; }
+      const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
 #pragma unroll
-  for (int i = 0; i < NCB; ++i) cb[i] = fetch_chunk<T, MODE_PLAIN, false>(ws, rb[i], kc, g.K);
+      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, false, A16>(g.a.ptr, conv_offset<MODE == MODE_PLAIN ? MODE_CONV_FWD : MODE>(g.a, ra[i], kh, kw, c), k, g.K);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) pb[i] = issue_load<T, false, A16>(g.W, rb[i].valid ? rb[i].base + k : -1, k, g.K);
+  };
+  auto stage = [&](int buf) {
+    char* As = smem + buf * TILE; char* Bs = As + BM * LDS_ROW;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) *(chunk16*)(As + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, SRC_F32 && MODE == MODE_PLAIN>(pa[i]);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) *(chunk16*)(Bs + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, false>(pb[i]);
+  };
 
   const int frag_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+  issue(0);
+  stage(0);
+  __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-    for (int i = 0; i < NCA; ++i) *(chunk16*)(As + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = ca[i];
-#pragma unroll
-    for (int i = 0; i < NCB; ++i) *(chunk16*)(Bs + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = cb[i];
-    __syncthreads();
-    if (kt + 1 < KT) {
-      const int k = (kt + 1) * KE + kc;
-#pragma unroll
-      for (int i = 0; i < NCA; ++i) ca[i] = fetch_chunk<T, MODE, SRC_F32>(g.a, ra[i], k, g.K);
-#pragma unroll
-      for (int i = 0; i < NCB; ++i) cb[i] = fetch_chunk<T, MODE_PLAIN, false>(ws, rb[i], k, g.K);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      chunk16 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + (wm * (BM / 2) + i * 32) * LDS_ROW + frag_off + kk * 32);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + (wn * (BN / 2) + j * 32) * LDS_ROW + frag_off + kk * 32);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-    }
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1);                                        // loads in flight during the MFMAs below
+    mma_tile<T, BM, BN, MT, NT>(smem + cur * TILE, smem + cur * TILE + BM * LDS_ROW, wm, wn, frag_off, acc);
+    if (kt + 1 < KT) stage(cur ^ 1);                                       // other buffer: last read two barriers ago
     __syncthreads();
   }
 
@@ -246,12 +259,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
           }
     }
     __syncthreads();
+    // 4-wide vector I/O whenever the 4 columns are inside N and every row stride keeps them 8/16-byte aligned
+    const bool v4 = vec_ok && !(e.ldo & 3) && !(e.ldpre & 3) && !(e.ldres & 3) && !(e.ldz & 3);
 #pragma unroll 1
     for (int lr = tid / TPR; lr < 64; lr += 256 / TPR) {
       const long long row = m0 + pass * 64 + lr;
       if (row >= g.M || col >= g.N) continue;
       float v[4];
       { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      if (v4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bias4[c];
+        if (e.out_pre) st4<T>((T*)e.out_pre + row * e.ldpre + col, v);
+        if (e.act == 1) { for (int c = 0; c < 4; ++c) v[c] = swishf_(v[c]); } else if (e.act == 2) { for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f); }
+        if (e.drop_p > 0.f) { for (int c = 0; c < 4; ++c) v[c] *= drop_scale(e.rng, e.stream, (unsigned long long)row * g.N + col + c, e.drop_p); }
+        if (e.dact) {
+          float z[4]; ld4<T>((const T*)e.dact_z + row * e.ldz + col, z);
+          for (int c = 0; c < 4; ++c) v[c] *= (e.dact == 1) ? dswishf_(z[c]) : (z[c] > 0.f ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * v[c]; v[c] *= e.alpha; }
+        if (e.res) {
+          float r4[4];
+          if (e.res_act) ld4<T>((const T*)e.res + row * e.ldres + col, r4); else ld4<float>((const float*)e.res + row * e.ldres + col, r4);
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (col + c >= g.N) { v[c] = 0.f; continue; }
@@ -268,14 +303,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         if (e.res) x += e.res_act ? ldf((const T*)e.res + row * e.ldres + col + c) : ((const float*)e.res)[row * e.ldres + col + c];
         v[c] = x;
       }
-      if (e.out_f32) {
-        float* o = (float*)e.out + row * e.ldo + col;
-        if (vec_ok && ((e.ldo & 3) == 0)) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        else { for (int c = 0; c < 4; ++c) if (col + c < g.N) o[c] = v[c]; }
-      } else {
-        T* o = (T*)e.out + row * e.ldo + col;
-        for (int c = 0; c < 4; ++c) if (col + c < g.N) stf(o + c, v[c]);
-      }
+      if (e.out_f32) { float* o = (float*)e.out + row * e.ldo + col; for (int c = 0; c < 4; ++c) if (col + c < g.N) o[c] = v[c]; }
+      else { T* o = (T*)e.out + row * e.ldo + col; for (int c = 0; c < 4; ++c) if (col + c < g.N) stf(o + c, v[c]); }
     }
     __syncthreads();
   }
@@ -302,11 +331,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // TN: O[i][j] += sum_m P[m][i] * Q[m][j];   P plain [M][I] (T), Q via row loader ([M][J], plain or im2col)
 // LDS images are [i][m] / [j][m] (reduction index contiguous) filled by transposing stores.
 // ------------------------------------------------------------------------------------------------
-struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J; int m_per_block; };
+struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Jq; int m_per_block; };   // Jq: load bound of Q (>= J when its rows are padded)
 
 template <typename T>
 __device__ __forceinline__ void store_transposed(char* S, int col0, int mloc, const chunk16& c) {
-  // writes the VEC elements of chunk (tile columns col0..col0+VEC-1, reduction row mloc) into S[col][mloc]
   constexpr int VEC = Elt<T>::VEC;
   if (sizeof(T) == 4) {
 #pragma unroll
@@ -317,22 +345,22 @@ __device__ __forceinline__ void store_transposed(char* S, int col0, int mloc, co
   }
 }
 
-template <typename T, int BI, int BJ, int MODE, bool Q_F32>
+template <typename T, int BI, int BJ, int MODE, bool Q_F32, bool A16>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = BKB / (int)sizeof(T);     // reduction rows (m) per tile
   constexpr int CPR_I = BI / VEC, CPR_J = BJ / VEC;          // chunks per m-row
   constexpr int NCI = KE * CPR_I / 256, NCJ = KE * CPR_J / 256;  // chunks per thread
   constexpr int MT = BI / 64, NT = BJ / 64;
+  constexpr int TILE = (BI + BJ) * LDS_ROW;
+  constexpr bool Q_CONV = (MODE == MODE_CONV_FWD);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ps = smem; char* Qs = smem + BI * LDS_ROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
   const long long mb = (long long)blockIdx.z * g.m_per_block;
   long long me = mb + g.m_per_block; if (me > g.M) me = g.M;
 
-  RowSrc ps; ps.ptr = g.P; ps.ld = g.ldp; ps.step = 0; ps.rows_out = ps.rows_in = 1;
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -341,45 +369,61 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  chunk16 cp[NCI], cq[NCJ];
-  auto fetch = [&](long long mt0) {
+  // each thread's chunk columns are loop invariant; conv: so is their (tap, channel); its row (img, oh, ow) advances by KE per step
+  int pi[NCI], qj[NCJ], qkh[NCJ], qkw[NCJ], qc[NCJ], qoh[NCJ], qow[NCJ]; long long qimg[NCJ];
+#pragma unroll
+  for (int u = 0; u < NCI; ++u) pi[u] = i0 + ((tid + u * 256) % CPR_I) * VEC;
+#pragma unroll
+  for (int u = 0; u < NCJ; ++u) {
+    const int c = tid + u * 256; qj[u] = j0 + (c % CPR_J) * VEC;
+    if (Q_CONV) {
+      const int tap = qj[u] / g.q.C; qc[u] = qj[u] - tap * g.q.C; qkh[u] = tap / g.q.KW; qkw[u] = tap - qkh[u] * g.q.KW;
+      const long long m = mb + c / CPR_J; qow[u] = (int)(m % g.q.OW); const long long t = m / g.q.OW; qoh[u] = (int)(t % g.q.OH); qimg[u] = t / g.q.OH;
+    }
+  }
+  Pend pp[NCI], pq[NCJ];
+  auto issue = [&](long long mt0) {
 #pragma unroll
     for (int u = 0; u < NCI; ++u) {
-      int c = tid + u * 256; int mloc = c / CPR_I, ci = c % CPR_I;
-      long long m = mt0 + mloc;
-      RowInfo r = row_info<MODE_PLAIN>(ps, m, me);
-      cp[u] = fetch_chunk<T, MODE_PLAIN, false>(ps, r, i0 + ci * VEC, g.I);
+      const long long m = mt0 + (tid + u * 256) / CPR_I;
+      pp[u] = issue_load<T, false, A16>(g.P, m < me ? m * g.ldp + pi[u] : -1, pi[u], g.I);
     }
 #pragma unroll
     for (int u = 0; u < NCJ; ++u) {
-      int c = tid + u * 256; int mloc = c / CPR_J, cj = c % CPR_J;
-      long long m = mt0 + mloc;
-      RowInfo r = row_info<MODE>(g.q, m, me);
-      cq[u] = fetch_chunk<T, MODE, Q_F32>(g.q, r, j0 + cj * VEC, g.J);
+      const long long m = mt0 + (tid + u * 256) / CPR_J;
+      if (Q_CONV) {
+        RowInfo r; r.valid = m < me; r.base = qimg[u] * (long long)g.q.H * g.q.W * g.q.C;
+        r.a = qoh[u] * g.q.stride - g.q.pad; r.b = qow[u] * g.q.stride - g.q.pad;
+        pq[u] = issue_load<T, false, A16>(g.q.ptr, conv_offset<MODE_CONV_FWD>(g.q, r, qkh[u], qkw[u], qc[u]), qj[u], g.J);
+        qow[u] += KE;                                         // advance this thread's row by one reduction tile
+        while (qow[u] >= g.q.OW) { qow[u] -= g.q.OW; if (++qoh[u] >= g.q.OH) { qoh[u] = 0; ++qimg[u]; } }
+      } else {
+        long long row = m;
+        if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
+        pq[u] = issue_load<T, Q_F32, A16>(g.q.ptr, m < me ? row * g.q.ld + qj[u] : -1, qj[u], g.Jq);
+      }
     }
   };
+  auto stage = [&](int buf) {
+    char* Ps = smem + buf * TILE; char* Qs = Ps + BI * LDS_ROW;
+#pragma unroll
+    for (int u = 0; u < NCI; ++u) { const int c = tid + u * 256; store_transposed<T>(Ps, (c % CPR_I) * VEC, c / CPR_I, finish_load<T, false>(pp[u])); }
+#pragma unroll
+    for (int u = 0; u < NCJ; ++u) { const int c = tid + u * 256; store_transposed<T>(Qs, (c % CPR_J) * VEC, c / CPR_J, finish_load<T, Q_F32 && !Q_CONV>(pq[u])); }
+  };
   const int frag_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
-  if (mb < me) fetch(mb);
-  for (long long mt0 = mb; mt0 < me; mt0 += KE) {
-#pragma unroll
-    for (int u = 0; u < NCI; ++u) { int c = tid + u * 256; store_transposed<T>(Ps, (c % CPR_I) * VEC, c / CPR_I, cp[u]); }
-#pragma unroll
-    for (int u = 0; u < NCJ; ++u) { int c = tid + u * 256; store_transposed<T>(Qs, (c % CPR_J) * VEC, c / CPR_J, cq[u]); }
+  if (mb < me) {
+    issue(mb);
+    stage(0);
     __syncthreads();
-    if (mt0 + KE < me) fetch(mt0 + KE);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      chunk16 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(Ps + (wm * (BI / 2) + i * 32) * LDS_ROW + frag_off + kk * 32);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Qs + (wn * (BJ / 2) + j * 32) * LDS_ROW + frag_off + kk * 32);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    int cur = 0;
+    for (long long mt0 = mb; mt0 < me; mt0 += KE, cur ^= 1) {
+      const bool more = mt0 + KE < me;
+      if (more) issue(mt0 + KE);
+      mma_tile<T, BI, BJ, MT, NT>(smem + cur * TILE, smem + cur * TILE + BI * LDS_ROW, wm, wn, frag_off, acc);
+      if (more) stage(cur ^ 1);
+      __syncthreads();
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -398,31 +442,50 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 // ------------------------------------------------------------------------------------------------
 // host launchers (C ABI)
 // ------------------------------------------------------------------------------------------------
+#include <stdint.h>
 static RowSrc make_src(const void* ptr, const avec_rows_t* d) {
   RowSrc s; s.ptr = ptr; s.ld = d->ld; s.rows_out = d->rows_out; s.rows_in = d->rows_in; s.step = d->step;
-  s.H = d->H; s.W = d->W; s.C = d->C; s.KH = d->KH; s.KW = d->KW; s.stride = d->stride; s.pad = d->pad; s.OH = d->OH; s.OW = d->OW; s.T3 = d->T3;
+  s.H = d->H; s.W = d->W; s.C = d->C; s.KH = d->KH; s.KW = d->KW; s.stride = d->stride; s.pad = d->pad; s.OH = d->OH; s.OW = d->OW;
   return s;
 }
 
+template <typename K> static int want_lds(K kern, size_t bytes) {
+  static const void* done[256]; static int ndone = 0;
+  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { avec_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+  if (ndone < 256) done[ndone++] = (const void*)kern;
+  return 0;
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 template <typename T, int BM, int BN>
-static void launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
+static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN));
-  size_t lds = (size_t)(BM + BN) * LDS_ROW;
-#define L(MODE, F) hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F>), grid, dim3(256), lds, st, g)
-  if (mode == MODE_PLAIN) { if (src_f32) L(MODE_PLAIN, true); else L(MODE_PLAIN, false); }
-  else if (mode == MODE_CONV_FWD) L(MODE_CONV_FWD, false);
-  else if (mode == MODE_CONV_BWD) L(MODE_CONV_BWD, false);
-  else L(MODE_STEM3D, true);
+  size_t lds = (size_t)2 * (BM + BN) * LDS_ROW;
+  constexpr int VEC = Elt<T>::VEC;
+  const bool f32src = src_f32 && sizeof(T) == 2;
+  // every chunk address 16-byte aligned?  (then each chunk is one global_load_dwordx4 instead of two dwordx2)
+  const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
+                   (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
+#define L(MODE, F, A) do { if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
+  if (mode == MODE_PLAIN) {
+    if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
+    else { if (a16) L(MODE_PLAIN, false, true); else L(MODE_PLAIN, false, false); }
+  } else if (mode == MODE_CONV_FWD) { if (a16) L(MODE_CONV_FWD, false, true); else L(MODE_CONV_FWD, false, false); }
+  else { if (a16) L(MODE_CONV_BWD, false, true); else L(MODE_CONV_BWD, false, false); }
 #undef L
+  return 0;
 }
 
 template <typename T>
-static void launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
+static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   // tile choice: big tiles only when they still fill the chip (256 CUs)
   long long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-  if (g.N > 64 && t128 >= 384) launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
-  else if (((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
-  else launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
+  if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
+  if (((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
+  return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
 }
 
 extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows, int a_mode, int a_f32,
@@ -431,8 +494,13 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   AVEC_CHECK_ARG(dtype == AVEC_F32 || dtype == AVEC_BF16, "gemm_nt: bad dtype %d", dtype);
   AVEC_CHECK_ARG(A && W && ep && ep->out && a_rows, "gemm_nt: null pointer");
   AVEC_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: bad dims M=%lld N=%d K=%d", M, N, K);
-  AVEC_CHECK_ARG(a_mode >= 0 && a_mode <= 3, "gemm_nt: bad a_mode %d", a_mode);
-  AVEC_CHECK_ARG(!(a_mode != MODE_PLAIN && a_mode != MODE_STEM3D && a_rows->C % (dtype == AVEC_BF16 ? 8 : 4)), "gemm_nt: conv C=%d not a multiple of the vector width", a_rows->C);
+  AVEC_CHECK_ARG(a_mode >= 0 && a_mode <= 2, "gemm_nt: bad a_mode %d", a_mode);
+  const int vec = dtype == AVEC_BF16 ? 8 : 4;
+  AVEC_CHECK_ARG(K >= vec && (dtype == AVEC_F32 || (K % 2 == 0 && ldw % 2 == 0)), "gemm_nt: K=%d / ldw=%lld: need K >= %d and (bf16) even K, ldw (dword-aligned chunks)", K, ldw, vec);
+  AVEC_CHECK_ARG(a_mode != AVEC_ROWS_PLAIN || dtype == AVEC_F32 || a_rows->ld % 2 == 0, "gemm_nt: lda=%lld must be even", a_rows->ld);
+  AVEC_CHECK_ARG(!(a_f32 && dtype == AVEC_BF16) || K % 4 == 0, "gemm_nt: fp32-source staging needs K %% 4 == 0 (K=%d)", K);
+  AVEC_CHECK_ARG(a_mode == AVEC_ROWS_PLAIN || (a_rows->C % vec == 0 && K == a_rows->KH * a_rows->KW * a_rows->C),
+                 "gemm_nt: conv C=%d must be a multiple of %d and K = KH*KW*C", a_rows->C, vec);
   GemmArgs g; g.a = make_src(A, a_rows); g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
   Epi& e = g.e;
   e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
@@ -440,13 +508,14 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
   AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt: dropout without rng state");
-  if (dtype == AVEC_BF16) launch_nt<bf16>(g, a_mode, a_f32, stream); else launch_nt<float>(g, a_mode, a_f32, stream);
+  int r = (dtype == AVEC_BF16) ? launch_nt<bf16>(g, a_mode, a_f32, stream) : launch_nt<float>(g, a_mode, a_f32, stream);
+  if (r) return r;
   AVEC_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T, int BI, int BJ>
-static void launch_tn_tile(TnArgs g, int mode, int q_f32, hipStream_t st) {
+static int launch_tn_tile(TnArgs g, int mode, int q_f32, hipStream_t st) {
   constexpr int KE = BKB / (int)sizeof(T);
   int tiles = ((g.I + BI - 1) / BI) * ((g.J + BJ - 1) / BJ);
   long long ksteps = (g.M + KE - 1) / KE;
@@ -455,12 +524,18 @@ static void launch_tn_tile(TnArgs g, int mode, int q_f32, hipStream_t st) {
   split = (g.M + per - 1) / per;
   g.m_per_block = (int)per;
   dim3 grid((g.I + BI - 1) / BI, (g.J + BJ - 1) / BJ, (unsigned)split);
-  size_t lds = (size_t)(BI + BJ) * LDS_ROW;
-#define L(MODE, F) hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F>), grid, dim3(256), lds, st, g)
-  if (mode == MODE_PLAIN) { if (q_f32) L(MODE_PLAIN, true); else L(MODE_PLAIN, false); }
-  else if (mode == MODE_CONV_FWD) L(MODE_CONV_FWD, false);
-  else L(MODE_STEM3D, true);
+  size_t lds = (size_t)2 * (BI + BJ) * LDS_ROW;
+  constexpr int VEC = Elt<T>::VEC;
+  const bool f32src = q_f32 && sizeof(T) == 2;
+  const bool a16 = aligned16(g.P) && aligned16(g.q.ptr) && g.I % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
+                   (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
+#define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
+  if (mode == MODE_PLAIN) {
+    if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
+    else { if (a16) L(MODE_PLAIN, false, true); else L(MODE_PLAIN, false, false); }
+  } else { if (a16) L(MODE_CONV_FWD, false, true); else L(MODE_CONV_FWD, false, false); }
 #undef L
+  return 0;
 }
 
 extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
@@ -468,11 +543,20 @@ extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void*
   AVEC_CHECK_ARG(dtype == AVEC_F32 || dtype == AVEC_BF16, "gemm_tn: bad dtype %d", dtype);
   AVEC_CHECK_ARG(P && Q && O && q_rows, "gemm_tn: null pointer");
   AVEC_CHECK_ARG(M > 0 && I > 0 && J > 0, "gemm_tn: bad dims");
-  AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_mode == MODE_CONV_FWD || q_mode == MODE_STEM3D, "gemm_tn: bad q_mode %d", q_mode);
-  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.m_per_block = 0;
+  AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_mode == MODE_CONV_FWD, "gemm_tn: bad q_mode %d", q_mode);
+  const int vec = dtype == AVEC_BF16 ? 8 : 4;
+  // Q rows padded to a multiple of the vector width (e.g. the stem im2col matrix, J=245 in rows of 248): load the padding, bound the output by J
+  const int Jq = (q_mode == MODE_PLAIN && q_rows->ld >= (J + vec - 1) / vec * vec) ? (J + vec - 1) / vec * vec : J;
+  AVEC_CHECK_ARG(I >= vec && J >= vec && (dtype == AVEC_F32 || (I % 2 == 0 && Jq % 2 == 0 && ldp % 2 == 0)), "gemm_tn: I=%d, J=%d: need >= %d and (bf16) even I, J, ldp", I, J, vec);
+  AVEC_CHECK_ARG(q_mode != MODE_PLAIN || dtype == AVEC_F32 || q_rows->ld % 2 == 0, "gemm_tn: ldq must be even");
+  AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
+  AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_rows->C % vec == 0, "gemm_tn: conv C=%d must be a multiple of %d", q_rows->C, vec);
+  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Jq = Jq; g.m_per_block = 0;
   bool big = (I >= 128 && J >= 128);
-  if (dtype == AVEC_BF16) { if (big) launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, stream); else launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, stream); }
-  else { if (big) launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, stream); else launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, stream); }
+  int r;
+  if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, stream) : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, stream);
+  else r = big ? launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, stream) : launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, stream);
+  if (r) return r;
   AVEC_LAUNCH_CHECK();
   return 0;
 }

@@ -40,13 +40,13 @@ int avec_version(void);
 const char* avec_last_error(void);
 
 /* ---- row sources for the GEMM family ------------------------------------------------------ */
-enum { AVEC_ROWS_PLAIN = 0, AVEC_ROWS_CONV_FWD = 1, AVEC_ROWS_CONV_BWD = 2, AVEC_ROWS_STEM3D = 3 };
+enum { AVEC_ROWS_PLAIN = 0, AVEC_ROWS_CONV_FWD = 1, AVEC_ROWS_CONV_BWD = 2 };
 typedef struct avec_rows {
   long long ld;                 /* PLAIN: row stride (elements) */
   int rows_out, rows_in, step;  /* PLAIN: src_row = (m / rows_out) * rows_in + (m % rows_out) * step when step > 1
                                    (strided time sub-sampling: the k=1 stride-2 conv_res, nnet/blocks.py:273-277) */
   int H, W, C, KH, KW, stride, pad, OH, OW; /* CONV_*: NHWC geometry; explicit "same" zero padding of nnet/layers.py:250-261 is folded into the loader */
-  int T3;                       /* STEM3D: frames per clip (Conv3d (5,7,7) stride (1,2,2), nnet/networks.py:460-469) */
+  int T3;                       /* reserved */
 } avec_rows_t;
 
 typedef struct avec_epilogue {
