@@ -333,24 +333,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Jq; int m_per_block; };   // Jq: load bound of Q (>= J when its rows are padded)
 
+// LDS image of a TN operand: [col][word], word = reduction-row pair (bf16: rows 2p,2p+1 packed in 32 bits) or row (fp32), 32 words
+// per 144-byte row.  Word index XOR-swizzled by 16 * parity(col bits 2..4): with lanes mapped (16 pairs x 4 column chunks) both the
+// ds_write_b32 of the transposing store and the ds_read_b128 of the MFMA fragments are bank-conflict free (brute-forced offline).
+__device__ __forceinline__ int tn_swz(int col) { return (((col >> 2) ^ (col >> 3) ^ (col >> 4)) & 1) << 4; }
+
 template <typename T>
-__device__ __forceinline__ void store_transposed(char* S, int col0, int mloc, const chunk16& c) {
+__device__ __forceinline__ void store_transposed(char* S, int col0, int p, const chunk16& c0, const chunk16& c1) {
   constexpr int VEC = Elt<T>::VEC;
   if (sizeof(T) == 4) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) *(uint32_t*)(S + (col0 + e) * LDS_ROW + mloc * 4) = c.w[e];
+    for (int e = 0; e < VEC; ++e) *(uint32_t*)(S + (col0 + e) * LDS_ROW + ((p ^ tn_swz(col0 + e)) << 2)) = c0.w[e];
   } else {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) *(bf16_raw*)(S + (col0 + e) * LDS_ROW + mloc * 2) = (bf16_raw)(c.w[e >> 1] >> (16 * (e & 1)));
+    for (int e = 0; e < VEC; ++e) {
+      const uint32_t w = (e & 1) ? __builtin_amdgcn_perm(c1.w[e >> 1], c0.w[e >> 1], 0x07060302u) : __builtin_amdgcn_perm(c1.w[e >> 1], c0.w[e >> 1], 0x05040100u);
+      *(uint32_t*)(S + (col0 + e) * LDS_ROW + ((p ^ tn_swz(col0 + e)) << 2)) = w;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void mma_tile_swz(const char* As, const char* Bs, int wm, int wn, int lane, f32x16 (&acc)[MT][NT]) {
+  int offa[MT], offb[NT], lowa[MT], lowb[NT];     // row base and swizzled in-row byte offset (kept apart: the k-step is XOR-ed into the latter)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / 2) + i * 32 + (lane & 31); offa[i] = row * LDS_ROW; lowa[i] = ((lane >> 5) * 16) ^ (tn_swz(row) << 2); }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * LDS_ROW; lowb[j] = ((lane >> 5) * 16) ^ (tn_swz(row) << 2); }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    chunk16 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + offa[i] + (lowa[i] ^ (kk * 32)));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + offb[j] + (lowb[j] ^ (kk * 32)));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
   }
 }
 
 template <typename T, int BI, int BJ, int MODE, bool Q_F32, bool A16>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   constexpr int VEC = Elt<T>::VEC;
-  constexpr int KE = BKB / (int)sizeof(T);     // reduction rows (m) per tile
-  constexpr int CPR_I = BI / VEC, CPR_J = BJ / VEC;          // chunks per m-row
-  constexpr int NCI = KE * CPR_I / 256, NCJ = KE * CPR_J / 256;  // chunks per thread
+  constexpr int RPT = sizeof(T) == 2 ? 2 : 1;   // reduction rows per task (bf16: a pair packed into one 32-bit LDS word)
+  constexpr int KE = 32 * RPT;                  // reduction rows (m) per tile = 128 bytes of LDS row
+  constexpr int CPR_I = BI / VEC, CPR_J = BJ / VEC;          // column chunks per row
+  constexpr int NTI = 32 * CPR_I / 256, NTJ = 32 * CPR_J / 256;  // tasks per thread
   constexpr int MT = BI / 64, NT = BJ / 64;
   constexpr int TILE = (BI + BJ) * LDS_ROW;
   constexpr bool Q_CONV = (MODE == MODE_CONV_FWD);
@@ -369,49 +399,55 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // each thread's chunk columns are loop invariant; conv: so is their (tap, channel); its row (img, oh, ow) advances by KE per step
-  int pi[NCI], qj[NCJ], qkh[NCJ], qkw[NCJ], qc[NCJ], qoh[NCJ], qow[NCJ]; long long qimg[NCJ];
+  // task t of this thread: (pair p, column chunk ci); lanes: 16 pairs x 4 chunks, the remaining index bits alternate pair-half / chunk-group
+  auto task_p = [&](int u) { const int hi = (tid >> 6) + 4 * u; return (tid & 15) + 16 * (hi & 1); };
+  auto task_c = [&](int u) { const int hi = (tid >> 6) + 4 * u; return ((tid >> 4) & 3) + 4 * (hi >> 1); };
+  int qkh[NTJ], qkw[NTJ], qc[NTJ], qoh[NTJ][RPT], qow[NTJ][RPT]; long long qimg[NTJ][RPT];
+  if (Q_CONV) {
 #pragma unroll
-  for (int u = 0; u < NCI; ++u) pi[u] = i0 + ((tid + u * 256) % CPR_I) * VEC;
+    for (int u = 0; u < NTJ; ++u) {
+      const int j = j0 + task_c(u) * VEC; const int tap = j / g.q.C; qc[u] = j - tap * g.q.C; qkh[u] = tap / g.q.KW; qkw[u] = tap - qkh[u] * g.q.KW;
 #pragma unroll
-  for (int u = 0; u < NCJ; ++u) {
-    const int c = tid + u * 256; qj[u] = j0 + (c % CPR_J) * VEC;
-    if (Q_CONV) {
-      const int tap = qj[u] / g.q.C; qc[u] = qj[u] - tap * g.q.C; qkh[u] = tap / g.q.KW; qkw[u] = tap - qkh[u] * g.q.KW;
-      const long long m = mb + c / CPR_J; qow[u] = (int)(m % g.q.OW); const long long t = m / g.q.OW; qoh[u] = (int)(t % g.q.OH); qimg[u] = t / g.q.OH;
+      for (int r = 0; r < RPT; ++r) {
+        const long long m = mb + task_p(u) * RPT + r; qow[u][r] = (int)(m % g.q.OW); const long long t = m / g.q.OW; qoh[u][r] = (int)(t % g.q.OH); qimg[u][r] = t / g.q.OH;
+      }
     }
   }
-  Pend pp[NCI], pq[NCJ];
+  Pend pp[NTI][RPT], pq[NTJ][RPT];
   auto issue = [&](long long mt0) {
 #pragma unroll
-    for (int u = 0; u < NCI; ++u) {
-      const long long m = mt0 + (tid + u * 256) / CPR_I;
-      pp[u] = issue_load<T, false, A16>(g.P, m < me ? m * g.ldp + pi[u] : -1, pi[u], g.I);
+    for (int u = 0; u < NTI; ++u) {
+      const int col = i0 + task_c(u) * VEC;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) { const long long m = mt0 + task_p(u) * RPT + r; pp[u][r] = issue_load<T, false, A16>(g.P, m < me ? m * g.ldp + col : -1, col, g.I); }
     }
 #pragma unroll
-    for (int u = 0; u < NCJ; ++u) {
-      const long long m = mt0 + (tid + u * 256) / CPR_J;
-      if (Q_CONV) {
-        RowInfo r; r.valid = m < me; r.base = qimg[u] * (long long)g.q.H * g.q.W * g.q.C;
-        r.a = qoh[u] * g.q.stride - g.q.pad; r.b = qow[u] * g.q.stride - g.q.pad;
-        pq[u] = issue_load<T, false, A16>(g.q.ptr, conv_offset<MODE_CONV_FWD>(g.q, r, qkh[u], qkw[u], qc[u]), qj[u], g.J);
-        qow[u] += KE;                                         // advance this thread's row by one reduction tile
-        while (qow[u] >= g.q.OW) { qow[u] -= g.q.OW; if (++qoh[u] >= g.q.OH) { qoh[u] = 0; ++qimg[u]; } }
-      } else {
-        long long row = m;
-        if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
-        pq[u] = issue_load<T, Q_F32, A16>(g.q.ptr, m < me ? row * g.q.ld + qj[u] : -1, qj[u], g.Jq);
+    for (int u = 0; u < NTJ; ++u) {
+      const int col = j0 + task_c(u) * VEC;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const long long m = mt0 + task_p(u) * RPT + r;
+        if (Q_CONV) {
+          RowInfo ri; ri.valid = m < me; ri.base = qimg[u][r] * (long long)g.q.H * g.q.W * g.q.C;
+          ri.a = qoh[u][r] * g.q.stride - g.q.pad; ri.b = qow[u][r] * g.q.stride - g.q.pad;
+          pq[u][r] = issue_load<T, false, A16>(g.q.ptr, conv_offset<MODE_CONV_FWD>(g.q, ri, qkh[u], qkw[u], qc[u]), col, g.J);
+          qow[u][r] += KE;                                       // advance this row by one reduction tile
+          while (qow[u][r] >= g.q.OW) { qow[u][r] -= g.q.OW; if (++qoh[u][r] >= g.q.OH) { qoh[u][r] = 0; ++qimg[u][r]; } }
+        } else {
+          long long row = m;
+          if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
+          pq[u][r] = issue_load<T, Q_F32, A16>(g.q.ptr, m < me ? row * g.q.ld + col : -1, col, g.Jq);
+        }
       }
     }
   };
   auto stage = [&](int buf) {
     char* Ps = smem + buf * TILE; char* Qs = Ps + BI * LDS_ROW;
 #pragma unroll
-    for (int u = 0; u < NCI; ++u) { const int c = tid + u * 256; store_transposed<T>(Ps, (c % CPR_I) * VEC, c / CPR_I, finish_load<T, false>(pp[u])); }
+    for (int u = 0; u < NTI; ++u) store_transposed<T>(Ps, task_c(u) * VEC, task_p(u), finish_load<T, false>(pp[u][0]), finish_load<T, false>(pp[u][RPT - 1]));
 #pragma unroll
-    for (int u = 0; u < NCJ; ++u) { const int c = tid + u * 256; store_transposed<T>(Qs, (c % CPR_J) * VEC, c / CPR_J, finish_load<T, Q_F32 && !Q_CONV>(pq[u])); }
+    for (int u = 0; u < NTJ; ++u) store_transposed<T>(Qs, task_c(u) * VEC, task_p(u), finish_load<T, Q_F32 && !Q_CONV>(pq[u][0]), finish_load<T, Q_F32 && !Q_CONV>(pq[u][RPT - 1]));
   };
-  const int frag_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
   if (mb < me) {
     issue(mb);
     stage(0);
@@ -420,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     for (long long mt0 = mb; mt0 < me; mt0 += KE, cur ^= 1) {
       const bool more = mt0 + KE < me;
       if (more) issue(mt0 + KE);
-      mma_tile<T, BI, BJ, MT, NT>(smem + cur * TILE, smem + cur * TILE + BI * LDS_ROW, wm, wn, frag_off, acc);
+      mma_tile_swz<T, BI, BJ, MT, NT>(smem + cur * TILE, smem + cur * TILE + BI * LDS_ROW, wm, wn, lane, acc);
       if (more) stage(cur ^ 1);
       __syncthreads();
     }
