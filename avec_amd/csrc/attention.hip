@@ -27,7 +27,8 @@ struct AttnArgs {
   const void* dout;                          // act [B*T][ldo]   (backward)
   void *dq, *dk, *dv; long long lddq, ldd;   // dq: act, row stride lddq; dk/dv: row stride ldd
   float* de; long long ldde;                 // fp32 [2T-1][ldde], atomically accumulated
-  float *pbuf, *dsbuf;                       // backward scratch [B*H][T][T] fp32: probabilities and dS (written by the dQ pass)
+  void *pbuf, *dsbuf; long long ldt;         // backward scratch, act [B*H][T][ldt]: probabilities and dS (written by the dQ pass)
+  void* dsrel; long long ldr;                // optional act [H][B*T][ldr]: dS re-indexed by E row r = j + (T-1) - i (zero elsewhere; caller zero-fills)
   int B, H, T, d; float scale;
 };
 
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
       } else {
         float p = (iv && jv) ? __expf(s - Li[rr]) * Il[rr] : 0.f;
         pval = p * (dp - dl[rr]) * a.scale;   // dS
-        if (iv && jv) { const long long o = ((long long)bh * Tn + i) * Tn + j; a.pbuf[o] = p; a.dsbuf[o] = pval; }
+        if (iv && jv) {
+          const long long o = ((long long)bh * Tn + i) * a.ldt + j; stf((T*)a.pbuf + o, p); stf((T*)a.dsbuf + o, pval);
+          if (a.dsrel) stf((T*)a.dsrel + ((long long)h * a.B * Tn + (long long)b * Tn + i) * a.ldr + (j + Tn - 1 - i), pval);
+        }
       }
       Ps[w * 64 + lane] = pval;
       __syncthreads();
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnArgs a, int ktil
   const int col = c0 + lane;
   const T* qp = (const T*)a.q + (long long)b * Tn * a.ld + h * d;
   const T* gp = (const T*)a.dout + (long long)b * Tn * a.ldo + h * d;
-  const float* P = a.pbuf + (long long)bh * Tn * Tn; const float* S = a.dsbuf + (long long)bh * Tn * Tn;
+  const T* P = (const T*)a.pbuf + (long long)bh * Tn * a.ldt; const T* S = (const T*)a.dsbuf + (long long)bh * Tn * a.ldt;
   float acc0[DPAD], acc1[DPAD];
 #pragma unroll
   for (int c = 0; c < DPAD; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
@@ -187,13 +191,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnArgs a, int ktil
       const float* qrow = Qs + qi * DP;
       if (!rel) {
         float ds = 0.f, p = 0.f;
-        if (col < Tn) { ds = S[(long long)i * Tn + col]; p = P[(long long)i * Tn + col]; }
+        if (col < Tn) { ds = ldf(S + (long long)i * a.ldt + col); p = ldf(P + (long long)i * a.ldt + col); }
         const float* grow = Gs + qi * DP;
 #pragma unroll
         for (int c = 0; c < DPAD; ++c) if (c < d) { acc0[c] += ds * qrow[c]; acc1[c] += p * grow[c]; }
       } else {
         const int j = i - (Tn - 1) + col;
-        const float ds = (col < 2 * Tn - 1 && j >= 0 && j < Tn) ? S[(long long)i * Tn + j] : 0.f;
+        const float ds = (col < 2 * Tn - 1 && j >= 0 && j < Tn) ? ldf(S + (long long)i * a.ldt + j) : 0.f;
 #pragma unroll
         for (int c = 0; c < DPAD; ++c) if (c < d) acc0[c] += ds * qrow[c];
       }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnArgs a, int ktil
 static int fill_args(AttnArgs& a, const avec_attn_t* p) {
   a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1; a.q_full = p->q_full > 0 ? p->q_full : p->T;
   a.mask = p->mask; a.mask_bstride = p->mask_bstride; a.o = p->o; a.ldo = p->ldo; a.lse = p->lse; a.dout = p->dout;
-  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde; a.pbuf = p->pbuf; a.dsbuf = p->dsbuf;
+  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde; a.pbuf = p->pbuf; a.dsbuf = p->dsbuf; a.ldt = p->ldt; a.dsrel = p->dsrel; a.ldr = p->ldr;
   a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale;
   AVEC_CHECK_ARG(a.q && a.k && a.v && a.e && a.o && a.lse, "attention: null pointer");
   AVEC_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.d > 0 && a.d <= 96, "attention: bad dims B=%d H=%d T=%d d=%d (d <= 96 supported)", a.B, a.H, a.T, a.d);
@@ -257,6 +261,7 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
   dim3 grid1((a.T + TQ - 1) / TQ, a.B * a.H);
   if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
   hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
+  if (a.dsrel) return 0;            // dK/dV/dE are computed by the caller with avec_gemm_tn_batched on P / dS / dSrel (MFMA path)
   size_t lds2 = (size_t)(2 * QC + 2 * 64) * DP * 4;
   const int ktiles = (a.T + 63) / 64, rtiles = (2 * a.T - 1 + 63) / 64;
   dim3 grid2(ktiles + rtiles, a.B * a.H);
@@ -268,7 +273,7 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
 
 extern "C" int avec_relpos_attention_bwd(int dtype, const avec_attn_t* p, hipStream_t st) {
   AttnArgs a; AVEC_CHECK_ARG(p, "attention_bwd: null args"); if (int r = fill_args(a, p)) return r;
-  AVEC_CHECK_ARG(a.dout && a.dq && a.dk && a.dv && a.de && a.pbuf && a.dsbuf, "attention_bwd: null gradient / scratch pointer");
+  AVEC_CHECK_ARG(a.dout && a.dq && a.pbuf && a.dsbuf && a.ldt >= a.T && (a.dsrel ? a.ldr >= 2 * a.T - 1 : (a.dk && a.dv && a.de)), "attention_bwd: null gradient / scratch pointer");
   int r = (dtype == AVEC_BF16) ? launch_bwd<bf16>(a, st) : launch_bwd<float>(a, st);
   if (r) return r;
   AVEC_LAUNCH_CHECK(); return 0;

@@ -84,11 +84,27 @@ extern "C" int avec_specaugment(float* mel, const long long* lens, int B, int n_
 // ---------------------------------------------------------------------------------------------
 struct StemA { int B, NM, F, C, Fo, To; };
 
+// add per-thread partials (a, b) of channel c to dst[c], dst[C + c]: LDS atomics inside the block (a 256-thread block spans <= 8 channels),
+// then one global atomic per channel per block
+__device__ __forceinline__ void block_channel_add2(float* dst, int C, int c, bool live, float a, float b) {
+  __shared__ float red[2][16]; __shared__ int cbase;
+  if (threadIdx.x == 0) cbase = c;
+  if (threadIdx.x < 32) red[threadIdx.x >> 4][threadIdx.x & 15] = 0.f;
+  __syncthreads();
+  const int k = c - cbase;
+  if (live && k >= 0 && k < 16) { atomicAdd(&red[0][k], a); atomicAdd(&red[1][k], b); }
+  else if (live) { atomicAdd(dst + c, a); atomicAdd(dst + C + c, b); }
+  __syncthreads();
+  if (threadIdx.x < 16 && cbase + (int)threadIdx.x < C && (red[0][threadIdx.x] != 0.f || red[1][threadIdx.x] != 0.f)) {
+    atomicAdd(dst + cbase + threadIdx.x, red[0][threadIdx.x]); atomicAdd(dst + C + cbase + threadIdx.x, red[1][threadIdx.x]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_conv_kernel(const float* __restrict__ mel, const float* __restrict__ w, const float* __restrict__ bias,
                                                               T* __restrict__ y, float* stats, StemA s) {
-  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
-  if (j >= J) return;
+  int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  const bool live = j < J; if (!live) j = J - 1;          // keep every thread for the block-level reduction
   const int c = j / s.Fo, fo = j % s.Fo;
   float wk[9]; for (int q = 0; q < 9; ++q) wk[q] = w[c * 9 + q];
   const float bb = bias ? bias[c] : 0.f;
@@ -100,9 +116,9 @@ __global__ __launch_bounds__(256) void audio_stem_conv_kernel(const float* __res
     for (int kh = 0; kh < 3; ++kh) { const int fi = 2 * fo + kh - 1; if (fi < 0 || fi >= s.NM) continue;
       for (int kw = 0; kw < 3; ++kw) { const int ti = 2 * to + kw - 1; if (ti < 0 || ti >= s.F) continue;
         acc += wk[kh * 3 + kw] * mel[(b * s.NM + fi) * s.F + ti]; } }
-    stf(y + row * J + j, acc); sum += acc; sq += acc * acc;
+    if (live) { stf(y + row * J + j, acc); sum += acc; sq += acc * acc; }
   }
-  if (stats) { atomicAdd(stats + c, sum); atomicAdd(stats + s.C + c, sq); }
+  if (stats) block_channel_add2(stats, s.C, c, live, sum, sq);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_act_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ a, long long M, int J, int Fo, int C) {
@@ -114,30 +130,30 @@ __global__ __launch_bounds__(256) void audio_stem_act_kernel(const T* __restrict
 // pass 1: dstats[c] += sum dr, dstats[C+c] += sum dr*yhat   with dr = da * swish'(pre)
 template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ ss, float* dstats, StemA s) {
-  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
-  if (j >= J) return;
+  int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  const bool live = j < J; if (!live) j = J - 1;
   const int c = j / s.Fo; const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c];
   float s1 = 0.f, s2 = 0.f; const long long M = (long long)s.B * s.To;
-  for (long long row = blockIdx.y; row < M; row += gridDim.y) {
+  if (live) for (long long row = blockIdx.y; row < M; row += gridDim.y) {
     const float yy = ldf(y + row * J + j); const float dr = ldf(da + row * J + j) * dswishf_(yy * sc + sh);
     s1 += dr; s2 += dr * (yy - mu) * rs;
   }
-  atomicAdd(dstats + c, s1); atomicAdd(dstats + s.C + c, s2);
+  block_channel_add2(dstats, s.C, c, live, s1, s2);
 }
 // pass 2: dy = gamma*rstd*(dr - s1/n - yhat*s2/n);  dw[c][kh][kw] += sum dy*mel(patch);  dbias[c] += sum dy; block row 0 adds dgamma/dbeta
 template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_bwd_params_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ mel, const float* __restrict__ ss,
                                                                     const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
                                                                     float* dw, float* dbias, float* dgamma, float* dbeta, StemA s) {
-  const int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
-  if (j >= J) return;
+  int j = blockIdx.x * 256 + threadIdx.x; const int J = s.C * s.Fo;
+  const bool live = j < J; if (!live) j = J - 1;
   const int c = j / s.Fo, fo = j % s.Fo; const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
   const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c], g = gamma[c];
   const float m1 = dstats[c] * inv_n, m2 = dstats[s.C + c] * inv_n;
-  if (blockIdx.y == 0 && fo == 0 && dgamma) { atomicAdd(dgamma + c, dstats[s.C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  if (live && blockIdx.y == 0 && fo == 0 && dgamma) { atomicAdd(dgamma + c, dstats[s.C + c]); atomicAdd(dbeta + c, dstats[c]); }
   float aw[9]; for (int q = 0; q < 9; ++q) aw[q] = 0.f; float ab = 0.f;
   const long long M = (long long)s.B * s.To;
-  for (long long row = blockIdx.y; row < M; row += gridDim.y) {
+  if (live) for (long long row = blockIdx.y; row < M; row += gridDim.y) {
     const int to = (int)(row % s.To); const long long b = row / s.To;
     const float yy = ldf(y + row * J + j); const float dr = ldf(da + row * J + j) * dswishf_(yy * sc + sh);
     const float dy = g * rs * (dr - m1 - (yy - mu) * rs * m2);
@@ -146,8 +162,19 @@ __global__ __launch_bounds__(256) void audio_stem_bwd_params_kernel(const T* __r
       for (int kw = 0; kw < 3; ++kw) { const int ti = 2 * to + kw - 1; if (ti < 0 || ti >= s.F) continue;
         aw[kh * 3 + kw] += dy * mel[(b * s.NM + fi) * s.F + ti]; } }
   }
-  for (int q = 0; q < 9; ++q) atomicAdd(dw + c * 9 + q, aw[q]);
-  if (dbias) atomicAdd(dbias + c, ab);
+  // block-level reduction: dw is [C][9] = per-channel groups of 9 -> reuse the 2-vector helper on (tap q, tap q+1) pairs via a flat [C*9] view
+  __shared__ float wred[16][10]; __shared__ int wbase;
+  if (threadIdx.x == 0) wbase = c;
+  if (threadIdx.x < 160) wred[threadIdx.x / 10][threadIdx.x % 10] = 0.f;
+  __syncthreads();
+  const int kq = c - wbase;
+  if (live && kq >= 0 && kq < 16) { for (int q = 0; q < 9; ++q) atomicAdd(&wred[kq][q], aw[q]); atomicAdd(&wred[kq][9], ab); }
+  else if (live) { for (int q = 0; q < 9; ++q) atomicAdd(dw + c * 9 + q, aw[q]); if (dbias) atomicAdd(dbias + c, ab); }
+  __syncthreads();
+  if (threadIdx.x < 160) {
+    const int cc = wbase + threadIdx.x / 10, q = threadIdx.x % 10; const float v = wred[threadIdx.x / 10][q];
+    if (cc < s.C && v != 0.f) { if (q < 9) atomicAdd(dw + cc * 9 + q, v); else if (dbias) atomicAdd(dbias + cc, v); }
+  }
 }
 static StemA stemA(int B, int NM, int F, int C) { StemA s; s.B = B; s.NM = NM; s.F = F; s.C = C; s.Fo = (NM - 1) / 2 + 1; s.To = (F - 1) / 2 + 1; return s; }
 static dim3 stem_grid(const StemA& s) { long long M = (long long)s.B * s.To; unsigned gx = (s.C * s.Fo + 255) / 256; long long gy = 2048 / gx; if (gy > M) gy = M; if (gy < 1) gy = 1; return dim3(gx, (unsigned)gy); }

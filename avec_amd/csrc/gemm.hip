@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // TN: O[i][j] += sum_m P[m][i] * Q[m][j];   P plain [M][I] (T), Q via row loader ([M][J], plain or im2col)
 // LDS images are [i][m] / [j][m] (reduction index contiguous) filled by transposing stores.
 // ------------------------------------------------------------------------------------------------
-struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Jq; int m_per_block; };   // Jq: load bound of Q (>= J when its rows are padded)
+struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block;   // Iq/Jq: load bounds (>= I/J when rows are padded)
+                int split, nb_inner; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
 
 // LDS image of a TN operand: [col][word], word = reduction-row pair (bf16: rows 2p,2p+1 packed in 32 bits) or row (fp32), 32 words
 // per 144-byte row.  Word index XOR-swizzled by 16 * parity(col bits 2..4): with lanes mapped (16 pairs x 4 column chunks) both the
@@ -388,7 +389,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-  const long long mb = (long long)blockIdx.z * g.m_per_block;
+  const int zb = blockIdx.z / g.split, zs = blockIdx.z - zb * g.split;
+  const long long bo = zb / g.nb_inner, bi = zb - bo * g.nb_inner;
+  g.P = (const T*)g.P + bo * g.sPo + bi * g.sPi;
+  g.q.ptr = (Q_F32 && sizeof(T) == 2) ? (const void*)((const float*)g.q.ptr + bo * g.sQo + bi * g.sQi) : (const void*)((const T*)g.q.ptr + bo * g.sQo + bi * g.sQi);
+  g.O += bo * g.sOo + bi * g.sOi;
+  const long long mb = (long long)zs * g.m_per_block;
   long long me = mb + g.m_per_block; if (me > g.M) me = g.M;
 
   f32x16 acc[MT][NT];
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     for (int u = 0; u < NTI; ++u) {
       const int col = i0 + task_c(u) * VEC;
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) { const long long m = mt0 + task_p(u) * RPT + r; pp[u][r] = issue_load<T, false, A16>(g.P, m < me ? m * g.ldp + col : -1, col, g.I); }
+      for (int r = 0; r < RPT; ++r) { const long long m = mt0 + task_p(u) * RPT + r; pp[u][r] = issue_load<T, false, A16>(g.P, m < me ? m * g.ldp + col : -1, col, g.Iq); }
     }
 #pragma unroll
     for (int u = 0; u < NTJ; ++u) {
@@ -551,19 +557,20 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
 }
 
 template <typename T, int BI, int BJ>
-static int launch_tn_tile(TnArgs g, int mode, int q_f32, hipStream_t st) {
+static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t st) {
   constexpr int KE = BKB / (int)sizeof(T);
-  int tiles = ((g.I + BI - 1) / BI) * ((g.J + BJ - 1) / BJ);
+  int tiles = ((g.I + BI - 1) / BI) * ((g.J + BJ - 1) / BJ) * nbatch;
   long long ksteps = (g.M + KE - 1) / KE;
-  long long split = (1024 + tiles - 1) / tiles; if (split > ksteps) split = ksteps; if (split < 1) split = 1;
+  // split the reduction so that ~512 workgroups exist, but keep >= 4 K-steps per workgroup: every split costs BI*BJ fp32 atomics
+  long long split = (512 + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1) split = 1;
   long long per = ((ksteps + split - 1) / split) * KE;
   split = (g.M + per - 1) / per;
-  g.m_per_block = (int)per;
-  dim3 grid((g.I + BI - 1) / BI, (g.J + BJ - 1) / BJ, (unsigned)split);
+  g.m_per_block = (int)per; g.split = (int)split;
+  dim3 grid((g.I + BI - 1) / BI, (g.J + BJ - 1) / BJ, (unsigned)(split * nbatch));
   size_t lds = (size_t)2 * (BI + BJ) * LDS_ROW;
   constexpr int VEC = Elt<T>::VEC;
   const bool f32src = q_f32 && sizeof(T) == 2;
-  const bool a16 = aligned16(g.P) && aligned16(g.q.ptr) && g.I % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
+  const bool a16 = nbatch == 1 && aligned16(g.P) && aligned16(g.q.ptr) && g.Iq % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
@@ -574,25 +581,43 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, hipStream_t st) {
   return 0;
 }
 
-extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
-                            float* O, long long ldo, long long M, int I, int J, hipStream_t stream) {
+static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
+                        float* O, long long ldo, long long M, int I, int J, int nb_outer, int nb_inner, const long long* strides, hipStream_t stream) {
   AVEC_CHECK_ARG(dtype == AVEC_F32 || dtype == AVEC_BF16, "gemm_tn: bad dtype %d", dtype);
   AVEC_CHECK_ARG(P && Q && O && q_rows, "gemm_tn: null pointer");
-  AVEC_CHECK_ARG(M > 0 && I > 0 && J > 0, "gemm_tn: bad dims");
+  AVEC_CHECK_ARG(M > 0 && I > 0 && J > 0 && nb_outer > 0 && nb_inner > 0, "gemm_tn: bad dims");
   AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_mode == MODE_CONV_FWD, "gemm_tn: bad q_mode %d", q_mode);
   const int vec = dtype == AVEC_BF16 ? 8 : 4;
-  // Q rows padded to a multiple of the vector width (e.g. the stem im2col matrix, J=245 in rows of 248): load the padding, bound the output by J
+  // rows padded to a multiple of the vector width (stem im2col matrix J=245 in rows of 248; attention P/dS): load the padding, bound the output by I / J
   const int Jq = (q_mode == MODE_PLAIN && q_rows->ld >= (J + vec - 1) / vec * vec) ? (J + vec - 1) / vec * vec : J;
-  AVEC_CHECK_ARG(I >= vec && J >= vec && (dtype == AVEC_F32 || (I % 2 == 0 && Jq % 2 == 0 && ldp % 2 == 0)), "gemm_tn: I=%d, J=%d: need >= %d and (bf16) even I, J, ldp", I, J, vec);
+  const int Iq = (ldp >= (I + vec - 1) / vec * vec) ? (I + vec - 1) / vec * vec : I;
+  AVEC_CHECK_ARG(Iq >= vec && Jq >= vec && (dtype == AVEC_F32 || (Iq % 2 == 0 && Jq % 2 == 0 && ldp % 2 == 0)), "gemm_tn: I=%d, J=%d: need >= %d and (bf16) even I, J, ldp", I, J, vec);
   AVEC_CHECK_ARG(q_mode != MODE_PLAIN || dtype == AVEC_F32 || q_rows->ld % 2 == 0, "gemm_tn: ldq must be even");
-  AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
   AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_rows->C % vec == 0, "gemm_tn: conv C=%d must be a multiple of %d", q_rows->C, vec);
-  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Jq = Jq; g.m_per_block = 0;
-  bool big = (I >= 128 && J >= 128);
+  AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
+  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0;
+  g.split = 1; g.nb_inner = nb_inner;
+  g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
+  g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
+  if (dtype == AVEC_BF16 && strides) for (int i = 0; i < 4; ++i) AVEC_CHECK_ARG(strides[i] % 2 == 0, "gemm_tn: bf16 batch strides must be even");
+  const int nbatch = nb_outer * nb_inner;
+  bool big = (I >= 128 && J >= 128) && ((long long)((I + 127) / 128) * ((J + 127) / 128) * nbatch >= 48);   // few output tiles: 64x64 tiles fill the chip with less atomic traffic
   int r;
-  if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, stream) : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, stream);
-  else r = big ? launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, stream) : launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, stream);
+  if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, nbatch, stream);
+  else r = big ? launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, nbatch, stream);
   if (r) return r;
   AVEC_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
+                            float* O, long long ldo, long long M, int I, int J, hipStream_t stream) {
+  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, stream);
+}
+
+extern "C" int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
+                                    int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream) {
+  avec_rows_t rows = {}; rows.ld = ldq;
+  AVEC_CHECK_ARG(strides6, "gemm_tn_batched: null strides");
+  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, O, ldo, M, I, J, nb_outer, nb_inner, strides6, stream);
 }

@@ -407,9 +407,25 @@ class AttentionModuleFn(torch.autograd.Function):
         a.dq, a.lddq = dqkv.data_ptr(), 3 * D
         a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
         a.de, a.ldde = de.data_ptr(), D
-        scratch = empty((2, B * H, Tp, Tp), torch.float32, dy)       # P and dS of every (batch, head)
-        a.pbuf, a.dsbuf = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * 4
+        Tld, Rld = (Tp + 7) // 8 * 8, (2 * Tp - 1 + 7) // 8 * 8
+        scratch = empty((2, B * H, Tp, Tld), adt, dy)                # P and dS of every (batch, head), row stride padded to 8
+        a.pbuf, a.dsbuf, a.ldt = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * esz, Tld
+        use_mfma = d % 2 == 0                                        # head column offsets must stay dword aligned in bf16 (d = 45 heads take the VALU column pass)
+        if use_mfma:
+            dsrel = torch.zeros((H, B * Tp, Rld), dtype=adt, device=dy.device)
+            a.dsrel, a.ldr = dsrel.data_ptr(), Rld
         lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())
+        if use_mfma:
+            # dK = dS^T Q and dV = P^T dO per (batch, head); dE_h = sum_b skew(dS)^T Q : batched TN MFMA GEMMs, fp32 accumulation
+            dkv32 = torch.zeros((Mp, 2 * D), dtype=torch.float32, device=dy.device)
+            L6 = ctypes.c_longlong * 6
+            lib.gemm_tn_batched(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dkv32.data_ptr(), 2 * D, Tp, Tp, d, B, H,
+                                L6(H * Tp * Tld, Tp * Tld, Tp * 3 * D, d, Tp * 2 * D, d), rt.stream())
+            lib.gemm_tn_batched(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dkv32.data_ptr() + D * 4, 2 * D, Tp, Tp, d, B, H,
+                                L6(H * Tp * Tld, Tp * Tld, Tp * D, d, Tp * 2 * D, d), rt.stream())
+            lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * Tp, 2 * Tp - 1, d, 1, H,
+                                L6(0, B * Tp * Rld, 0, d, 0, d), rt.stream())
+            lib.cast_rows(rt.dt(), dkv32.data_ptr(), 2 * D, dqkv.data_ptr() + D * esz, 3 * D, Mp, 2 * D, rt.stream())
         dhp = None
         for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
             g = dqkv[:, i * D:]
@@ -464,8 +480,7 @@ def bn_finalize(bn, st, count, training):
     sptr, nrep = st.stats.data_ptr(), st.NREP
     if training and rt.sync_batchnorm():
         # SyncBatchNorm: collapse the replicas, append the local count, sum over ranks (one small RCCL all-reduce)
-        st.red = torch.cat([st.stats.view(st.NREP, 2 * C).sum(0), torch.full((1,), float(count), device=st.stats.device)])
-        _sync_stats(st.red)
+        st.red = rt.sync_bn_stats(st.stats, st.NREP, C, count)
         sptr, nrep, cptr = st.red.data_ptr(), 1, st.red.data_ptr() + 2 * C * 4
     mom = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats and bn.running_mean is not None

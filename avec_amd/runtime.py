@@ -219,11 +219,24 @@ class ParamArena:
     def all_reduce_grads(self, bucket_bytes=64 << 20):
         """DDP gradient averaging: sum over ranks in large contiguous buckets (RCCL over xGMI); the 1/world factor is
         folded into the Adam kernel's grad_scale."""
-        import torch.distributed as dist
-        n = self.numel
-        step = max(bucket_bytes // 4, 1)
-        works = []
-        for s in range(0, n, step):
-            works.append(dist.all_reduce(self.grad[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
+        all_reduce_flat(self.grad, bucket_bytes)
+
+
+def all_reduce_flat(flat, bucket_bytes=64 << 20):
+    """Sum a flat buffer over all ranks in contiguous slices of `bucket_bytes` (asynchronous, then waited in order)."""
+    import torch.distributed as dist
+    n = flat.numel()
+    step = max(bucket_bytes // flat.element_size(), 1)
+    works = [dist.all_reduce(flat[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=True) for s in range(0, n, step)]
+    for w in works:
+        w.wait()
+    return flat
+
+
+def sync_bn_stats(stats, nrep, C, count):
+    """SyncBatchNorm statistic exchange: collapse the `nrep` replicated [sum | sumsq] partials, append the local element count and sum
+    the (2C+1)-vector over ranks.  Returns the reduced vector (global sum, global sumsq, global count)."""
+    import torch.distributed as dist
+    red = torch.cat([stats.view(nrep, 2 * C).sum(0), torch.full((1,), float(count), dtype=stats.dtype, device=stats.device)])
+    dist.all_reduce(red, op=dist.ReduceOp.SUM)
+    return red

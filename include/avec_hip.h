@@ -72,6 +72,10 @@ int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows, int a_mode
  * Linear backward and convolution_backward(weight). */
 int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
                  float* O, long long ldo, long long M, int I, int J, hipStream_t stream);
+/* batched form: batch = outer * nb_inner + inner; strides6 = element strides {P_outer, P_inner, Q_outer, Q_inner, O_outer, O_inner}.
+ * Used for the attention backward bmm's (dK = dS^T Q, dV = P^T dO per (batch, head); dE_h = sum_b skew(dS)^T Q), nnet/attentions.py:300-315. */
+int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
+                         int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 
 /* ---- normalisation / elementwise (avec_amd/csrc/norm.hip) ---------------------------------- */
 /* nn.LayerNorm(eps=1e-6) forward/backward: aten::native_layer_norm(_backward) emitted by nnet/modules.py:278,302,373
@@ -129,7 +133,8 @@ typedef struct avec_attn {
   const void* dout;                           /* backward input, act [B*T][ldo] */
   void *dq, *dk, *dv; long long lddq, ldd;    /* act gradients: dq (row stride lddq), dk / dv (row stride ldd) */
   float* de; long long ldde;                  /* fp32 [2T-1][ldde], accumulated */
-  float *pbuf, *dsbuf;                        /* backward scratch, fp32 [B*H][T][T] each (probabilities, dS) */
+  void *pbuf, *dsbuf; long long ldt;          /* backward scratch, act [B*H][T][ldt] each (probabilities, dS) */
+  void* dsrel; long long ldr;                 /* optional act [H][B*T][ldr] (zero-filled): dS indexed by E row; when given, dK/dV/dE are left to avec_gemm_tn_batched */
   int B, H, T, d; float scale;
 } avec_attn_t;
 /* RelPos1dMultiHeadAttention.forwardQKV core (nnet/attentions.py:299-315): bmm + rel_to_abs + mask + softmax + bmm */
