@@ -601,7 +601,9 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
   if (dtype == AVEC_BF16 && strides) for (int i = 0; i < 4; ++i) AVEC_CHECK_ARG(strides[i] % 2 == 0, "gemm_tn: bf16 batch strides must be even");
   const int nbatch = nb_outer * nb_inner;
-  bool big = (I >= 128 && J >= 128) && ((long long)((I + 127) / 128) * ((J + 127) / 128) * nbatch >= 48);   // few output tiles: 64x64 tiles fill the chip with less atomic traffic
+  // few output tiles AND a short reduction (conformer weight gradients): 64x64 tiles fill the chip with less atomic traffic; long reductions
+  // (conv weight gradients, M ~ 1e5..1e6) amortise the atomics and prefer the more efficient 128x128 tile
+  bool big = (I >= 128 && J >= 128) && ((long long)((I + 127) / 128) * ((J + 127) / 128) * nbatch >= 48 || M >= 32768);
   int r;
   if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, nbatch, stream);
   else r = big ? launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, nbatch, stream);

@@ -166,6 +166,48 @@ class Model(Module):
         self.add_info("step", int(self.model_step))
         return batch_losses, batch_metrics, 0
 
+    def make_graphed_train_step(self, inputs, targets, precision=torch.bfloat16, warmup=2):
+        """Capture ONE optimisation step (shadow refresh, forward, 6 losses, backward, Adam) into a hipGraph: ~2500 launches replay from a
+        single submission, removing the host-side launch overhead.  Static shapes: later batches are copied into the captured buffers.
+        Single-process only (collectives are kept out of captures); returns step(inputs, targets) -> losses dict (device scalars)."""
+        assert not self.is_distributed, "graph capture is used for single-GPU steps; multi-GPU steps run eagerly"
+        rt.set_compute_dtype(precision)
+        static_in = [t.clone() for t in inputs]
+        static_tg = tuple(t.clone() for t in targets)
+
+        def body():
+            losses, _, _, _ = self.forward_model(static_in, static_tg, compute_metrics=False)
+            losses["loss"].backward()
+            rt.advance_rng(self.device)
+            self.optimizer.launch_step()
+            return losses
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):             # warm-up on a side stream: lazy kernel attributes, caches, allocator
+                self.optimizer.prepare_step()
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.prepare_step()
+        with torch.cuda.graph(graph):
+            static_losses = body()
+
+        def step(new_inputs=None, new_targets=None):
+            if new_inputs is not None:
+                for d, s_ in zip(static_in, new_inputs):
+                    d.copy_(s_, non_blocking=True)
+                for d, s_ in zip(static_tg, new_targets):
+                    d.copy_(s_, non_blocking=True)
+            self.optimizer.prepare_step()
+            graph.replay()
+            return static_losses
+
+        step.graph = graph
+        return step
+
     def eval_step(self, inputs, targets, verbose=0):
         with torch.no_grad():
             return self.forward_model(inputs, targets, verbose=verbose)

@@ -33,24 +33,39 @@ class Adam(optim.Adam):
             st["exp_avg"] = self._flat["exp_avg"][o:o + n].as_strided(p.shape, p.stride())
             st["exp_avg_sq"] = self._flat["exp_avg_sq"][o:o + n].as_strided(p.shape, p.stride())
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def prepare_step(self):
+        """host half of step(): advance the scheduler, publish {step, lr} to the device scalar pair the kernel reads"""
         lr = self.scheduler.step()
         for group in self.param_groups:
             group["lr"] = lr
         if self.arena is None:
             raise RuntimeError("nnet.Adam steps a model's flat parameter arena on the GPU: move the model with Model.to('cuda') first "
                                "(there is no per-tensor / CPU optimizer path)")
+        if "host_state" not in self._flat:
+            self._flat["host_state"] = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._flat["host_state"][0] = float(self.scheduler.model_step)
+        self._flat["host_state"][1] = float(lr)
+        self._flat["state"].copy_(self._flat["host_state"], non_blocking=True)
+
+    def launch_step(self):
+        """device half: ONE kernel over the flat arenas (graph-capturable)"""
         g = self.param_groups[0]
-        step = float(self.scheduler.model_step)
-        self._flat["state"].copy_(torch.tensor([step, float(lr)], dtype=torch.float32), non_blocking=True)
-        lib.adam_step(self.arena.master.data_ptr(), self.arena.grad.data_ptr(), self._flat["exp_avg"].data_ptr(), self._flat["exp_avg_sq"].data_ptr(),
-                      self._flat["state"].data_ptr(), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale, 1,
-                      self.arena.numel, rt.stream())
+        self._launch(g)
         self.arena.mark_dirty()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.prepare_step()
+        self.launch_step()
+        step = float(self.scheduler.model_step)
         for p in self.arena.params:
             self.state[p]["step"] = torch.tensor(step)
         return None
+
+    def _launch(self, g):
+        lib.adam_step(self.arena.master.data_ptr(), self.arena.grad.data_ptr(), self._flat["exp_avg"].data_ptr(), self._flat["exp_avg_sq"].data_ptr(),
+                      self._flat["state"].data_ptr(), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale, 1,
+                      self.arena.numel, rt.stream())
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:
