@@ -164,73 +164,9 @@ __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wm,
   }
 }
 
-template <typename T, int BM, int BN, int MODE, bool SRC_F32, bool A16>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-  constexpr int VEC = Elt<T>::VEC;
-  constexpr int KE = BKB / (int)sizeof(T);   // K elements per tile
-  constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
-  constexpr int MT = BM / 64, NT = BN / 64;
-  constexpr int TILE = (BM + BN) * LDS_ROW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
-  const int kc = (tid & 7) * VEC;            // this thread's K offset inside a tile
-  const int r0 = tid >> 3;                   // first tile row handled by this thread (+32 per extra chunk)
-
-  RowInfo ra[NCA]; RowInfo rb[NCB];
-  RowSrc ws; ws.ptr = g.W; ws.ld = g.ldw; ws.step = 0; ws.rows_out = ws.rows_in = 1;
-#pragma unroll
-  for (int i = 0; i < NCA; ++i) ra[i] = row_info<MODE>(g.a, m0 + r0 + i * 32, g.M);
-#pragma unroll
-  for (int i = 0; i < NCB; ++i) rb[i] = row_info<MODE_PLAIN>(ws, n0 + r0 + i * 32, g.N);
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  Pend pa[NCA], pb[NCB];
-  const int KT = (g.K + KE - 1) / KE;
-  auto issue = [&](int kt) {
-    const int k = kt * KE + kc;
-    if (MODE == MODE_PLAIN) {
-#pragma unroll
-      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, SRC_F32, A16>(g.a.ptr, ra[i].valid ? ra[i].base + k : -1, k, g.K);
-    } else {
-      int tap, c;
-      if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + kc; }   // whole K-step inside one tap: wave-uniform
-      else { tap = k / g.a.C; c = k - tap * g.a.C; }
-      const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
-#pragma unroll
-      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, false, A16>(g.a.ptr, conv_offset<MODE == MODE_PLAIN ? MODE_CONV_FWD : MODE>(g.a, ra[i], kh, kw, c), k, g.K);
-    }
-#pragma unroll
-    for (int i = 0; i < NCB; ++i) pb[i] = issue_load<T, false, A16>(g.W, rb[i].valid ? rb[i].base + k : -1, k, g.K);
-  };
-  auto stage = [&](int buf) {
-    char* As = smem + buf * TILE; char* Bs = As + BM * LDS_ROW;
-#pragma unroll
-    for (int i = 0; i < NCA; ++i) *(chunk16*)(As + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, SRC_F32 && MODE == MODE_PLAIN>(pa[i]);
-#pragma unroll
-    for (int i = 0; i < NCB; ++i) *(chunk16*)(Bs + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, false>(pb[i]);
-  };
-
-  const int frag_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
-  issue(0);
-  stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) issue(kt + 1);                                        // loads in flight during the MFMAs below
-    mma_tile<T, BM, BN, MT, NT>(smem + cur * TILE, smem + cur * TILE + BM * LDS_ROW, wm, wn, frag_off, acc);
-    if (kt + 1 < KT) stage(cur ^ 1);                                       // other buffer: last read two barriers ago
-    __syncthreads();
-  }
-
+// ---- shared epilogue of the NT kernels ----
+template <typename T, int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, long long m0, int n0, int tid, int lane, int wm, int wn) {
   // ---- epilogue: accumulators -> LDS (64-row passes) -> coalesced 4-wide rows with fused bias/act/dropout/residual/stats ----
   const Epi& e = g.e;
   constexpr int CLD = BN + 4;                 // fp32 row stride of the staged C tile
@@ -311,12 +247,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   if (e.colsum || e.stats) {
     // workgroup-level reduction in LDS (the staged C tile is dead now), then ONE atomic per column per workgroup;
     // BatchNorm statistics additionally spread over AVEC_STAT_REPLICAS copies to cut same-address contention.
-    float* red = (float*)smem;                 // [2][BN]
-    for (int c = tid; c < 2 * BN; c += 256) red[c] = 0.f;
-    __syncthreads();
+    float* red = (float*)smem;                 // [4 waves][2][BN]: shuffle-reduce inside each wave, plain stores, no LDS atomics
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { atomicAdd(red + cg + c, csum[c]); atomicAdd(red + BN + cg + c, csq[c]); }
+    for (int c = 0; c < 4; ++c)
+      for (int o = TPR; o < 64; o <<= 1) { csum[c] += __shfl_xor(csum[c], o, 64); csq[c] += __shfl_xor(csq[c], o, 64); }
+    const int wv = tid >> 6;
+    if (lane < TPR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { red[(wv * 2 + 0) * BN + cg + c] = csum[c]; red[(wv * 2 + 1) * BN + cg + c] = csq[c]; }
+    }
     __syncthreads();
+    if (tid < 2 * BN) { float t = 0.f; for (int w = 0; w < 4; ++w) t += red[(w * 2) * BN + tid]; red[8 * BN + tid] = t; }   // [sum | sq] totals behind the partials
+    __syncthreads();
+    red += 8 * BN;
     if (tid < BN && n0 + tid < g.N) {
       if (e.colsum) atomicAdd(e.colsum + n0 + tid, red[tid]);
       if (e.stats) {
@@ -325,6 +268,172 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+template <typename T, int BM, int BN, int MODE, bool SRC_F32, bool A16>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+  constexpr int VEC = Elt<T>::VEC;
+  constexpr int KE = BKB / (int)sizeof(T);   // K elements per tile
+  constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int TILE = (BM + BN) * LDS_ROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  const int kc = (tid & 7) * VEC;            // this thread's K offset inside a tile
+  const int r0 = tid >> 3;                   // first tile row handled by this thread (+32 per extra chunk)
+
+  RowInfo ra[NCA]; RowInfo rb[NCB];
+  RowSrc ws; ws.ptr = g.W; ws.ld = g.ldw; ws.step = 0; ws.rows_out = ws.rows_in = 1;
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) ra[i] = row_info<MODE>(g.a, m0 + r0 + i * 32, g.M);
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) rb[i] = row_info<MODE_PLAIN>(ws, n0 + r0 + i * 32, g.N);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Pend pa[NCA], pb[NCB];
+  const int KT = (g.K + KE - 1) / KE;
+  auto issue = [&](int kt) {
+    const int k = kt * KE + kc;
+    if (MODE == MODE_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, SRC_F32, A16>(g.a.ptr, ra[i].valid ? ra[i].base + k : -1, k, g.K);
+    } else {
+      int tap, c;
+      if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + kc; }   // whole K-step inside one tap: wave-uniform
+      else { tap = k / g.a.C; c = k - tap * g.a.C; }
+      const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) pa[i] = issue_load<T, false, A16>(g.a.ptr, conv_offset<MODE == MODE_PLAIN ? MODE_CONV_FWD : MODE>(g.a, ra[i], kh, kw, c), k, g.K);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) pb[i] = issue_load<T, false, A16>(g.W, rb[i].valid ? rb[i].base + k : -1, k, g.K);
+  };
+  auto stage = [&](int buf) {
+    char* As = smem + buf * TILE; char* Bs = As + BM * LDS_ROW;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) *(chunk16*)(As + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, SRC_F32 && MODE == MODE_PLAIN>(pa[i]);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) *(chunk16*)(Bs + (r0 + i * 32) * LDS_ROW + (tid & 7) * 16) = finish_load<T, false>(pb[i]);
+  };
+
+  const int frag_off = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+  issue(0);
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1);                                        // loads in flight during the MFMAs below
+    mma_tile<T, BM, BN, MT, NT>(smem + cur * TILE, smem + cur * TILE + BM * LDS_ROW, wm, wn, frag_off, acc);
+    if (kt + 1 < KT) stage(cur ^ 1);                                       // other buffer: last read two barriers ago
+    __syncthreads();
+  }
+
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, LDS-DMA variant (global_load_lds, 16 B per lane): the tile goes HBM/L2 -> LDS without a VGPR round trip, without
+// ds_write and without per-chunk finishing VALU.  The DMA writes lane-linearly (wave-uniform base + lane*16), so LDS rows are
+// unpadded 128-byte rows and bank conflicts are removed by an XOR swizzle applied on the SOURCE side: the lane that fills physical
+// 16-byte slot p of tile row r fetches logical K-chunk p ^ ((r >> 1) & 7); the MFMA fragment reads apply the same involution
+// (conflict-free for ds_read_b128's 16-lane groups).  Invalid rows / taps / K-tails fetch 16 zero bytes from `avec_zero16`.
+// Requires every chunk address 16-byte aligned and K % VEC == 0 (host-checked: the A16 case).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned char avec_zero16[64];
+
+template <typename T, int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
+  constexpr int VEC = Elt<T>::VEC;
+  constexpr int KE = BKB / (int)sizeof(T);
+  constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int TILE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  // chunk c = tid + i*256 of a tile -> row c>>3, physical slot c&7; it carries logical K-chunk (c&7) ^ ((row>>1)&7)
+  RowInfo ra[NCA]; RowInfo rb[NCB]; int ka[NCA], kb[NCB];
+  RowSrc ws; ws.ptr = g.W; ws.ld = g.ldw; ws.step = 0; ws.rows_out = ws.rows_in = 1;
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) { const int row = (tid >> 3) + i * 32; ra[i] = row_info<MODE>(g.a, m0 + row, g.M); ka[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) { const int row = (tid >> 3) + i * 32; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int KT = (g.K + KE - 1) / KE;
+  auto issue = [&](int kt, int buf) {
+    char* As = smem + buf * TILE; char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int k = kt * KE + ka[i];
+      long long off;
+      if (MODE == MODE_PLAIN) off = (ra[i].valid && k < g.K) ? ra[i].base + k : -1;
+      else {
+        int tap, c;
+        if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + ka[i]; } else { tap = k / g.a.C; c = k - tap * g.a.C; }
+        const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
+        off = (k < g.K) ? conv_offset<MODE == MODE_PLAIN ? MODE_CONV_FWD : MODE>(g.a, ra[i], kh, kw, c) : -1;
+      }
+      const void* src = off >= 0 ? (const void*)((const T*)g.a.ptr + off) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int k = kt * KE + kb[i];
+      const void* src = (rb[i].valid && k < g.K) ? (const void*)((const T*)g.W + rb[i].base + k) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  // fragment addressing: lane (row = lane&31 within a 32-row block, k-half g = lane>>5), K-substep kk: logical chunk 2*kk + g
+  int offa[MT], swa[MT], offb[NT], swb[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / 2) + i * 32 + (lane & 31); offa[i] = row * 128; swa[i] = (row >> 1) & 7; }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * 128; swb[j] = (row >> 1) & 7; }
+  const int gsel = lane >> 5;
+
+  issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0) (expcnt/lgkmcnt untouched): the DMA of this wave has landed
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
+    const char* As = smem + cur * TILE; const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      chunk16 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + offa[i] + (((kk * 2 + gsel) ^ swa[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + offb[j] + (((kk * 2 + gsel) ^ swb[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+  }
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 // host launchers (C ABI)
 // ------------------------------------------------------------------------------------------------
 #include <stdint.h>
+#include <stdlib.h>
 static RowSrc make_src(const void* ptr, const avec_rows_t* d) {
   RowSrc s; s.ptr = ptr; s.ld = d->ld; s.rows_out = d->rows_out; s.rows_in = d->rows_in; s.step = d->step;
   s.H = d->H; s.W = d->W; s.C = d->C; s.KH = d->KH; s.KW = d->KW; s.stride = d->stride; s.pad = d->pad; s.OH = d->OH; s.OW = d->OW;
@@ -511,6 +621,11 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   // every chunk address 16-byte aligned?  (then each chunk is one global_load_dwordx4 instead of two dwordx2)
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
+#define G(MODE) do { const size_t l2 = (size_t)2 * (BM + BN) * 128 > (size_t)64 * (BN + 4) * 4 ? (size_t)2 * (BM + BN) * 128 : (size_t)64 * (BN + 4) * 4; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
+  if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
+#undef G
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
