@@ -65,18 +65,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU multi-process debugging)")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend, init_method="env://")
 
     import avec_amd
     import nnet
@@ -113,12 +120,13 @@ def main():
         last = run_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if rank == 0 and not args.no_kernel_timing:
-        # roofline leg: the same step, eagerly, with HIP events around every GEMM-family launch (events cannot be recorded inside a graph)
-        ops.KERNEL_TIMER.reset(enabled=True)
+    if not args.no_kernel_timing:
+        # roofline leg: the same step, eagerly, with HIP events around every GEMM-family launch (events cannot be recorded inside a graph).
+        # Every rank runs it (the step contains collectives); only rank 0 records events.
+        ops.KERNEL_TIMER.reset(enabled=(rank == 0))
         for _ in range(min(args.steps, 3)):
             model.train_step(inputs, targets, precision=precision)
-        torch.cuda.synchronize()
+        barrier()
         ops.KERNEL_TIMER.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
