@@ -495,12 +495,25 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
     adt = rt.act_dtype()
     dstats = torch.zeros(2 * C, dtype=torch.float32, device=dout.device)
     lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
-    _sync_stats(dstats)
+    gw, gb = grad_of(bn.weight), grad_of(bn.bias)
+    if _add_local_affine_grads(dstats, gw, gb, C):
+        gw = gb = None                    # (SyncBatchNorm) already added from the LOCAL sums; the kernel must not add the global ones
     dy = empty((M, C), adt, dout)
     dres = empty((M, C), adt, dout) if want_dres else None
     lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count), act,
-                     dy.data_ptr(), _p(dres), grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), M, C, rt.stream())
+                     dy.data_ptr(), _p(dres), _p(gw), _p(gb), M, C, rt.stream())
     return dy, dres
+
+
+def _add_local_affine_grads(dstats, gw, gb, C):
+    """SyncBatchNorm: d(gamma), d(beta) are the LOCAL sums (the gradient all-reduce averages them like any other parameter, as torch's
+    SyncBatchNorm does); only the statistics entering dx are global.  Adds the local sums, then all-reduces `dstats`.  Returns True if it did."""
+    if not rt.sync_batchnorm():
+        return False
+    gw.add_(dstats[C:2 * C].view_as(gw))
+    gb.add_(dstats[:C].view_as(gb))
+    _sync_stats(dstats)
+    return True
 
 
 class ConvModuleFn(torch.autograd.Function):
@@ -810,9 +823,11 @@ class VideoStemFn(torch.autograd.Function):
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
         args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
         lib.stem_pool_bwd(rt.dt(), *args, 0, None, None, None, B * T, OH, OW, C, rt.stream())
-        _sync_stats(dstats)
+        gw, gb = grad_of(bn.weight), grad_of(bn.bias)
+        if _add_local_affine_grads(dstats, gw, gb, C):
+            gw = gb = None
         dy = empty((M, C), rt.act_dtype(), v)
-        lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B * T, OH, OW, C, rt.stream())
+        lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), _p(gw), _p(gb), B * T, OH, OW, C, rt.stream())
         gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]))
         if conv.bias is not None:
             grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
@@ -870,9 +885,11 @@ class AudioStemFn(torch.autograd.Function):
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=mel.device)
         base = (da.data_ptr(), y.data_ptr(), mel.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(count))
         lib.audio_stem_bwd(rt.dt(), *base, 0, None, None, None, None, B, NM, F, C, rt.stream())
-        _sync_stats(dstats)
+        gw, gb = grad_of(bn.weight), grad_of(bn.bias)
+        if _add_local_affine_grads(dstats, gw, gb, C):
+            gw = gb = None
         lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
-                           grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B, NM, F, C, rt.stream())
+                           _p(gw), _p(gb), B, NM, F, C, rt.stream())
         return None, None, None, None, None
 
 

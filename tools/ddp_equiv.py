@@ -50,7 +50,8 @@ def main():
         loss /= world
     if rank == 0:
         bn = model.encoder.video_encoder.front_end[3].blocks[0].layers[1]
-        torch.save({"grad": grad.cpu(), "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
+        names = {k: (o, p_.numel()) for (k, p_), o in zip(model.named_parameters(), model.arena.offsets)}
+        torch.save({"grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
