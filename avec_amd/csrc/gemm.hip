@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char avec_zero16[64];
 
-template <typename T, int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE, int STAGES>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = BKB / (int)sizeof(T);
@@ -411,13 +411,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * 128; swb[j] = (row >> 1) & 7; }
   const int gsel = lane >> 5;
 
-  issue(0, 0);
-  __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0) (expcnt/lgkmcnt untouched): the DMA of this wave has landed
-  __syncthreads();
+  // STAGES-deep ring of LDS buffers, counted vmcnt waits, ONE raw barrier per K-step (the DMA stays in flight across barriers):
+  //   wait(tile kt landed: only the newer S-2 tiles may still be outstanding) -> barrier -> issue tile kt+S-1 into the buffer everybody
+  //   finished reading before this barrier -> MFMAs on tile kt.
+  constexpr int LPT = NCA + NCB;             // DMA instructions per thread per tile
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st) if (st < KT) issue(st, st);
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);
-    const char* As = smem + cur * TILE; const char* Bs = As + BM * 128;
+    const int newer = min(STAGES - 2, KT - 1 - kt);     // tiles issued after kt that may still be in flight
+    if (STAGES <= 2 || newer <= 0) AVEC_WAIT_VM(0);
+    else if (newer == 1) AVEC_WAIT_VM(LPT);
+    else if (newer == 2) AVEC_WAIT_VM(2 * LPT);
+    else AVEC_WAIT_VM(3 * LPT);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       chunk16 fa[MT], fb[NT];
@@ -430,9 +440,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
   }
+#undef AVEC_WAIT_VM
+  __syncthreads();                            // every wave is done with the ring before the epilogue reuses the LDS
   nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
@@ -621,8 +631,9 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   // every chunk address 16-byte aligned?  (then each chunk is one global_load_dwordx4 instead of two dwordx2)
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
-#define G(MODE) do { const size_t l2 = (size_t)2 * (BM + BN) * 128 > (size_t)64 * (BN + 4) * 4 ? (size_t)2 * (BM + BN) * 128 : (size_t)64 * (BN + 4) * 4; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  constexpr int STG = (BM + BN) <= 128 ? 4 : 2;      // ring depth: deep for the small latency-bound tiles; the big tiles keep 3 workgroups per CU instead (measured)
+#define G(MODE) do { const size_t l2 = (size_t)STG * (BM + BN) * 128 > (size_t)64 * (BN + 4) * 4 + 10 * BN * 4 ? (size_t)STG * (BM + BN) * 128 : (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG>), grid, dim3(256), l2, st, g); return 0; } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
   if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G
