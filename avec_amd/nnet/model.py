@@ -37,6 +37,9 @@ class Model(Module):
                 self.optimizer.attach_arena(self.arena)
         return out
 
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else device)))
+
     def load_state_dict(self, state_dict, strict=True):
         out = super().load_state_dict(state_dict, strict=strict)
         if self.arena is not None:

@@ -26,10 +26,11 @@ class Adam(optim.Adam):
         dev = arena.master.device
         self._flat = {"exp_avg": torch.zeros_like(arena.master), "exp_avg_sq": torch.zeros_like(arena.master),
                       "state": torch.zeros(2, dtype=torch.float32, device=dev)}
+        self._step_t = torch.tensor(0.0)
         for p, o in zip(arena.params, arena.offsets):
             st = self.state[p]
             n = p.numel()
-            st["step"] = torch.tensor(0.0)
+            st["step"] = self._step_t
             st["exp_avg"] = self._flat["exp_avg"][o:o + n].as_strided(p.shape, p.stride())
             st["exp_avg_sq"] = self._flat["exp_avg_sq"][o:o + n].as_strided(p.shape, p.stride())
 
@@ -57,9 +58,7 @@ class Adam(optim.Adam):
     def step(self, closure=None):
         self.prepare_step()
         self.launch_step()
-        step = float(self.scheduler.model_step)
-        for p in self.arena.params:
-            self.state[p]["step"] = torch.tensor(step)
+        self._step_t.fill_(float(self.scheduler.model_step))     # one shared CPU scalar stands for every per-parameter "step"
         return None
 
     def _launch(self, g):
