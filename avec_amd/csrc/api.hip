@@ -1,6 +1,7 @@
 // Error plumbing + version for libavec_hip.so
 #include "common.h"
 #include "avec_hip.h"
+#include "vec.h"
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -11,3 +12,27 @@ void avec_set_error(const char* fmt, ...) {
 }
 extern "C" const char* avec_last_error() { return g_err; }
 extern "C" int avec_version() { return AVEC_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// reduction workspace (vec.h: two-pass column reductions).  One registration per device.
+// ---------------------------------------------------------------------------------------------
+static constexpr int WS_MAX_DEV = 64;
+static struct { void* base; size_t bytes; } g_ws[WS_MAX_DEV];
+
+extern "C" int avec_set_reduce_workspace(void* base, long long bytes) {
+  int dev = 0; hipError_t e = hipGetDevice(&dev);
+  AVEC_CHECK_ARG(e == hipSuccess && dev >= 0 && dev < WS_MAX_DEV, "set_reduce_workspace: no current device");
+  AVEC_CHECK_ARG((base == nullptr && bytes == 0) || (base != nullptr && bytes >= (1 << 16) && ((size_t)base & 255) == 0),
+                 "set_reduce_workspace: need a 256-byte aligned buffer of at least 64 KB (or NULL, 0 to unregister)");
+  g_ws[dev].base = base; g_ws[dev].bytes = (size_t)bytes;
+  return 0;
+}
+ColWs avec_reduce_ws(size_t partial_floats) {
+  ColWs ws{nullptr};
+  static const bool off = getenv("AVEC_NO_TREE") != nullptr;
+  if (off) return ws;
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return ws;
+  if (!g_ws[dev].base || partial_floats * sizeof(float) > g_ws[dev].bytes) return ws;
+  ws.partial = (float*)g_ws[dev].base;
+  return ws;
+}

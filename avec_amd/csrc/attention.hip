@@ -6,13 +6,14 @@
 // streamed in tiles of 64 through LDS with an online softmax, so nothing of size TxT is stored;
 // the backward recomputes probabilities from the saved log-sum-exp.  All arithmetic is fp32 VALU
 // (the attention bmm's are 0.5 % of the model's FLOPs); I/O is the activation dtype.
-//   fwd  : grid (ceil(T/16), B*H), lanes = keys (scores) then lanes = channels (P.V)
+//   fwd  : grid (ceil(T/32), B*H), lanes = keys (scores) then lanes = channels (P.V)
 //   bwd1 : dQ, same tiling as fwd
 //   bwd2 : dK, dV, dE; grid (key tiles, B*H, query segments of 64), lanes = keys, register accumulators
 #include "common.h"
 #include "avec_hip.h"
 
-static constexpr int TQ = 16;    // query rows per workgroup (fwd / bwd1): 4 waves x 4 rows
+static constexpr int TQ = 32;    // query rows per workgroup (fwd / bwd1): 4 waves x RPW rows
+static constexpr int RPW = TQ / 4;
 static constexpr int TK = 64;    // keys per tile = one per lane
 static constexpr int QC = 32;    // queries staged per chunk in the column pass (dK/dV/dE)
 
@@ -40,13 +41,52 @@ __device__ __forceinline__ bool key_keep(const AttnArgs& a, int b, int i, int j)
   return true;
 }
 
-// cooperative load of `rows` rows x d channels (act dtype -> fp32 LDS, zero outside [0, limit))
+// cooperative load of `rows` rows x d channels (act dtype -> fp32 LDS, zero outside [0, limit)).
+// VW elements per access: 16 B when the head width allows it (d % 8 == 0 for bf16, d % 4 == 0 for fp32), 4/8 B for even d,
+// scalar otherwise (d = 45).  Threads are laid out as (row, chunk) with a power-of-two chunk count, so no integer division.
+template <typename T, int VW>
+__device__ __forceinline__ void load_vec(const T* p, float* v) {
+  constexpr int NB = VW * (int)sizeof(T);
+  if constexpr (NB < 4) { v[0] = ldf(p); }
+  else {
+    uint32_t w[NB / 4];
+    if constexpr (NB == 16) { const chunk16 c = ldg16(p); w[0] = c.w[0]; w[1] = c.w[1]; w[2] = c.w[2]; w[3] = c.w[3]; }
+    else {
+#pragma unroll
+      for (int k = 0; k < NB / 4; ++k) w[k] = ((const uint32_t*)p)[k];
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int k = 0; k < NB / 4; ++k) v[k] = __uint_as_float(w[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB / 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+  }
+}
+template <typename T, int VW>
+__device__ __forceinline__ void load_rows_v(float* dst, int DP, const T* src, long long ld, int row0, int rows, int limit, int d) {
+  const int cpr = d / VW;
+  int sh = 0; while ((1 << sh) < cpr && sh < 8) ++sh;
+  const int tpr = 1 << sh, rl = threadIdx.x >> sh, cl = threadIdx.x & (tpr - 1), rpp = 256 >> sh;
+  for (int r = rl; r < rows; r += rpp) {
+    const int gr = row0 + r; const bool ok = gr >= 0 && gr < limit;
+    const T* rp = src + (long long)(ok ? gr : 0) * ld;
+    for (int cc = cl; cc < cpr; cc += tpr) {
+      float v[VW];
+      load_vec<T, VW>(rp + cc * VW, v);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) dst[r * DP + cc * VW + k] = ok ? v[k] : 0.f;
+    }
+  }
+}
 template <typename T>
 __device__ __forceinline__ void load_rows(float* dst, int DP, const T* src, long long ld, int row0, int rows, int limit, int d) {
-  for (int idx = threadIdx.x; idx < rows * d; idx += 256) {
-    int r = idx / d, c = idx - r * d; int gr = row0 + r;
-    dst[r * DP + c] = (gr >= 0 && gr < limit) ? ldf(src + (long long)gr * ld + c) : 0.f;
-  }
+  constexpr int V16 = 16 / (int)sizeof(T);
+  const bool al4 = ((ld * (long long)sizeof(T)) & 3) == 0 && (((size_t)src) & 3) == 0;
+  if (d % V16 == 0 && al4) load_rows_v<T, V16>(dst, DP, src, ld, row0, rows, limit, d);
+  else if (d % 2 == 0 && al4) load_rows_v<T, 2>(dst, DP, src, ld, row0, rows, limit, d);
+  else load_rows_v<T, 1>(dst, DP, src, ld, row0, rows, limit, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -68,13 +108,13 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
   if (BWD) load_rows<T>(Gs, DP, (const T*)a.dout + (long long)b * Tn * a.ldo + h * d, a.ldo, i0, TQ, Tn, d);
   __syncthreads();
 
-  float m_run[4], l_run[4], acc[4][2], Li[4], Il[4], dl[4];
+  float m_run[RPW], l_run[RPW], acc[RPW][2], Li[RPW], Il[RPW], dl[RPW];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; Il[rr] = 0.f; dl[rr] = 0.f; }
+  for (int rr = 0; rr < RPW; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; Il[rr] = 0.f; dl[rr] = 0.f; }
   if (BWD) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int ri = w * 4 + rr, i = i0 + ri;
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int ri = w * RPW + rr, i = i0 + ri;
       float s = 0.f;
       if (i < Tn) {
         const T* op = (const T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
@@ -94,8 +134,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
     __syncthreads();
     const int j = j0 + lane;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int ri = w * 4 + rr, i = i0 + ri;
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int ri = w * RPW + rr, i = i0 + ri;
       const bool iv = i < Tn, jv = j < Tn;
       const float* qrow = Qs + ri * DP; const float* krow = Ks + lane * DP; const float* erow = Es + (TQ - 1 - ri + lane) * DP;
       float s = 0.f, dp = 0.f;
@@ -141,8 +181,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
     }
   }
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int i = i0 + w * 4 + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int i = i0 + w * RPW + rr;
     if (i >= Tn) continue;
     if (!BWD) {
       const float inv = 1.f / l_run[rr];

@@ -16,7 +16,7 @@ __device__ __forceinline__ void glu4(const T* u, long long row, int C, int col, 
 
 template <typename T>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                                                             float* stats, int B, int Tn, int C, int K, int stride, int To) {
+                                                             float* stats, int B, int Tn, int C, int K, int stride, int To, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   const int padl = (K - 1) / 2; const long long M = (long long)B * To;
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict
     }
   }
   float* const dst[2] = {stats, stats ? stats + C : nullptr};
-  colreduce_atomic<2>(part, dst, col, C);
+  if (stats) colreduce_atomic<2>(part, dst, col, C, ws);
 }
 
 // du (act [B*T][2C]) from dc (act [B*To][C])
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_input_kernel(const T* __re
 // dw[k][c] += sum dc * g(shifted);  dbias[c] += sum dc
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ dc, const T* __restrict__ u, float* dw, float* dbias,
-                                                                int B, int Tn, int C, int K, int stride, int To) {
+                                                                int B, int Tn, int C, int K, int stride, int To, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   const int padl = (K - 1) / 2; const long long M = (long long)B * To;
   float part[KMAX + 1][4];
@@ -88,24 +88,33 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   for (int k = 0; k < KMAX; ++k) dst[k] = (k < K) ? dw + (long long)k * C : nullptr;
   dst[KMAX] = dbias;
   float* const (&cdst)[KMAX + 1] = dst;
-  colreduce_atomic<KMAX + 1>(part, cdst, col, C);
+  colreduce_atomic<KMAX + 1>(part, cdst, col, C, ws);
 }
 
 extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
                                    int B, int T_, int C, int K, int stride, hipStream_t st) {
   AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "glu_dwconv_fwd: bad arguments (C=%d K=%d)", C, K);
   const int To = (T_ - 1) / stride + 1;
-  dim3 grid = col_grid((long long)B * To, C);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To));
-  AVEC_LAUNCH_CHECK(); return 0;
+  dim3 grid = col_grid((long long)B * To, C); ColWs ws = stats ? col_ws_if(grid, 2, C) : ColWs{nullptr};
+  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
+  return 0;
 }
 extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
                                    int B, int T_, int C, int K, int stride, hipStream_t st) {
   AVEC_CHECK_ARG(dc && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "dwconv_glu_bwd: bad arguments");
   const int To = (T_ - 1) / stride + 1;
   long long n4 = (long long)B * T_ * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
-  dim3 grid = col_grid((long long)B * To, C);
+  dim3 grid = col_grid((long long)B * To, C); ColWs ws = col_ws_if(grid, KMAX + 1, C);
   DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To);
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), 0, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To));
-  AVEC_LAUNCH_CHECK(); return 0;
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), 0, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) {
+    float* dst[KMAX + 1];
+    for (int k = 0; k < KMAX; ++k) dst[k] = (k < K) ? dw + (long long)k * C : nullptr;
+    dst[KMAX] = dbias;
+    return col_finalize(ws, grid.x, grid.y, KMAX + 1, 128, dst, C, st);
+  }
+  return 0;
 }

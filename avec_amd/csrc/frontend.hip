@@ -233,7 +233,7 @@ __device__ __forceinline__ void stem_dr(const T* dp, const unsigned char* idx, l
 }
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
-                                                                   float* dstats, long long Fr, int H, int W, int C, int OH, int OW) {
+                                                                   float* dstats, long long Fr, int H, int W, int C, int OH, int OW, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const long long M = Fr * H * W;
@@ -246,7 +246,61 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const T* __re
     }
   }
   float* const dst[2] = {dstats, dstats + C};
-  colreduce_atomic<2>(part, dst, col, C);
+  colreduce_atomic<2>(part, dst, col, C, ws);
+}
+// 8-channel variants (C % 8 == 0): 16 B accesses, every lane busy for C = 64
+template <typename T>
+__device__ __forceinline__ void stem_dr8(const T* dp, const unsigned char* idx, long long fr, int h, int w, int c, int C, int OH, int OW, float dr[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dr[e] = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) { const int t = h + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= OH) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) { const int u = w + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= OW) continue;
+      const long long o = ((fr * OH + oh) * OW + ow) * C + c;
+      const uint2 sel = *(const uint2*)(idx + o); float g[8]; ld8<T>(dp + o, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { if (((sel.x >> (8 * e)) & 255u) == (unsigned)(kh * 3 + kw)) dr[e] += g[e];
+                                    if (((sel.y >> (8 * e)) & 255u) == (unsigned)(kh * 3 + kw)) dr[4 + e] += g[4 + e]; } } }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_reduce8_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
+                                                                    float* dstats, long long Fr, int H, int W, int C, int OH, int OW, ColWs ws) {
+  const Col8 m = col8_map(C);
+  float part[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
+  const long long M = Fr * H * W;
+  if (m.active) {
+    const int c = m.l * 8;
+    float mu[8], rs[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
+    for (long long row = (long long)blockIdx.x * m.R + m.r; row < M; row += (long long)gridDim.x * m.R) {
+      const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+      float dr[8], v[8]; stem_dr8<T>(dp, idx, fr, h, w, c, C, OH, OW, dr); ld8<T>(y + row * C + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { part[0][e] += dr[e]; part[1][e] += dr[e] * (v[e] - mu[e]) * rs[e]; }
+    }
+  }
+  float* const dst[2] = {dstats, dstats + C};
+  colreduce8_atomic<2>(part, dst, m, ws);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_apply8_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
+                                                                   T* __restrict__ dy, float* dgamma, float* dbeta, long long Fr, int H, int W, int C, int OH, int OW) {
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  const int C8 = C / 8; const long long n8 = Fr * H * W * C8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8; const long long row = i / C8;
+    const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+    float dr[8], v[8], mu[8], rs[8], g[8], s1[8], s2[8], o[8];
+    stem_dr8<T>(dp, idx, fr, h, w, c, C, OH, OW, dr); ld8<T>(y + row * C + c, v);
+    ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs); ld8<float>(gamma + c, g); ld8<float>(dstats + c, s1); ld8<float>(dstats + C + c, s2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float yh = (v[e] - mu[e]) * rs[e]; o[e] = g[e] * rs[e] * (dr[e] - s1[e] * inv_n - yh * s2[e] * inv_n); }
+    st8<T>(dy + row * C + c, o);
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bwd_apply_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
@@ -265,34 +319,44 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_apply_kernel(const T* __res
     st4<T>(dy + row * C + c, o);
   }
 }
-// im2col for the Cin=1 Conv3d stem: one thread = 8 consecutive k of one output pixel
+// im2col for the Cin=1 Conv3d stem (5x7x7, stride (1,2,2), pad (2,3,3)): one workgroup = one output row (clip, frame, oh).
+// The 5x7 input rows it touches are staged zero-padded in LDS (row pitch WP, chosen == 10 mod 32 to spread the banks); then
+// 32 lanes serve one output pixel, lane q writing the 16 B chunk k = 8q..8q+7 of its im2col row (contiguous 496 B rows).
 template <typename T>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ video, T* __restrict__ A, long long M, int T3, int H, int W, int OH, int OW, int ldk) {
-  const int cpr = ldk / 8; const long long total = M * cpr;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int q = (int)(i % cpr); const long long m = i / cpr;
-    const int ow = (int)(m % OW); long long t = m / OW; const int oh = (int)(t % OH); const long long ft = t / OH;
-    const int fr = (int)(ft % T3); const long long clip = ft / T3;
-    const float* src = video + clip * (long long)T3 * H * W;
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ video, T* __restrict__ A, int T3, int H, int W, int OH, int OW, int ldk, int WP) {
+  extern __shared__ float slab[];              // [35][WP]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long blk = blockIdx.x; const int oh = (int)(blk % OH); const long long ft = blk / OH; const int fr = (int)(ft % T3); const long long clip = ft / T3;
+  const float* src = video + clip * (long long)T3 * H * W;
+  for (int rw = wv; rw < 35; rw += 4) {
+    const int kd = rw / 7, kh = rw - kd * 7; const int it = fr + kd - 2, ih = oh * 2 - 3 + kh;
+    const bool rv = it >= 0 && it < T3 && ih >= 0 && ih < H;
+    const float* rp = src + ((long long)(rv ? it : 0) * H + (rv ? ih : 0)) * W;
+    for (int x = lane; x < WP; x += 64) { const int iw = x - 3; slab[rw * WP + x] = (rv && iw >= 0 && iw < W) ? rp[iw] : 0.f; }
+  }
+  const int q = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  int off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const int kk = q * 8 + e; const int kw = kk % 7, t2 = kk / 7; off[e] = kk < 245 ? t2 * WP + kw : -1; }
+  __syncthreads();
+  const int nq = ldk / 8;
+  T* Arow = A + blk * (long long)OW * ldk;
+  for (int ow = pg; ow < OW; ow += 8) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int kk = q * 8 + e; float x = 0.f;
-      if (kk < 245) {
-        const int kw = kk % 7, t2 = kk / 7, kh = t2 % 7, kd = t2 / 7;
-        const int it = fr + kd - 2, ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
-        if (it >= 0 && it < T3 && ih >= 0 && ih < H && iw >= 0 && iw < W) x = src[((long long)it * H + ih) * W + iw];
-      }
-      v[e] = x;
-    }
-    st4<T>(A + m * ldk + q * 8, v); st4<T>(A + m * ldk + q * 8 + 4, v + 4);
+    for (int e = 0; e < 8; ++e) v[e] = off[e] >= 0 ? slab[off[e] + 2 * ow] : 0.f;
+    if (q < nq) st8<T>(Arow + (long long)ow * ldk + q * 8, v);
   }
 }
 extern "C" int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, int T_, int H, int W, int ldk, hipStream_t st) {
-  AVEC_CHECK_ARG(video && A && clips > 0 && T_ > 0 && H > 0 && W > 0 && ldk >= 248 && ldk % 8 == 0, "stem_im2col: bad arguments");
-  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; const long long M = clips * T_ * OH * OW;
-  long long nb = (M * (ldk / 8) + 255) / 256; if (nb > 65536) nb = 65536;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, video, (T*)A, M, T_, H, W, OH, OW, ldk));
+  AVEC_CHECK_ARG(video && A && clips > 0 && T_ > 0 && H > 0 && W > 0 && (ldk == 248 || ldk == 256), "stem_im2col: bad arguments (ldk must be 248 or 256)");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  int WP = W + 6; while (WP % 32 != 10) ++WP;
+  const size_t lds = (size_t)35 * WP * 4;
+  AVEC_CHECK_ARG(lds <= 64 * 1024, "stem_im2col: frame width %d too large", W);
+  const long long nb = clips * T_ * OH;
+  AVEC_CHECK_ARG(nb < (1ll << 31), "stem_im2col: too many output rows");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3((unsigned)nb), dim3(256), lds, st, video, (T*)A, T_, H, W, OH, OW, ldk, WP));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t st) {
@@ -305,9 +369,27 @@ extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned c
                                   const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dpool && idx && y && ss && gamma && dstats && (phase == 0 || dy) && frames > 0 && C % 4 == 0, "stem_pool_bwd: bad arguments");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  if (C % 8 == 0 && C <= 2048) {
+    if (phase == 0) {
+      ColWs ws; const unsigned nb8 = col8_cfg(frames * H * W, C, 2, &ws);
+      DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce8_kernel<T>, dim3(nb8), dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats,
+                                           frames, H, W, C, OH, OW, ws));
+      AVEC_LAUNCH_CHECK();
+      if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb8, 2, C, dst, C, st); }
+      return 0;
+    } else {
+      long long n8 = frames * H * W * (C / 8); long long nb = (n8 + 255) / 256; if (nb > 16384) nb = 16384;
+      DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_apply8_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, gamma, dstats, count_ptr, count,
+                                           (T*)dy, dgamma, dbeta, frames, H, W, C, OH, OW));
+    }
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   if (phase == 0) {
-    dim3 grid = col_grid(frames * H * W, C);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats, frames, H, W, C, OH, OW));
+    dim3 grid = col_grid(frames * H * W, C); ColWs ws = col_ws_if(grid, 2, C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats, frames, H, W, C, OH, OW, ws));
+    AVEC_LAUNCH_CHECK();
+    if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
+    return 0;
   } else {
     long long n4 = frames * H * W * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
     DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, gamma, dstats, count_ptr, count,

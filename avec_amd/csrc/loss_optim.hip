@@ -87,12 +87,96 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
   }
 }
 
+// LDS-resident variant (used when 3*T*S + T + 4*V floats fit in 64 KB): 256 threads per utterance.
+//   phase 1  frame log-normalisers, one frame per wave, then log p(ext[s] | t) for every (t, s) in parallel
+//   phase 2  alpha (threads 0..127) and beta (threads 128..255) recursions run concurrently, one barrier per frame, LDS only
+//   phase 3  gradient rows, one frame per wave (occupancy scatter into a per-wave LDS histogram)
+__global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+                                                      const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
+                                                      int B, int T, int V, int Lmax, int blank, int zero_inf) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Smax = 2 * Lmax + 1;
+  float* lpe = sm; float* alpha = lpe + T * Smax; float* beta = alpha + T * Smax; float* lnorm = beta + T * Smax;
+  float* occ = lnorm + T; int* ext = (int*)(occ + 4 * V);
+  const int Tb = min((int)in_lens[b], T), L = min((int)tgt_lens[b], Lmax), S = 2 * L + 1;
+  const float* lg = logits + (long long)b * T * V;
+  float* gr = grad ? grad + (long long)b * T * V : nullptr;
+  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
+  for (int t = wv; t < Tb; t += 4) {
+    float mx = -INFINITY; for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[t * V + v]);
+    mx = wave_max(mx);
+    float se = 0.f; for (int v = lane; v < V; v += 64) se += __expf(lg[t * V + v] - mx);
+    se = wave_sum(se);
+    if (lane == 0) lnorm[t] = mx + __logf(se);
+  }
+  __syncthreads();
+  for (int i = tid; i < Tb * S; i += 256) { const int t = i / S, s = i - t * S; lpe[t * Smax + s] = lg[t * V + ext[s]] - lnorm[t]; }
+  __syncthreads();
+  float ll = -INFINITY;
+  if (Tb > 0) {
+    const bool fw = tid < 128; const int s0 = fw ? tid : tid - 128;
+    for (int k = 0; k < Tb; ++k) {
+      if (fw) {
+        const int t = k; float* an = alpha + t * Smax; const float* ap = an - Smax;
+        for (int s = s0; s < S; s += 128) {
+          float a;
+          if (t == 0) a = (s < 2) ? 0.f : -INFINITY;
+          else {
+            a = ap[s];
+            if (s >= 1) a = logaddexpf_(a, ap[s - 1]);
+            if (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) a = logaddexpf_(a, ap[s - 2]);
+          }
+          an[s] = a + lpe[t * Smax + s];
+        }
+      } else {
+        const int t = Tb - 1 - k; float* bc = beta + t * Smax; const float* bn = bc + Smax;
+        for (int s = s0; s < S; s += 128) {
+          float bv;
+          if (k == 0) bv = (s >= S - 2) ? 0.f : -INFINITY;
+          else {
+            bv = bn[s];
+            if (s + 1 < S) bv = logaddexpf_(bv, bn[s + 1]);
+            if (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != ext[s]) bv = logaddexpf_(bv, bn[s + 2]);
+          }
+          bc[s] = bv + lpe[t * Smax + s];
+        }
+      }
+      __syncthreads();
+    }
+    const float* al = alpha + (Tb - 1) * Smax;
+    ll = al[S - 1]; if (S > 1) ll = logaddexpf_(ll, al[S - 2]);
+  } else if (L == 0) ll = 0.f;
+  float loss = -ll;
+  const bool inf = !(loss < INFINITY);
+  if (inf && zero_inf) loss = 0.f;
+  if (tid == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); }
+  if (!gr) return;
+  for (int i = tid; i < (T - Tb) * V; i += 256) gr[(long long)Tb * V + i] = 0.f;
+  if (inf || Tb == 0) { for (int i = tid; i < Tb * V; i += 256) gr[i] = 0.f; return; }
+  float* oc = occ + wv * V;
+  for (int t0 = 0; t0 < Tb; t0 += 4) {
+    const int t = t0 + wv;
+    for (int v = lane; v < V; v += 64) oc[v] = 0.f;
+    __syncthreads();
+    if (t < Tb) for (int s = lane; s < S; s += 64) atomicAdd(oc + ext[s], __expf(alpha[t * Smax + s] + beta[t * Smax + s] - lpe[t * Smax + s] - ll));
+    __syncthreads();
+    if (t < Tb) for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - oc[v];
+  }
+}
+
 extern "C" long long avec_ctc_workspace_floats(int B, int T, int Lmax) { return (long long)B * ((long long)T * (2 * Lmax + 1) + T); }
 
 extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
                              float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
   AVEC_CHECK_ARG(logits && in_lens && targets && tgt_lens && nll && workspace, "ctc_loss: null pointer");
   AVEC_CHECK_ARG(B > 0 && T > 0 && V > 0 && Lmax >= 0 && blank >= 0 && blank < V, "ctc_loss: bad dims B=%d T=%d V=%d Lmax=%d", B, T, V, Lmax);
+  const size_t Smax = 2 * (size_t)Lmax + 1;
+  const size_t lds_fast = (3 * (size_t)T * Smax + T + 4 * (size_t)V + Smax) * 4;
+  if (lds_fast <= 64 * 1024) {
+    hipLaunchKernelGGL(ctc_lds_kernel, dim3(B), dim3(256), lds_fast, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_infinity);
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   size_t lds = (size_t)(2 * (2 * Lmax + 1) + V) * 4 + (size_t)(2 * Lmax + 1) * 4;
   AVEC_CHECK_ARG(lds <= 60 * 1024, "ctc_loss: label length %d too long for the LDS state buffers", Lmax);
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(64), lds, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, workspace, B, T, V, Lmax, blank, zero_infinity);

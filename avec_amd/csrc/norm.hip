@@ -7,6 +7,45 @@
 
 #include "vec.h"
 
+// second pass of the two-pass column reductions (vec.h): dst[n][colblock*W + w] += sum over slots of partial[colblock][slot][n][w]
+__global__ __launch_bounds__(256) void col_finalize_kernel(ColFin f) {
+  __shared__ float red[16][17];
+  const int cw = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int ncols = f.NV * f.W;
+  const int o = blockIdx.x * 16 + cw;
+  const unsigned cb = blockIdx.y;
+  const int s0 = blockIdx.z * 128;
+  float s = 0.f;
+  if (o < ncols) {
+    const float* p = f.partial + ((size_t)cb * f.nslots) * ncols + o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int si = s0 + sl + 16 * k; const int sc = si < f.nslots ? si : f.nslots - 1;
+      const float v = p[(size_t)sc * ncols];
+      s += si < f.nslots ? v : 0.f;
+    }
+  }
+  red[sl][cw] = s;
+  __syncthreads();
+  if (sl == 0 && o < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cw];
+    const int n = o / f.W, w = o - n * f.W; const int col = (int)cb * f.W + w;
+    float* d = nullptr;
+#pragma unroll
+    for (int i = 0; i < FIN_MAXNV; ++i) if (i == n) d = f.dst[i];
+    if (d && col < f.C) atomicAdd(d + col, t);
+  }
+}
+int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st) {
+  ColFin f; f.partial = ws.partial; f.NV = NV; f.W = W; f.C = C; f.nslots = (int)nslots;
+  for (int i = 0; i < FIN_MAXNV; ++i) f.dst[i] = i < NV ? dst[i] : nullptr;
+  dim3 grid((unsigned)((NV * W + 15) / 16), colblocks, (nslots + 127) / 128);
+  hipLaunchKernelGGL(col_finalize_kernel, grid, dim3(256), 0, st, f);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // =============================================================================================
 // LayerNorm: x fp32 [M][D]; one wave per row.   (nn.LayerNorm(eps=1e-6): nnet/modules.py:278,302,373; nnet/blocks.py:267)
 // =============================================================================================
@@ -34,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <typename TG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ g, float* dx, const float* dres,
-                                                     float* __restrict__ dg, float* __restrict__ db, long long M, int D) {
+                                                     float* __restrict__ dg, float* __restrict__ db, long long M, int D, ColWs ws) {
   const int lane = threadIdx.x & 63; const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6); const int nwaves = gridDim.x * 4;
   // D <= 1536: each lane owns up to 6 groups of 4 columns
   float pg[6][4], pb[6][4];
@@ -68,7 +107,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
     for (int e = 0; e < 4; ++e) { atomicAdd(lnred + c + e, pg[i][e]); atomicAdd(lnred + D + c + e, pb[i][e]); }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) { atomicAdd(dg + c, lnred[c]); atomicAdd(db + c, lnred[D + c]); }
+  if (!ws.partial) { for (int c = threadIdx.x; c < D; c += 256) { atomicAdd(dg + c, lnred[c]); atomicAdd(db + c, lnred[D + c]); } return; }
+  float* mine = ws_slot(ws, 0, blockIdx.x, gridDim.x, 2 * D);
+  for (int c = threadIdx.x; c < 2 * D; c += 256) mine[c] = lnred[c];
 }
 
 extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int y_f32,
@@ -85,11 +126,15 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
                                   float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
-  long long nb = (M + 15) / 16; if (nb > 128) nb = 128; if (nb < 1) nb = 1;
+  long long nb = (M + 15) / 16; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  ColWs ws = avec_reduce_ws((size_t)nb * 2 * D);
+  if (!ws.partial && nb > 128) nb = 128;
   const size_t lds = (size_t)2 * D * sizeof(float);
-  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
-  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), lds, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D);
-  AVEC_LAUNCH_CHECK(); return 0;
+  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws);
+  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), lds, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws);
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {dgamma, dbeta}; return col_finalize(ws, 1, (unsigned)nb, 2, D, dst, D, st); }
+  return 0;
 }
 
 // =============================================================================================
@@ -98,7 +143,7 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
 // =============================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void grad_prep_kernel(const float* __restrict__ dout, long long ldd, T* __restrict__ dacc, float alpha, float p,
-                                                        const unsigned long long* rng, unsigned stream, float* dbias, long long M, int N) {
+                                                        const unsigned long long* rng, unsigned stream, float* dbias, long long M, int N, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = (blockIdx.x * 32 + tx) * 4;
   float part[1][4] = {{0.f, 0.f, 0.f, 0.f}};
@@ -110,34 +155,38 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float* __restrict_
     }
   }
   float* const dst[1] = {dbias};
-  colreduce_atomic<1>(part, dst, col, N);
+  if (dbias) colreduce_atomic<1>(part, dst, col, N, ws);
 }
 
 extern "C" int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
                               unsigned rng_stream, float* dbias, long long M, int N, hipStream_t st) {
   AVEC_CHECK_ARG(dout && dacc && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "grad_prep: bad arguments (N=%d ld=%lld)", N, ld);
   AVEC_CHECK_ARG(!(drop_p > 0.f) || rng, "grad_prep: dropout without rng");
-  dim3 grid = col_grid(M, N);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_kernel<T>, grid, dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, dbias, M, N));
-  AVEC_LAUNCH_CHECK(); return 0;
+  dim3 grid = col_grid(M, N); ColWs ws = dbias ? col_ws_if(grid, 1, N) : ColWs{nullptr};
+  DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_kernel<T>, grid, dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, dbias, M, N, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[1] = {dbias}; return col_finalize(ws, grid.x, grid.y, 1, 128, dst, N, st); }
+  return 0;
 }
 
 // column sums of an act matrix:  out[n] += sum_m x[m][n]
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long long ld, float* out, long long M, int N) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long long ld, float* out, long long M, int N, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   float part[1][4] = {{0.f, 0.f, 0.f, 0.f}};
   if (col < N) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
     float v[4]; ld4<T>(x + row * ld + col, v); for (int e = 0; e < 4; ++e) part[0][e] += v[e];
   }
   float* const dst[1] = {out};
-  colreduce_atomic<1>(part, dst, col, N);
+  colreduce_atomic<1>(part, dst, col, N, ws);
 }
 extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t st) {
   AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: bad arguments");
-  dim3 grid = col_grid(M, N);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ld, out, M, N));
-  AVEC_LAUNCH_CHECK(); return 0;
+  dim3 grid = col_grid(M, N); ColWs ws = col_ws_if(grid, 1, N);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ld, out, M, N, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[1] = {out}; return col_finalize(ws, grid.x, grid.y, 1, 128, dst, N, st); }
+  return 0;
 }
 
 // =============================================================================================
@@ -146,20 +195,22 @@ extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, l
 //   ss = [scale | shift | mean | rstd], each [C]
 // =============================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, float* stats, long long M, int C) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, float* stats, long long M, int C, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (col < C) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
     float v[4]; ld4<T>(y + row * C + col, v); for (int e = 0; e < 4; ++e) { part[0][e] += v[e]; part[1][e] += v[e] * v[e]; }
   }
   float* const dst[2] = {stats, stats + C};
-  colreduce_atomic<2>(part, dst, col, C);
+  colreduce_atomic<2>(part, dst, col, C, ws);
 }
 extern "C" int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && stats && M > 0 && C > 0 && C % 4 == 0, "bn_stats: bad arguments");
-  dim3 grid = col_grid(M, C);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), 0, st, (const T*)y, stats, M, C));
-  AVEC_LAUNCH_CHECK(); return 0;
+  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), 0, st, (const T*)y, stats, M, C, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
+  return 0;
 }
 
 __global__ void bn_finalize_kernel(const float* stats, int nrep, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
@@ -220,7 +271,7 @@ __device__ __forceinline__ void bn_dr(const T* dout, const T* y, const T* out, c
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
-                                                            int act, float* dstats, long long M, int C) {
+                                                            int act, float* dstats, long long M, int C, ColWs ws) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (col < C) for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
@@ -228,13 +279,50 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int e = 0; e < 4; ++e) { part[0][e] += dr[e]; part[1][e] += dr[e] * yh[e]; }
   }
   float* const dst[2] = {dstats, dstats + C};
-  colreduce_atomic<2>(part, dst, col, C);
+  colreduce_atomic<2>(part, dst, col, C, ws);
+}
+// 8-wide flat variant (C % 8 == 0): every lane busy for narrow C, 16 B accesses
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
+                                                             int act, float* dstats, long long M, int C, ColWs ws) {
+  const Col8 m = col8_map(C);
+  float part[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
+  if (m.active) {
+    const int c = m.l * 8;
+    float mu[8], rs[8], sc[8], sh[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
+    if (act == 1) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
+    for (long long row = (long long)blockIdx.x * m.R + m.r; row < M; row += (long long)gridDim.x * m.R) {
+      const long long off = row * C + c;
+      float d[8], v[8]; ld8<T>(dout + off, d); ld8<T>(y + off, v);
+      if (act == 2) { float o[8]; ld8<T>(out + off, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f; }
+      else if (act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= dswishf_(v[e] * sc[e] + sh[e]); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { part[0][e] += d[e]; part[1][e] += d[e] * (v[e] - mu[e]) * rs[e]; }
+    }
+  }
+  float* const dst[2] = {dstats, dstats + C};
+  colreduce8_atomic<2>(part, dst, m, ws);
 }
 extern "C" int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && ss && dstats && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
-  dim3 grid = col_grid(M, C);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C));
-  AVEC_LAUNCH_CHECK(); return 0;
+  if (col8_ok(C)) {
+    ColWs ws; const unsigned nb = col8_cfg(M, C, 2, &ws);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C, ws));
+    AVEC_LAUNCH_CHECK();
+    if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
+    return 0;
+  }
+  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
+  return 0;
 }
 // dy = gamma*rstd*(dr - mean(dr) - yhat*mean(dr*yhat)); optional dres = dr; block 0 adds dgamma/dbeta
 template <typename T>

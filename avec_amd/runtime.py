@@ -65,7 +65,23 @@ def sync_batchnorm():
         and torch.distributed.get_world_size() > 1
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 32 << 20
+
+
+def _register_workspace(dev):
+    """Scratch for the two-level column reductions (include/avec_hip.h: avec_set_reduce_workspace), one per device, zero-initialised.
+    The engine launches on one stream per device, as the registration requires."""
+    buf = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", dev))
+    with torch.cuda.device(dev):
+        lib.set_reduce_workspace(buf.data_ptr(), WORKSPACE_BYTES)
+    _WORKSPACE[dev] = buf
+
+
 def stream():
+    dev = torch.cuda.current_device()
+    if dev not in _WORKSPACE:
+        _register_workspace(dev)
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -38,6 +38,11 @@ extern "C" {
 
 int avec_version(void);
 const char* avec_last_error(void);
+/* Optional scratch for the two-pass column reductions (LayerNorm / BatchNorm / depthwise-conv parameter-gradient sums): a 256-byte aligned
+ * device buffer (>= 64 KB; 32 MB serves every shape of the AV model) registered for the current device.  Without it those kernels fall back
+ * to one float atomic per column per workgroup.  The buffer must stay alive and must not be used by two streams at once.
+ * (base = NULL, bytes = 0 unregisters.) */
+int avec_set_reduce_workspace(void* base, long long bytes);
 
 /* ---- row sources for the GEMM family ------------------------------------------------------ */
 enum { AVEC_ROWS_PLAIN = 0, AVEC_ROWS_CONV_FWD = 1, AVEC_ROWS_CONV_BWD = 2 };
