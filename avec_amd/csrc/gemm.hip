@@ -688,7 +688,11 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   int tiles = ((g.I + BI - 1) / BI) * ((g.J + BJ - 1) / BJ) * nbatch;
   long long ksteps = (g.M + KE - 1) / KE;
   // split the reduction so that ~512 workgroups exist, but keep >= 4 K-steps per workgroup: every split costs BI*BJ fp32 atomics
-  long long split = (512 + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1) split = 1;
+  // measured on MI355X: the implicit-GEMM weight gradients keep improving up to ~2048 workgroups (8 per CU; 183 -> 255 TFLOP/s on the
+  // 64->64 3x3 layer), the plain small-K products are best around 512
+  static const long long wg_env = getenv("AVEC_TN_WGS") ? atoll(getenv("AVEC_TN_WGS")) : 0;
+  const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? 2048 : 512);
+  long long split = (wg_target + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1) split = 1;
   long long per = ((ksteps + split - 1) / split) * KE;
   split = (g.M + per - 1) / per;
   g.m_per_block = (int)per; g.split = (int)split;
