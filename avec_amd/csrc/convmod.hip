@@ -14,24 +14,37 @@ __device__ __forceinline__ void glu4(const T* u, long long row, int C, int col, 
   for (int e = 0; e < 4; ++e) g[e] = a[e] * sigmoidf_(b[e]);
 }
 
+// Workgroup = (128-channel slab, batch b, chunk of DW_TT output frames).  GLU(u) of the frames the chunk touches is computed ONCE into
+// LDS (fp32, zero outside the sequence = the "same" padding), then every output frame reads its K taps from LDS.
+static constexpr int DW_TT = 32;
+template <typename T>
+__device__ __forceinline__ void stage_glu(float* gs, const T* u, long long b, int Tn, int C, int col, int t_base, int nrows) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < nrows; r += 8) {
+    const int t = t_base + r; float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < C && t >= 0 && t < Tn) glu4<T>(u, b * Tn + t, C, col, g);
+    *(float4*)(gs + r * 128 + tx * 4) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                                                             float* stats, int B, int Tn, int C, int K, int stride, int To, ColWs ws) {
+                                                             float* stats, int B, int Tn, int C, int K, int stride, int To, int nchunks, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float gs[];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
-  const int padl = (K - 1) / 2; const long long M = (long long)B * To;
+  const int b = blockIdx.y / nchunks, to0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, To - to0);
+  const int padl = (K - 1) / 2;
+  stage_glu<T>(gs, u, b, Tn, C, col, to0 * stride - padl, (nto - 1) * stride + K);
+  __syncthreads();
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (col < C) {
     float bb[4] = {0.f, 0.f, 0.f, 0.f}; if (bias) ld4<float>(bias + col, bb);
-    for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
-      const int to = (int)(row % To); const long long b = row / To;
+    for (int r = ty; r < nto; r += 8) {
       float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
       for (int k = 0; k < K; ++k) {
-        const int t = to * stride + k - padl;
-        if (t < 0 || t >= Tn) continue;
-        float g[4], ww[4]; glu4<T>(u, b * Tn + t, C, col, g); ld4<float>(w + (long long)k * C + col, ww);
-        for (int e = 0; e < 4; ++e) acc[e] += ww[e] * g[e];
+        const float4 g = *(const float4*)(gs + (r * stride + k) * 128 + tx * 4); float ww[4]; ld4<float>(w + (long long)k * C + col, ww);
+        acc[0] += ww[0] * g.x; acc[1] += ww[1] * g.y; acc[2] += ww[2] * g.z; acc[3] += ww[3] * g.w;
       }
-      st4<T>(out + row * C + col, acc);
+      st4<T>(out + ((long long)b * To + to0 + r) * C + col, acc);
       for (int e = 0; e < 4; ++e) { part[0][e] += acc[e]; part[1][e] += acc[e] * acc[e]; }
     }
   }
@@ -59,27 +72,28 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_input_kernel(const T* __re
   }
 }
 
-// dw[k][c] += sum dc * g(shifted);  dbias[c] += sum dc
+// dw[k][c] += sum dc * g(shifted);  dbias[c] += sum dc        (same tiling as the forward: GLU staged once per chunk in LDS)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ dc, const T* __restrict__ u, float* dw, float* dbias,
-                                                                int B, int Tn, int C, int K, int stride, int To, ColWs ws) {
+                                                                int B, int Tn, int C, int K, int stride, int To, int nchunks, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float gs[];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
-  const int padl = (K - 1) / 2; const long long M = (long long)B * To;
+  const int b = blockIdx.y / nchunks, to0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, To - to0);
+  const int padl = (K - 1) / 2;
+  stage_glu<T>(gs, u, b, Tn, C, col, to0 * stride - padl, (nto - 1) * stride + K);
+  __syncthreads();
   float part[KMAX + 1][4];
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) for (int e = 0; e < 4; ++e) part[k][e] = 0.f;
   if (col < C) {
-    for (long long row = (long long)blockIdx.y * 8 + ty; row < M; row += (long long)gridDim.y * 8) {
-      const int to = (int)(row % To); const long long b = row / To;
-      float d[4]; ld4<T>(dc + row * C + col, d);
+    for (int r = ty; r < nto; r += 8) {
+      float d[4]; ld4<T>(dc + ((long long)b * To + to0 + r) * C + col, d);
       for (int e = 0; e < 4; ++e) part[KMAX][e] += d[e];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k >= K) break;
-        const int t = to * stride + k - padl;
-        if (t < 0 || t >= Tn) continue;
-        float g[4]; glu4<T>(u, b * Tn + t, C, col, g);
-        for (int e = 0; e < 4; ++e) part[k][e] += d[e] * g[e];
+        const float4 g = *(const float4*)(gs + (r * stride + k) * 128 + tx * 4);
+        part[k][0] += d[0] * g.x; part[k][1] += d[1] * g.y; part[k][2] += d[2] * g.z; part[k][3] += d[3] * g.w;
       }
     }
   }
@@ -95,8 +109,11 @@ extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, con
                                    int B, int T_, int C, int K, int stride, hipStream_t st) {
   AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "glu_dwconv_fwd: bad arguments (C=%d K=%d)", C, K);
   const int To = (T_ - 1) / stride + 1;
-  dim3 grid = col_grid((long long)B * To, C); ColWs ws = stats ? col_ws_if(grid, 2, C) : ColWs{nullptr};
-  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), 0, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, ws));
+  const int nchunks = (To + DW_TT - 1) / DW_TT;
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = stats ? col_ws_if(grid, 2, C) : ColWs{nullptr};
+  const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
+  AVEC_CHECK_ARG(lds <= 64 * 1024, "glu_dwconv_fwd: stride %d too large", stride);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), lds, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, nchunks, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
   return 0;
@@ -106,9 +123,12 @@ extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, con
   AVEC_CHECK_ARG(dc && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "dwconv_glu_bwd: bad arguments");
   const int To = (T_ - 1) / stride + 1;
   long long n4 = (long long)B * T_ * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
-  dim3 grid = col_grid((long long)B * To, C); ColWs ws = col_ws_if(grid, KMAX + 1, C);
+  const int nchunks = (To + DW_TT - 1) / DW_TT;
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C);
+  const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
+  AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
   DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To);
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), 0, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, ws));
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), lds, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, nchunks, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) {
     float* dst[KMAX + 1];

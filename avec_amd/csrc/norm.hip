@@ -213,15 +213,23 @@ extern "C" int avec_bn_stats(int dtype, const void* y, float* stats, long long M
   return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* stats, int nrep, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                   long long* nbt, float momentum, float eps, float* ss, int C, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 16 channels x 16 replica lanes (the 64 replicated partial sums of the GEMM epilogue are read in parallel, 4 per lane)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int nrep, const float* count_ptr, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                                          long long* nbt, float momentum, float eps, float* ss, int C, int training) {
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (training && c < C) for (int r = rl; r < nrep; r += 16) { s1 += stats[(long long)r * 2 * C + c]; s2 += stats[(long long)r * 2 * C + C + c]; }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
   float mean, var;
   if (training) {
     const float n = count_ptr ? *count_ptr : count;
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < nrep; ++r) { s1 += stats[(long long)r * 2 * C + c]; s2 += stats[(long long)r * 2 * C + C + c]; }   // replicated partial sums (GEMM epilogue)
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     mean = s1 / n; var = fmaxf(s2 / n - mean * mean, 0.f);
     if (rmean) {
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
@@ -235,7 +243,7 @@ __global__ void bn_finalize_kernel(const float* stats, int nrep, const float* co
 extern "C" int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t st) {
   AVEC_CHECK_ARG(gamma && beta && ss && C > 0 && (training ? (stats != nullptr) : (running_mean && running_var)), "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, n_replicas > 0 ? n_replicas : 1, count_ptr, count, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, stats, n_replicas > 0 ? n_replicas : 1, count_ptr, count, gamma, beta, running_mean, running_var,
                      num_batches_tracked, momentum, eps, ss, C, training);
   AVEC_LAUNCH_CHECK(); return 0;
 }
