@@ -601,6 +601,147 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TN, bf16, gfx950 transposed-read variant.  The reduction tiles are copied AS THEY LIE in memory ([m][i] and [m][j], 64 rows) by the
+// LDS-DMA (no register staging, no transposing stores) and the MFMA operands are fetched with ds_read_b64_tr_b16: a 16-lane group reads a
+// [4 m][16 col] block and every lane receives 4 consecutive m of its column = half of a 32x32x16 operand.  16-byte chunks are XOR-swizzled
+// (source side: lane L of a DMA fetches the logical chunk that belongs in physical slot L) so that the 4 rows of a block fall on
+// distinct banks: chunk ^= 4*(row & 3) for 256-byte rows, ^= 4*((row >> 1) & 1) for 128-byte rows.
+// ------------------------------------------------------------------------------------------------
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ chunk16 tr_read8(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) v4s_t* lp_t;
+  const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p1);
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  chunk16 f; f.w[0] = ua.x; f.w[1] = ua.y; f.w[2] = ub.x; f.w[3] = ub.y; return f;
+}
+template <int BC> __device__ __forceinline__ int tr_swz(int row) { return BC == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
+
+template <int BI, int BJ, int MODE, int STAGES>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
+  typedef bf16 T;
+  constexpr int KT = 64;                                       // reduction rows per tile
+  constexpr int CPI = BI / 8, CPJ = BJ / 8;                    // 16-byte chunks per LDS row
+  constexpr int RI = 256 / CPI, RJ = 256 / CPJ;                // rows covered by one DMA pass of the workgroup
+  constexpr int NLI = KT / RI, NLJ = KT / RJ;                  // DMA instructions per thread per tile
+  constexpr int MTI = BI / 64, MTJ = BJ / 64;
+  constexpr int PBYTES = KT * BI * 2, QBYTES = KT * BJ * 2, TILE = PBYTES + QBYTES;
+  constexpr bool Q_CONV = (MODE == MODE_CONV_FWD);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
+  const int zb = blockIdx.z / g.split, zs = blockIdx.z - zb * g.split;
+  const long long bo = zb / g.nb_inner, bi = zb - bo * g.nb_inner;
+  const T* Pp = (const T*)g.P + bo * g.sPo + bi * g.sPi;
+  const T* Qp = (const T*)g.q.ptr + bo * g.sQo + bi * g.sQi;
+  float* Op = g.O + bo * g.sOo + bi * g.sOi;
+  const long long mb = (long long)zs * g.m_per_block;
+  long long me = mb + g.m_per_block; if (me > g.M) me = g.M;
+
+  f32x16 acc[MTI][MTJ];
+#pragma unroll
+  for (int i = 0; i < MTI; ++i)
+#pragma unroll
+    for (int j = 0; j < MTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA task u: LDS slot u*256 + tid = (row tid/CP + u*R, physical chunk tid%CP); the swizzle term does not depend on u (R = 16 or 32 rows)
+  const int prow0 = tid / CPI, pcol = i0 + (((tid % CPI) ^ tr_swz<BI>(prow0)) << 3);
+  const int qrow0 = tid / CPJ, qcol = j0 + (((tid % CPJ) ^ tr_swz<BJ>(qrow0)) << 3);
+  const bool pok = pcol < g.Iq, qok = qcol < (Q_CONV ? g.J : g.Jq);
+  int qkh = 0, qkw = 0, qc = 0, qoh[NLJ], qow[NLJ]; long long qimg[NLJ];
+  if (Q_CONV) {
+    const int tap = qcol / g.q.C; qc = qcol - tap * g.q.C; qkh = tap / g.q.KW; qkw = tap - qkh * g.q.KW;
+#pragma unroll
+    for (int u = 0; u < NLJ; ++u) {
+      const long long m = mb + qrow0 + u * RJ; qow[u] = (int)(m % g.q.OW); const long long t = m / g.q.OW; qoh[u] = (int)(t % g.q.OH); qimg[u] = (t / g.q.OH) * (long long)g.q.H * g.q.W * g.q.C;
+    }
+  }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue = [&](long long mt0, int buf) {
+    char* Ps = smem + buf * TILE; char* Qs = Ps + PBYTES;
+#pragma unroll
+    for (int u = 0; u < NLI; ++u) {
+      const long long m = mt0 + prow0 + u * RI;
+      const void* src = (pok && m < me) ? (const void*)(Pp + m * g.ldp + pcol) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ps + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NLJ; ++u) {
+      const long long m = mt0 + qrow0 + u * RJ;
+      const void* src = (const void*)avec_zero16;
+      if (Q_CONV) {
+        const int ih = qoh[u] * g.q.stride - g.q.pad + qkh, iw = qow[u] * g.q.stride - g.q.pad + qkw;
+        const bool ok = qok && m < me && ih >= 0 && ih < g.q.H && iw >= 0 && iw < g.q.W;
+        const T* sp = Qp + qimg[u] + (ih * g.q.W + iw) * g.q.C + qc;
+        src = ok ? (const void*)sp : src;
+        qow[u] += KT;                                            // advance this row by one reduction tile
+        while (qow[u] >= g.q.OW) { qow[u] -= g.q.OW; if (++qoh[u] >= g.q.OH) { qoh[u] = 0; qimg[u] += (long long)g.q.H * g.q.W * g.q.C; } }
+      } else {
+        long long row = m;
+        if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
+        src = (qok && m < me) ? (const void*)(Qp + row * g.q.ld + qcol) : src;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Qs + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  // fragment addressing: lane = (16-lane group g4, t); operand row/col 16*(g4&1) + t of the 32-wide block, k-group g4>>1; read h fetches
+  // reduction rows 8*(g4>>1) + 4h + (t>>2), 8-byte piece (t&3) of the 32-byte column block
+  const int g4 = lane >> 4, t = lane & 15;
+  int offa[MTI][2], offb[MTJ][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * (g4 >> 1) + 4 * h + (t >> 2);
+#pragma unroll
+    for (int i = 0; i < MTI; ++i) { const int cb = wi * (BI / 2) + i * 32 + 16 * (g4 & 1); offa[i][h] = row * (BI * 2) + ((((cb >> 3) + ((t & 3) >> 1)) ^ tr_swz<BI>(row)) << 4) + (t & 1) * 8; }
+#pragma unroll
+    for (int j = 0; j < MTJ; ++j) { const int cb = wj * (BJ / 2) + j * 32 + 16 * (g4 & 1); offb[j][h] = PBYTES + row * (BJ * 2) + ((((cb >> 3) + ((t & 3) >> 1)) ^ tr_swz<BJ>(row)) << 4) + (t & 1) * 8; }
+  }
+  constexpr int LPT = NLI + NLJ;
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  const int KTN = (int)((me - mb + KT - 1) / KT);
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st) if (st < KTN) issue(mb + (long long)st * KT, st);
+  for (int kt = 0; kt < KTN; ++kt) {
+    const int newer = min(STAGES - 2, KTN - 1 - kt);
+    if (STAGES <= 2 || newer <= 0) AVEC_WAIT_VM(0);
+    else if (newer == 1) AVEC_WAIT_VM(LPT);
+    else AVEC_WAIT_VM(2 * LPT);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < KTN) issue(mb + (long long)(kt + STAGES - 1) * KT, (kt + STAGES - 1) % STAGES);
+    const char* S = smem + (kt % STAGES) * TILE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      chunk16 fa[MTI], fb[MTJ];
+#pragma unroll
+      for (int i = 0; i < MTI; ++i) fa[i] = tr_read8(S + offa[i][0] + kk * 16 * BI * 2, S + offa[i][1] + kk * 16 * BI * 2);
+#pragma unroll
+      for (int j = 0; j < MTJ; ++j) fb[j] = tr_read8(S + offb[j][0] + kk * 16 * BJ * 2, S + offb[j][1] + kk * 16 * BJ * 2);
+#pragma unroll
+      for (int i = 0; i < MTI; ++i)
+#pragma unroll
+        for (int j = 0; j < MTJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+#undef AVEC_WAIT_VM
+#pragma unroll
+  for (int j = 0; j < MTJ; ++j) {
+    const int col = j0 + wj * (BJ / 2) + j * 32 + (lane & 31);
+    if (col >= g.J) continue;
+#pragma unroll
+    for (int i = 0; i < MTI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi * (BI / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.I) atomicAdd(Op + (long long)row * g.ldo + col, acc[i][j][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host launchers (C ABI)
 // ------------------------------------------------------------------------------------------------
 #include <stdint.h>
@@ -702,6 +843,15 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   const bool f32src = q_f32 && sizeof(T) == 2;
   const bool a16 = nbatch == 1 && aligned16(g.P) && aligned16(g.q.ptr) && g.Iq % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
+  if (sizeof(T) == 2 && a16 && !f32src) {                   // bf16: LDS-DMA + transposed-read kernel
+    static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
+    if (use_tr) {
+      constexpr int STG = 2; const size_t l2 = (size_t)STG * 64 * (BI + BJ) * 2;
+#define LT(MODE) do { if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, STG>, l2)) return r; hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, STG>), grid, dim3(256), l2, st, g); return 0; } while (0)
+      if (mode == MODE_PLAIN) LT(MODE_PLAIN); else LT(MODE_CONV_FWD);
+#undef LT
+    }
+  }
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
