@@ -9,37 +9,12 @@
 //   fwd  : grid (ceil(T/32), B*H), lanes = keys (scores) then lanes = channels (P.V)
 //   bwd1 : dQ, same tiling as fwd
 //   bwd2 : dK, dV, dE; grid (key tiles, B*H, query segments of 64), lanes = keys, register accumulators
-#include "common.h"
-#include "avec_hip.h"
+#include "attention.h"
 
 static constexpr int TQ = 32;    // query rows per workgroup (fwd / bwd1): 4 waves x RPW rows
 static constexpr int RPW = TQ / 4;
 static constexpr int TK = 64;    // keys per tile = one per lane
 static constexpr int QC = 32;    // queries staged per chunk in the column pass (dK/dV/dE)
-
-struct AttnArgs {
-  const void *q, *k, *v; long long ld;      // act, row stride (elements); head h occupies columns [h*d, (h+1)*d)
-  const void* e; long long lde;             // act [2T-1][lde]
-  const long long* lens; int len_div;       // key j kept iff j < lens[b] / len_div  (null: all kept)
-  int q_full;                               // query rows i >= q_full see every key masked (the zero-padded last patch, nnet/attentions.py:152-154,357-362)
-  const float* mask; long long mask_bstride; // optional dense mask [Bm][T][T] (1 = keep); overrides lens
-  void* o; long long ldo;                    // act [B*T][ldo]
-  float* lse;                                // [B*H][T][2] = (row max m, row sum l): kept apart, m + log l loses log l when every key is masked (m = -1e9)
-  const void* dout;                          // act [B*T][ldo]   (backward)
-  void *dq, *dk, *dv; long long lddq, ldd;   // dq: act, row stride lddq; dk/dv: row stride ldd
-  float* de; long long ldde;                 // fp32 [2T-1][ldde], atomically accumulated
-  void *pbuf, *dsbuf; long long ldt;         // backward scratch, act [B*H][T][ldt]: probabilities and dS (written by the dQ pass)
-  void* dsrel; long long ldr;                // optional act [H][B*T][ldr]: dS re-indexed by E row r = j + (T-1) - i (zero elsewhere; caller zero-fills)
-  int B, H, T, d; float scale;
-};
-
-template <typename T>
-__device__ __forceinline__ bool key_keep(const AttnArgs& a, int b, int i, int j) {
-  if (a.mask) return a.mask[(long long)b * a.mask_bstride + (long long)i * a.T + j] != 0.f;
-  if (i >= a.q_full) return false;
-  if (a.lens) return j < (int)(a.lens[b] / a.len_div);
-  return true;
-}
 
 // cooperative load of `rows` rows x d channels (act dtype -> fp32 LDS, zero outside [0, limit)).
 // VW elements per access: 16 B when the head width allows it (d % 8 == 0 for bf16, d % 4 == 0 for fp32), 4/8 B for even d,
@@ -288,6 +263,7 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
 
 extern "C" int avec_relpos_attention_fwd(int dtype, const avec_attn_t* p, hipStream_t st) {
   AttnArgs a; AVEC_CHECK_ARG(p, "attention_fwd: null args"); if (int r = fill_args(a, p)) return r;
+  if (dtype == AVEC_BF16) { const int r = attn_mfma_fwd(a, st); if (r != 1) return r; }      // MFMA path; 1 = not applicable, fall through
   const int DP = a.d | 1; size_t lds = (size_t)(2 * TK + (TQ + TK - 1) + TQ) * DP * 4 + 4 * 64 * 4;
   dim3 grid((a.T + TQ - 1) / TQ, a.B * a.H);
   if (dtype == AVEC_BF16) { if (int r = set_lds(attn_rows_kernel<bf16, false>, lds)) return r; hipLaunchKernelGGL((attn_rows_kernel<bf16, false>), grid, dim3(256), lds, st, a); }
