@@ -275,8 +275,12 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
   const int DP = a.d | 1;
   size_t lds1 = (size_t)(2 * TK + (TQ + TK - 1) + 2 * TQ) * DP * 4 + 4 * 64 * 4;
   dim3 grid1((a.T + TQ - 1) / TQ, a.B * a.H);
-  if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
-  hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
+  bool rows_done = false;
+  if (sizeof(T) == 2) { const int r = attn_mfma_bwd_rows(a, st); if (r == 0) rows_done = true; else if (r != 1) return r; }   // bf16 MFMA row pass
+  if (!rows_done) {
+    if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
+    hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
+  }
   if (a.dsrel) return 0;            // dK/dV/dE are computed by the caller with avec_gemm_tn_batched on P / dS / dSrel (MFMA path)
   size_t lds2 = (size_t)(2 * QC + 2 * 64) * DP * 4;
   const int ktiles = (a.T + 63) / 64, rtiles = (2 * a.T - 1 + 63) / 64;

@@ -66,39 +66,16 @@ static MfmaGeom mfma_geom(int T, int d, int pitch, bool bwd) {
   return g;
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------
+// S^T tiles of one wave: S[jt][r] = scale * (K_j.Q_i + E_{T-1-i+j}.Q_i) (+ -1e9 on masked keys, -inf beyond T) for key
+// j = 32 jt + (r&3) + 8 (r>>2) + 4 hf and query il = lane & 31; returns this lane-half's running maximum.
 template <int PITCH>
-__global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];
-  char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5, il = lane & 31;
-  float* ring = (float*)(sm + G.offS + w * 8192);
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int Tn = a.T, d = a.d, i0 = blockIdx.x * 64;
-  const bf16* qp = (const bf16*)a.q + (long long)b * Tn * a.ld + h * d;
-  const bf16* kp = (const bf16*)a.k + (long long)b * Tn * a.ld + h * d;
-  const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
-  const bf16* ep = (const bf16*)a.e + h * d;
-  stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
-  stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
-  __syncthreads();
-
-  const int i = i0 + 32 * w + il;                        // this lane's query
-  const int swr = aswz<PITCH>(il);                       // swizzle of operand row (tile base is a multiple of 32: same bits)
-  const char* qrow = Qs + (32 * w + il) * PITCH;
-  const int klen = a.lens ? (int)(a.lens[b] / a.len_div) : Tn;
-  const bool row_masked = i >= a.q_full;
-
-  f32x16 S[NTMAX];
+__device__ __forceinline__ float scores(f32x16 (&S)[NTMAX], const char* Ks, const char* Es, const char* qrow, float* ring, const MfmaGeom& G, float scale,
+                                        int w, int il, int hf, int Tn, int klen, bool row_masked) {
+  const int swr = aswz<PITCH>(il);                       // swizzle of operand row (tile bases are multiples of 32: same bits)
 #pragma unroll
   for (int jt = 0; jt < NTMAX; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[jt][r] = 0.f;
-
   // R^T tile et -> ring slot et & 1 (rows e_local = 32 et + ..., this wave's window starts 32 (1 - w) rows into the staged E window)
   auto rel_tile = [&](int et) {
     f32x16 R;
@@ -125,17 +102,16 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
         S[jt] = mma(fa, fb, S[jt]);
       }
       rel_tile(jt + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring writes of this wave are visible to its own reads (LDS is in-order per wave)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS is in-order per wave: the ring writes above are visible to the reads below
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = (r & 3) + 8 * (r >> 2) + 4 * hf;            // key within the tile
-        const int el = 32 * jt + jl + 31 - il;                     // window row; ring holds rows [32 jt, 32 jt + 64)
+        const int el = 32 * jt + jl + 31 - il;                     // window row; the ring holds rows [32 jt, 32 jt + 64)
         S[jt][r] += ring[(el & 63) * 32 + il];
       }
       asm volatile("" ::: "memory");
     }
   }
-  // scale, masks, softmax over keys (registers + the other half-wave)
   float mx = -INFINITY;
 #pragma unroll
   for (int jt = 0; jt < NTMAX; ++jt) {
@@ -143,13 +119,85 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-        float s = S[jt][r] * a.scale;
-        if (row_masked || j >= klen) s += -1e9f;
-        s = j < Tn ? s : -INFINITY;
-        S[jt][r] = s; mx = fmaxf(mx, s);
+        float v = S[jt][r] * scale;
+        if (row_masked || j >= klen) v += -1e9f;
+        v = j < Tn ? v : -INFINITY;
+        S[jt][r] = v; mx = fmaxf(mx, v);
       }
     }
   }
+  return mx;
+}
+
+// transposed-read operand offsets of a [rows][PITCH] image for channel tile ct: lane (16-lane group g4, t) fetches rows 8 hh + 4 (g4>>1) + (t>>2)
+template <int PITCH>
+__device__ __forceinline__ void tr_offsets(int (&off)[CTMAX][2], int lane) {
+  const int g4 = lane >> 4, t = lane & 15;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int key = 8 * hh + 4 * (g4 >> 1) + (t >> 2);   // + a multiple of 16: the swizzle bits of the row do not change
+#pragma unroll
+    for (int ct = 0; ct < CTMAX; ++ct) {
+      const int cb = 32 * ct + 16 * (g4 & 1);
+      off[ct][hh] = key * PITCH + ((((cb >> 3) + ((t & 3) >> 1)) ^ aswz<PITCH>(key)) << 4) + (t & 1) * 8;
+    }
+  }
+}
+
+// stage a [32 queries][d] fp32 register tile held as O^T (channel tiles x 16 registers) through the wave's ring and store its rows coalesced
+__device__ __forceinline__ void store_rows_T(const f32x16 (&O)[CTMAX], float mul, float* ring, const MfmaGeom& G, bf16* op, long long ldo, int nrow, int d, int lane) {
+  const int hf = lane >> 5, il = lane & 31;
+  bf16* ost = (bf16*)ring; const int OP = G.dpad + 4;          // 8 KB ring >= 32 * (96 + 4) * 2 B
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ct = 0; ct < CTMAX; ++ct) {
+    if (ct < G.CT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * ct + 8 * q + 4 * hf;
+        uint2 u; u.x = pack2(O[ct][4 * q] * mul, O[ct][4 * q + 1] * mul); u.y = pack2(O[ct][4 * q + 2] * mul, O[ct][4 * q + 3] * mul);
+        if (c0 < G.dpad) *(uint2*)(ost + il * OP + c0) = u;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const bool pair = (d & 1) == 0 && (((size_t)op | ((size_t)ldo * 2)) & 3) == 0;
+  if (pair) {
+    const int dh = d >> 1;
+    for (int idx = lane; idx < nrow * dh; idx += 64) { const int r = idx / dh, c = (idx - r * dh) * 2; *(uint32_t*)(op + (long long)r * ldo + c) = *(const uint32_t*)(ost + r * OP + c); }
+  } else {
+    for (int idx = lane; idx < nrow * d; idx += 64) { const int r = idx / d, c = idx - r * d; op[(long long)r * ldo + c] = ost[r * OP + c]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int PITCH>
+__global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5, il = lane & 31;
+  float* ring = (float*)(sm + G.offS + w * 8192);
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int Tn = a.T, d = a.d, i0 = blockIdx.x * 64;
+  const bf16* qp = (const bf16*)a.q + (long long)b * Tn * a.ld + h * d;
+  const bf16* kp = (const bf16*)a.k + (long long)b * Tn * a.ld + h * d;
+  const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
+  const bf16* ep = (const bf16*)a.e + h * d;
+  stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
+  stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
+  __syncthreads();
+
+  const int i = i0 + 32 * w + il;                        // this lane's query
+  const char* qrow = Qs + (32 * w + il) * PITCH;
+  const int klen = a.lens ? (int)(a.lens[b] / a.len_div) : Tn;
+  const bool row_masked = i >= a.q_full;
+
+  f32x16 S[NTMAX];
+  float mx = scores<PITCH>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float lsum = 0.f;
 #pragma unroll
@@ -168,17 +216,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   for (int ct = 0; ct < CTMAX; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
-  const int g4 = lane >> 4, t = lane & 15;
-  int offv[CTMAX][2];
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const int key = 8 * hh + 4 * (g4 >> 1) + (t >> 2);   // + 32 jt + 16 s: the swizzle bits of the key do not change
-#pragma unroll
-    for (int ct = 0; ct < CTMAX; ++ct) {
-      const int cb = 32 * ct + 16 * (g4 & 1);
-      offv[ct][hh] = key * PITCH + ((((cb >> 3) + ((t & 3) >> 1)) ^ aswz<PITCH>(key)) << 4) + (t & 1) * 8;
-    }
-  }
+  int offv[CTMAX][2]; tr_offsets<PITCH>(offv, lane);
 #pragma unroll
   for (int jt = 0; jt < NTMAX; ++jt) {
     if (jt < G.NT) {
@@ -193,31 +231,153 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
       }
     }
   }
-  // stage O (bf16, [il][c]) through this wave's ring, then coalesced row stores
-  const float inv = 1.f / lsum;
-  bf16* ost = (bf16*)ring; const int OP = G.dpad + 4;          // 8 KB ring >= 32 * (128 + 4) * 2 B
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  bf16* op = (bf16*)a.o + ((long long)b * Tn + i0 + 32 * w) * a.ldo + h * d;
+  store_rows_T(O, 1.f / lsum, ring, G, op, a.ldo, min(32, Tn - (i0 + 32 * w)), d, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, row pass: P and dS (stored for the batched dK / dV / dE GEMMs) and dQ
+//     dP^T[j][i] = V_j . dO_i ;  dS^T = P^T o (dP^T - delta_i) * scale ;  dQ^T = K^T dS^T + E_win^T unskew(dS^T)
+// ------------------------------------------------------------------------------------------------
+template <int PITCH>
+__global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom G) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ; char* Gs = Qs + 64 * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5, il = lane & 31;
+  float* ring = (float*)(sm + G.offS + w * 8192);
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int Tn = a.T, d = a.d, i0 = blockIdx.x * 64;
+  const bf16* qp = (const bf16*)a.q + (long long)b * Tn * a.ld + h * d;
+  const bf16* kp = (const bf16*)a.k + (long long)b * Tn * a.ld + h * d;
+  const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
+  const bf16* ep = (const bf16*)a.e + h * d;
+  const bf16* gp = (const bf16*)a.dout + (long long)b * Tn * a.ldo + h * d;
+  stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
+  stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
+  stage_rows<PITCH, 128>(Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad);
+  __syncthreads();
+
+  const int i = i0 + 32 * w + il;
+  const int swr = aswz<PITCH>(il);
+  const char* qrow = Qs + (32 * w + il) * PITCH; const char* grow = Gs + (32 * w + il) * PITCH;
+  const int klen = a.lens ? (int)(a.lens[b] / a.len_div) : Tn;
+  const bool row_masked = i >= a.q_full, iv = i < Tn;
+  // delta_i = dO_i . O_i  (each lane-half takes half of the channels)
+  float delta = 0.f, m_i = 0.f, il_i = 0.f;
+  if (iv) {
+    const bf16* orow = (const bf16*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
+    const int c0 = hf * ((d + 1) >> 1), c1 = hf ? d : ((d + 1) >> 1);
+    for (int c = c0; c < c1; ++c) {
+      const int ch = c >> 3; const bf16* gq = (const bf16*)(grow + ((ch ^ swr) << 4)) + (c & 7);
+      delta += bf16_to_f32(gq->v) * bf16_to_f32(orow[c].v);
+    }
+    m_i = a.lse[((long long)bh * Tn + i) * 2]; il_i = 1.f / a.lse[((long long)bh * Tn + i) * 2 + 1];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+
+  f32x16 S[NTMAX];
+  scores<PITCH>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  bf16* prow = (bf16*)a.pbuf + ((long long)bh * Tn + i) * a.ldt;
+  bf16* srow = (bf16*)a.dsbuf + ((long long)bh * Tn + i) * a.ldt;
+  bf16* rrow = a.dsrel ? (bf16*)a.dsrel + ((long long)h * a.B * Tn + (long long)b * Tn + i) * a.ldr + (Tn - 1 - i) : nullptr;
+  const bool st8 = (a.ldt & 3) == 0 && ((((size_t)a.pbuf) | ((size_t)a.dsbuf)) & 7) == 0;
 #pragma unroll
-  for (int ct = 0; ct < CTMAX; ++ct) {
-    if (ct < G.CT) {
+  for (int jt = 0; jt < NTMAX; ++jt) {
+    if (jt < G.NT) {
+      f32x16 dP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dP[r] = 0.f;
+      const char* vrow = Vs + (32 * jt + il) * PITCH;
+      for (int kk = 0; kk < G.DKS; ++kk) {
+        const chunk16 fa = *(const chunk16*)(vrow + (((2 * kk + hf) ^ swr) << 4));
+        const chunk16 fb = *(const chunk16*)(grow + (((2 * kk + hf) ^ swr) << 4));
+        dP = mma(fa, fb, dP);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * ct + 8 * q + 4 * hf;
-        uint2 u; u.x = pack2(O[ct][4 * q] * inv, O[ct][4 * q + 1] * inv); u.y = pack2(O[ct][4 * q + 2] * inv, O[ct][4 * q + 3] * inv);
-        if (c0 < G.dpad) *(uint2*)(ost + il * OP + c0) = u;
+        const int j0 = 32 * jt + 8 * q + 4 * hf;
+        float pv[4], dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e; const bool ok = iv && (j0 + e) < Tn;
+          const float p = ok ? __expf(S[jt][r] - m_i) * il_i : 0.f;
+          pv[e] = p; dv[e] = p * (dP[r] - delta) * a.scale; S[jt][r] = dv[e];
+        }
+        if (iv && j0 < Tn) {
+          if (st8 && j0 + 3 < Tn) {
+            uint2 up, ud; up.x = pack2(pv[0], pv[1]); up.y = pack2(pv[2], pv[3]); ud.x = pack2(dv[0], dv[1]); ud.y = pack2(dv[2], dv[3]);
+            *(uint2*)(prow + j0) = up; *(uint2*)(srow + j0) = ud;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (j0 + e < Tn) { prow[j0 + e].v = f32_to_bf16(pv[e]); srow[j0 + e].v = f32_to_bf16(dv[e]); }
+          }
+          if (rrow) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (j0 + e < Tn) rrow[j0 + e].v = f32_to_bf16(dv[e]);
+          }
+        }
       }
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  bf16* op = (bf16*)a.o + ((long long)b * Tn + i0 + 32 * w) * a.ldo + h * d;
-  const int nrow = min(32, Tn - (i0 + 32 * w));
-  const bool pair = (d & 1) == 0 && (((size_t)op | ((size_t)a.ldo * 2)) & 3) == 0;
-  if (pair) {
-    const int dh = d >> 1;
-    for (int idx = lane; idx < nrow * dh; idx += 64) { const int r = idx / dh, c = (idx - r * dh) * 2; *(uint32_t*)(op + (long long)r * a.ldo + c) = *(const uint32_t*)(ost + r * OP + c); }
-  } else {
-    for (int idx = lane; idx < nrow * d; idx += 64) { const int r = idx / d, c = idx - r * d; op[(long long)r * a.ldo + c] = ost[r * OP + c]; }
+  // dQ^T = K^T dS^T   (A = K^T via transposed reads, B = dS^T registers)
+  f32x16 DQ[CTMAX];
+#pragma unroll
+  for (int ct = 0; ct < CTMAX; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) DQ[ct][r] = 0.f;
+  int offt[CTMAX][2]; tr_offsets<PITCH>(offt, lane);
+#pragma unroll
+  for (int jt = 0; jt < NTMAX; ++jt) {
+    if (jt < G.NT) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        chunk16 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pb.w[e] = pack2(S[jt][8 * s + 2 * e], S[jt][8 * s + 2 * e + 1]);
+        const char* kb = Ks + (32 * jt + 16 * s) * PITCH;
+#pragma unroll
+        for (int ct = 0; ct < CTMAX; ++ct) if (ct < G.CT) DQ[ct] = mma(tr8(kb + offt[ct][0], kb + offt[ct][1]), pb, DQ[ct]);
+      }
+    }
   }
+  // relative term: window row e_local of query il pairs with key j = e_local - 31 + il: un-skew dS^T through the ring (tile jt -> slot jt & 1,
+  // "tile -1" and tile NT are zero), one window tile at a time, and multiply by E_win^T
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ring[1024 + ((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + il] = 0.f;     // slot 1 = tile -1
+#pragma unroll
+  for (int et = 0; et <= NTMAX; ++et) {
+    if (et <= G.NT) {
+      float* slot = ring + (et & 1) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+        if (et < NTMAX) v = (et < G.NT) ? S[et < NTMAX ? et : 0][r] : 0.f;
+        slot[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + il] = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float rs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * et + (r & 3) + 8 * (r >> 2) + 4 * hf - 31 + il;      // in [32 et - 31, 32 et + 31]: tiles et - 1 and et
+        rs[r] = ring[(j & 63) * 32 + il];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        chunk16 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pb.w[e] = pack2(rs[8 * s + 2 * e], rs[8 * s + 2 * e + 1]);
+        const char* eb = Es + (32 * et + 32 * (1 - w) + 16 * s) * PITCH;
+#pragma unroll
+        for (int ct = 0; ct < CTMAX; ++ct) if (ct < G.CT) DQ[ct] = mma(tr8(eb + offt[ct][0], eb + offt[ct][1]), pb, DQ[ct]);
+      }
+    }
+  }
+  bf16* dqp = (bf16*)a.dq + ((long long)b * Tn + i0 + 32 * w) * a.lddq + h * d;
+  store_rows_T(DQ, 1.f, ring, G, dqp, a.lddq, min(32, Tn - (i0 + 32 * w)), d, lane);
 }
 
 static const bool g_mfma_off = getenv("AVEC_NO_MFMA_ATTN") != nullptr;
@@ -242,4 +402,13 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
-int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) { (void)a; (void)st; return 1; }
+int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) {
+  if (g_mfma_off || a.mask || a.d > 96 || a.T > 32 * NTMAX || !a.pbuf || !a.dsbuf || !a.dq || !a.dout) return 1;
+  const int pitch = a.d <= 64 ? 128 : 256;
+  const MfmaGeom G = mfma_geom(a.T, a.d, pitch, true);
+  if (G.total > 160 * 1024) return 1;
+  dim3 grid((a.T + 63) / 64, a.B * a.H);
+  if (pitch == 128) { if (int r = mfma_set_lds(attn_mfma_bwd_kernel<128>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_bwd_kernel<128>, grid, dim3(128), G.total, st, a, G); }
+  else { if (int r = mfma_set_lds(attn_mfma_bwd_kernel<256>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_bwd_kernel<256>, grid, dim3(128), G.total, st, a, G); }
+  AVEC_LAUNCH_CHECK(); return 0;
+}
