@@ -132,7 +132,7 @@ struct Epi {
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
 };
 
-struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; };
+struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv; };   // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -368,6 +368,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   for (int i = 0; i < NCA; ++i) { const int row = (tid >> 3) + i * 32; ra[i] = row_info<MODE>(g.a, m0 + row, g.M); ka[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) { const int row = (tid >> 3) + i * 32; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
+  // fast convolution addressing (host-checked: C % KE == 0 so a K-step lies inside one tap, <= 32 taps, < 2^31 source elements, backward
+  // only with stride 1): per row a 32-bit origin offset and a bit mask of the taps that fall inside the image; per K-step the tap and its
+  // offset are wave-uniform, so a chunk address costs an add and a select instead of the bounds arithmetic of conv_offset().
+  int rofs[NCA]; unsigned rmask[NCA];
+  const bool fast = MODE != MODE_PLAIN && g.fast_conv;
+  if (MODE != MODE_PLAIN && fast) {
+    const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;      // row pitch of the source image
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int sgn = MODE == MODE_CONV_FWD ? 1 : -1;
+      rofs[i] = (int)ra[i].base + (ra[i].a * IW + ra[i].b) * g.a.C + ka[i];
+      unsigned mk = 0u;
+      for (int kh = 0; kh < g.a.KH; ++kh)
+        for (int kw = 0; kw < g.a.KW; ++kw) {
+          const int y = ra[i].a + sgn * kh, x = ra[i].b + sgn * kw;
+          const bool ok = ra[i].valid && y >= 0 && x >= 0 && y < (MODE == MODE_CONV_FWD ? g.a.H : g.a.OH) && x < (MODE == MODE_CONV_FWD ? g.a.W : g.a.OW);
+          mk |= (ok ? 1u : 0u) << (kh * g.a.KW + kw);
+        }
+      rmask[i] = mk;
+    }
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -387,7 +408,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
       const int k = kt * KE + ka[i];
       long long off;
       if (MODE == MODE_PLAIN) off = (ra[i].valid && k < g.K) ? ra[i].base + k : -1;
-      else {
+      else if (fast) {
+        const int k0 = kt * KE; const int tap = k0 / g.a.C; const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;     // wave-uniform
+        const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
+        const int tapoff = (MODE == MODE_CONV_FWD ? (kh * IW + kw) : -(kh * IW + kw)) * g.a.C + (k0 - tap * g.a.C);
+        off = ((rmask[i] >> tap) & 1u) ? (long long)(rofs[i] + tapoff) : -1;
+      } else {
         int tap, c;
         if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + ka[i]; } else { tap = k / g.a.C; c = k - tap * g.a.C; }
         const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
@@ -811,6 +837,15 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   AVEC_CHECK_ARG(a_mode == AVEC_ROWS_PLAIN || (a_rows->C % vec == 0 && K == a_rows->KH * a_rows->KW * a_rows->C),
                  "gemm_nt: conv C=%d must be a multiple of %d and K = KH*KW*C", a_rows->C, vec);
   GemmArgs g; g.a = make_src(A, a_rows); g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+  g.fast_conv = 0;
+  if (a_mode != AVEC_ROWS_PLAIN) {
+    const int KE = dtype == AVEC_BF16 ? 64 : 32;
+    const long long imgs = a_mode == MODE_CONV_FWD ? (M + (long long)a_rows->OH * a_rows->OW - 1) / ((long long)a_rows->OH * a_rows->OW) : (M + (long long)a_rows->H * a_rows->W - 1) / ((long long)a_rows->H * a_rows->W);
+    const long long src_elems = imgs * (a_mode == MODE_CONV_FWD ? (long long)a_rows->H * a_rows->W : (long long)a_rows->OH * a_rows->OW) * a_rows->C;
+    static const bool no_fast = getenv("AVEC_NO_FAST_CONV") != nullptr;
+    g.fast_conv = !no_fast && a_rows->C % KE == 0 && a_rows->KH * a_rows->KW <= 32 && src_elems + (long long)(a_rows->W + a_rows->OW + 2) * a_rows->C * 4 < (1ll << 31) &&
+                  (a_mode == MODE_CONV_FWD || a_rows->stride == 1);
+  }
   Epi& e = g.e;
   e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
   e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
