@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char avec_zero16[64];
 
-template <typename T, int BM, int BN, int MODE, int STAGES>
+template <typename T, int BM, int BN, int MODE, int STAGES, bool FASTC = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = BKB / (int)sizeof(T);
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   // only with stride 1): per row a 32-bit origin offset and a bit mask of the taps that fall inside the image; per K-step the tap and its
   // offset are wave-uniform, so a chunk address costs an add and a select instead of the bounds arithmetic of conv_offset().
   int rofs[NCA]; unsigned rmask[NCA];
-  const bool fast = MODE != MODE_PLAIN && g.fast_conv;
-  if (MODE != MODE_PLAIN && fast) {
+  constexpr bool fast = MODE != MODE_PLAIN && FASTC;
+  if (fast) {
     const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;      // row pitch of the source image
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
@@ -401,19 +401,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int KT = (g.K + KE - 1) / KE;
+  int f_tap = 0, f_kh = 0, f_kw = 0, f_c0 = 0;       // fast path: running (tap, kh, kw, channel offset) of the next K-step to be issued (issue() is called with kt = 0, 1, 2, ...)
   auto issue = [&](int kt, int buf) {
     char* As = smem + buf * TILE; char* Bs = As + BM * 128;
+    if (fast) {
+      const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
+      const int tapoff = (MODE == MODE_CONV_FWD ? (f_kh * IW + f_kw) : -(f_kh * IW + f_kw)) * g.a.C + f_c0;
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        const T* sp = (const T*)g.a.ptr + (rofs[i] + tapoff);
+        const void* src = ((rmask[i] >> f_tap) & 1u) ? (const void*)sp : (const void*)avec_zero16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+      f_c0 += KE;
+      if (f_c0 >= g.a.C) { f_c0 = 0; ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } }
+    } else {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int k = kt * KE + ka[i];
       long long off;
       if (MODE == MODE_PLAIN) off = (ra[i].valid && k < g.K) ? ra[i].base + k : -1;
-      else if (fast) {
-        const int k0 = kt * KE; const int tap = k0 / g.a.C; const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;     // wave-uniform
-        const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
-        const int tapoff = (MODE == MODE_CONV_FWD ? (kh * IW + kw) : -(kh * IW + kw)) * g.a.C + (k0 - tap * g.a.C);
-        off = ((rmask[i] >> tap) & 1u) ? (long long)(rofs[i] + tapoff) : -1;
-      } else {
+      else {
         int tap, c;
         if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + ka[i]; } else { tap = k / g.a.C; c = k - tap * g.a.C; }
         const int kh = tap / g.a.KW, kw = tap - kh * g.a.KW;
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
       }
       const void* src = off >= 0 ? (const void*)((const T*)g.a.ptr + off) : (const void*)avec_zero16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
@@ -642,7 +651,7 @@ __device__ __forceinline__ chunk16 tr_read8(const char* p0, const char* p1) {
 }
 template <int BC> __device__ __forceinline__ int tr_swz(int row) { return BC == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
-template <int BI, int BJ, int MODE, int STAGES>
+template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false>      // Q32: the im2col source has < 2^31 elements: 32-bit offsets
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
   typedef bf16 T;
   constexpr int KT = 64;                                       // reduction rows per tile
@@ -700,8 +709,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
       const void* src = (const void*)avec_zero16;
       if (Q_CONV) {
         const int ih = qoh[u] * g.q.stride - g.q.pad + qkh, iw = qow[u] * g.q.stride - g.q.pad + qkw;
-        const bool ok = qok && m < me && ih >= 0 && ih < g.q.H && iw >= 0 && iw < g.q.W;
-        const T* sp = Qp + qimg[u] + (ih * g.q.W + iw) * g.q.C + qc;
+        const bool ok = qok && m < me && (unsigned)ih < (unsigned)g.q.H && (unsigned)iw < (unsigned)g.q.W;
+        const T* sp = Q32 ? Qp + ((int)qimg[u] + (ih * g.q.W + iw) * g.q.C + qc) : Qp + qimg[u] + (ih * g.q.W + iw) * g.q.C + qc;
         src = ok ? (const void*)sp : src;
         qow[u] += KT;                                            // advance this row by one reduction tile
         while (qow[u] >= g.q.OW) { qow[u] -= g.q.OW; if (++qoh[u] >= g.q.OH) { qoh[u] = 0; qimg[u] += (long long)g.q.H * g.q.W * g.q.C; } }
@@ -800,7 +809,8 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
   constexpr int STG = (BM + BN) <= 128 ? 4 : 2;      // ring depth: deep for the small latency-bound tiles; the big tiles keep 3 workgroups per CU instead (measured)
 #define G(MODE) do { const size_t l2 = (size_t)STG * (BM + BN) * 128 > (size_t)64 * (BN + 4) * 4 + 10 * BN * 4 ? (size_t)STG * (BM + BN) * 128 : (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG>), grid, dim3(256), l2, st, g); return 0; } while (0)
+    if (MODE != MODE_PLAIN && g.fast_conv) { if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, true>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, true>), grid, dim3(256), l2, st, g); return 0; } \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, false>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, false>), grid, dim3(256), l2, st, g); return 0; } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
   if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G
@@ -882,8 +892,9 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
     static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
     if (use_tr) {
       constexpr int STG = 2; const size_t l2 = (size_t)STG * 64 * (BI + BJ) * 2;
-#define LT(MODE) do { if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, STG>, l2)) return r; hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, STG>), grid, dim3(256), l2, st, g); return 0; } while (0)
-      if (mode == MODE_PLAIN) LT(MODE_PLAIN); else LT(MODE_CONV_FWD);
+#define LT(MODE, Q32) do { if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, STG, Q32>, l2)) return r; hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, STG, Q32>), grid, dim3(256), l2, st, g); return 0; } while (0)
+      const long long q_elems = mode == MODE_PLAIN ? 0 : ((g.M + (long long)g.q.OH * g.q.OW - 1) / ((long long)g.q.OH * g.q.OW) + 1) * g.q.H * g.q.W * g.q.C;
+      if (mode == MODE_PLAIN) LT(MODE_PLAIN, false); else if (q_elems < (1ll << 31)) LT(MODE_CONV_FWD, true); else LT(MODE_CONV_FWD, false);
 #undef LT
     }
   }
