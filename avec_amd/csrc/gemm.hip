@@ -651,10 +651,9 @@ __device__ __forceinline__ chunk16 tr_read8(const char* p0, const char* p1) {
 }
 template <int BC> __device__ __forceinline__ int tr_swz(int row) { return BC == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
-template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false>      // Q32: the im2col source has < 2^31 elements: 32-bit offsets
+template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false, int KT = 64>      // Q32: the im2col source has < 2^31 elements: 32-bit offsets; KT: reduction rows per tile
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
   typedef bf16 T;
-  constexpr int KT = 64;                                       // reduction rows per tile
   constexpr int CPI = BI / 8, CPJ = BJ / 8;                    // 16-byte chunks per LDS row
   constexpr int RI = 256 / CPI, RJ = 256 / CPJ;                // rows covered by one DMA pass of the workgroup
   constexpr int NLI = KT / RI, NLJ = KT / RJ;                  // DMA instructions per thread per tile
@@ -749,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
     if (kt + STAGES - 1 < KTN) issue(mb + (long long)(kt + STAGES - 1) * KT, (kt + STAGES - 1) % STAGES);
     const char* S = smem + (kt % STAGES) * TILE;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KT / 16; ++kk) {
       chunk16 fa[MTI], fb[MTJ];
 #pragma unroll
       for (int i = 0; i < MTI; ++i) fa[i] = tr_read8(S + offa[i][0] + kk * 16 * BI * 2, S + offa[i][1] + kk * 16 * BI * 2);
@@ -891,10 +890,16 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   if (sizeof(T) == 2 && a16 && !f32src) {                   // bf16: LDS-DMA + transposed-read kernel
     static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
     if (use_tr) {
-      constexpr int STG = 2; const size_t l2 = (size_t)STG * 64 * (BI + BJ) * 2;
-#define LT(MODE, Q32) do { if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, STG, Q32>, l2)) return r; hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, STG, Q32>), grid, dim3(256), l2, st, g); return 0; } while (0)
+      // reduction rows per LDS tile: 32 (two 16 KB stages for 128x128) keeps 4 workgroups resident per CU; measured on the ResNet weight
+      // gradients 1.2-2.1x over 64-row tiles (2 per CU), and 4-stage rings (1 per CU) are 1.5-2x slower: occupancy hides the HBM latency
+      static const int kt_env = getenv("AVEC_TN_KT") ? atoi(getenv("AVEC_TN_KT")) : 32;
       const long long q_elems = mode == MODE_PLAIN ? 0 : ((g.M + (long long)g.q.OH * g.q.OW - 1) / ((long long)g.q.OH * g.q.OW) + 1) * g.q.H * g.q.W * g.q.C;
-      if (mode == MODE_PLAIN) LT(MODE_PLAIN, false); else if (q_elems < (1ll << 31)) LT(MODE_CONV_FWD, true); else LT(MODE_CONV_FWD, false);
+      const bool q32 = q_elems < (1ll << 31);
+#define LT(MODE, Q32, KT_) do { const size_t l2 = (size_t)2 * KT_ * (BI + BJ) * 2; if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>, l2)) return r; \
+        hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>), grid, dim3(256), l2, st, g); return 0; } while (0)
+#define LK(KT_) do { if (mode == MODE_PLAIN) LT(MODE_PLAIN, false, KT_); else if (q32) LT(MODE_CONV_FWD, true, KT_); else LT(MODE_CONV_FWD, false, KT_); } while (0)
+      if (kt_env == 64) LK(64); else LK(32);
+#undef LK
 #undef LT
     }
   }
