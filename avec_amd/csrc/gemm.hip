@@ -350,13 +350,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char avec_zero16[64];
 
-template <typename T, int BM, int BN, int MODE, int STAGES, bool FASTC = false>
+template <int RB> __device__ __forceinline__ int glds_swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+// RB: bytes of K per LDS row (128: 8 chunks, swizzle (row>>1)&7;  64: 4 chunks, swizzle (row>>2)&3 -- half the ring, twice the resident workgroups)
+template <typename T, int BM, int BN, int MODE, int STAGES, bool FASTC = false, int RB = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
-  constexpr int KE = BKB / (int)sizeof(T);
-  constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
+  constexpr int KE = RB / (int)sizeof(T);
+  constexpr int CPR = RB / 16, RPP = 256 / CPR;      // chunks per row, rows per DMA pass
+  constexpr int NCA = BM * CPR / 256, NCB = BN * CPR / 256;
   constexpr int MT = BM / 64, NT = BN / 64;
-  constexpr int TILE = (BM + BN) * 128;
+  constexpr int TILE = (BM + BN) * RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   RowInfo ra[NCA]; RowInfo rb[NCB]; int ka[NCA], kb[NCB];
   RowSrc ws; ws.ptr = g.W; ws.ld = g.ldw; ws.step = 0; ws.rows_out = ws.rows_in = 1;
 #pragma unroll
-  for (int i = 0; i < NCA; ++i) { const int row = (tid >> 3) + i * 32; ra[i] = row_info<MODE>(g.a, m0 + row, g.M); ka[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
+  for (int i = 0; i < NCA; ++i) { const int row = tid / CPR + i * RPP; ra[i] = row_info<MODE>(g.a, m0 + row, g.M); ka[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC; }
 #pragma unroll
-  for (int i = 0; i < NCB; ++i) { const int row = (tid >> 3) + i * 32; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = (((tid & 7) ^ ((row >> 1) & 7))) * VEC; }
+  for (int i = 0; i < NCB; ++i) { const int row = tid / CPR + i * RPP; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC; }
   // fast convolution addressing (host-checked: C % KE == 0 so a K-step lies inside one tap, <= 32 taps, < 2^31 source elements, backward
   // only with stride 1): per row a 32-bit origin offset and a bit mask of the taps that fall inside the image; per K-step the tap and its
   // offset are wave-uniform, so a chunk address costs an add and a select instead of the bounds arithmetic of conv_offset().
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   const int KT = (g.K + KE - 1) / KE;
   int f_tap = 0, f_kh = 0, f_kw = 0, f_c0 = 0;       // fast path: running (tap, kh, kw, channel offset) of the next K-step to be issued (issue() is called with kt = 0, 1, 2, ...)
   auto issue = [&](int kt, int buf) {
-    char* As = smem + buf * TILE; char* Bs = As + BM * 128;
+    char* As = smem + buf * TILE; char* Bs = As + BM * RB;
     if (fast) {
       const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
       const int tapoff = (MODE == MODE_CONV_FWD ? (f_kh * IW + f_kw) : -(f_kh * IW + f_kw)) * g.a.C + f_c0;
@@ -441,9 +445,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   // fragment addressing: lane (row = lane&31 within a 32-row block, k-half g = lane>>5), K-substep kk: logical chunk 2*kk + g
   int offa[MT], swa[MT], offb[NT], swb[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / 2) + i * 32 + (lane & 31); offa[i] = row * 128; swa[i] = (row >> 1) & 7; }
+  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / 2) + i * 32 + (lane & 31); offa[i] = row * RB; swa[i] = glds_swz<RB>(row); }
 #pragma unroll
-  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * 128; swb[j] = (row >> 1) & 7; }
+  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * RB; swb[j] = glds_swz<RB>(row); }
   const int gsel = lane >> 5;
 
   // STAGES-deep ring of LDS buffers, counted vmcnt waits, ONE raw barrier per K-step (the DMA stays in flight across barriers):
@@ -462,9 +466,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-    const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * 128;
+    const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * RB;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < RB / 32; ++kk) {
       chunk16 fa[MT], fb[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + offa[i] + (((kk * 2 + gsel) ^ swa[i]) << 4));
@@ -807,11 +811,19 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
   constexpr int STG = (BM + BN) <= 128 ? 4 : 2;      // ring depth: deep for the small latency-bound tiles; the big tiles keep 3 workgroups per CU instead (measured)
-#define G(MODE) do { const size_t l2 = (size_t)STG * (BM + BN) * 128 > (size_t)64 * (BN + 4) * 4 + 10 * BN * 4 ? (size_t)STG * (BM + BN) * 128 : (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; \
-    if (MODE != MODE_PLAIN && g.fast_conv) { if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, true>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, true>), grid, dim3(256), l2, st, g); return 0; } \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, false>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, false>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  static const bool rb_env_set = getenv("AVEC_NT_RB") != nullptr;
+  static const int rb_env = rb_env_set ? atoi(getenv("AVEC_NT_RB")) : 128;
+  const size_t epi_lds = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4;
+#define G2(MODE, FC, RB_) do { const size_t l2 = (size_t)STG * (BM + BN) * RB_ > epi_lds ? (size_t)STG * (BM + BN) * RB_ : epi_lds; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  // 64-byte rows (K-step 32): half the ring, 4 resident workgroups per CU instead of 2 -- measured +4..18 % on the implicit-GEMM layers with
+  // thousands of tiles, -16 % on the deep-K / few-tile ones (512-channel 3x3 stage): chosen by tile count.  AVEC_NT_RB=64/128 forces it.
+  const long long ntiles = (long long)grid.x * grid.y;
+  const bool rb64 = sizeof(T) == 2 && (rb_env_set ? rb_env == 64 : ntiles >= 1536);
+#define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
   if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
+#undef G2
 #undef G
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
@@ -936,7 +948,11 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   // (conv weight gradients, M ~ 1e5..1e6) amortise the atomics and prefer the more efficient 128x128 tile
   bool big = (I >= 128 && J >= 128) && ((long long)((I + 127) / 128) * ((J + 127) / 128) * nbatch >= 48 || M >= 32768);
   int r;
-  if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, nbatch, stream);
+  // narrow-I long reductions (64-channel conv layers, the stem): a 64x128 tile re-reads P half as often as 64x64 (these launches are bound by L2/HBM traffic)
+  const bool wide = !big && I <= 64 && J >= 128 && M >= 32768 && dtype == AVEC_BF16 && !q_f32 && nbatch == 1 && aligned16(P) && aligned16(Q) && Iq % 8 == 0 && Jq % 8 == 0 &&
+                    ldp % 8 == 0 && (q_mode != MODE_PLAIN || q_rows->ld % 8 == 0);      // (only the transposed-read kernel is instantiated for this shape in practice)
+  if (dtype == AVEC_BF16) r = big ? launch_tn_tile<bf16, 128, 128>(g, q_mode, q_f32, nbatch, stream) : wide ? launch_tn_tile<bf16, 64, 128>(g, q_mode, q_f32, nbatch, stream)
+                                                                                                    : launch_tn_tile<bf16, 64, 64>(g, q_mode, q_f32, nbatch, stream);
   else r = big ? launch_tn_tile<float, 128, 128>(g, q_mode, q_f32, nbatch, stream) : launch_tn_tile<float, 64, 64>(g, q_mode, q_f32, nbatch, stream);
   if (r) return r;
   AVEC_LAUNCH_CHECK();
