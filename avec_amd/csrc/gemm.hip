@@ -373,22 +373,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < NCB; ++i) { const int row = tid / CPR + i * RPP; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC; }
   // fast convolution addressing (host-checked: C % KE == 0 so a K-step lies inside one tap, <= 32 taps, < 2^31 source elements, backward
-  // only with stride 1): per row a 32-bit origin offset and a bit mask of the taps that fall inside the image; per K-step the tap and its
+  // with stride 1 or 2): per row a 32-bit origin offset and a bit mask of the taps that fall inside the image; per K-step the tap and its
   // offset are wave-uniform, so a chunk address costs an add and a select instead of the bounds arithmetic of conv_offset().
   int rofs[NCA]; unsigned rmask[NCA];
   constexpr bool fast = MODE != MODE_PLAIN && FASTC;
   if (fast) {
     const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;      // row pitch of the source image
+    // backward with stride 2: tap kh is valid iff (a - kh) is even and then oh = (a - kh)/2 = (a >> 1) - (kh >> 1): still linear in the tap
+    const int sh = (MODE == MODE_CONV_BWD && g.a.stride == 2) ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
-      const int sgn = MODE == MODE_CONV_FWD ? 1 : -1;
-      rofs[i] = (int)ra[i].base + (ra[i].a * IW + ra[i].b) * g.a.C + ka[i];
+      rofs[i] = (int)ra[i].base + ((ra[i].a >> sh) * IW + (ra[i].b >> sh)) * g.a.C + ka[i];
       unsigned mk = 0u;
       for (int kh = 0; kh < g.a.KH; ++kh)
         for (int kw = 0; kw < g.a.KW; ++kw) {
-          const int y = ra[i].a + sgn * kh, x = ra[i].b + sgn * kw;
-          const bool ok = ra[i].valid && y >= 0 && x >= 0 && y < (MODE == MODE_CONV_FWD ? g.a.H : g.a.OH) && x < (MODE == MODE_CONV_FWD ? g.a.W : g.a.OW);
-          mk |= (ok ? 1u : 0u) << (kh * g.a.KW + kw);
+          bool ok;
+          if (MODE == MODE_CONV_FWD) { const int y = ra[i].a + kh, x = ra[i].b + kw; ok = y >= 0 && x >= 0 && y < g.a.H && x < g.a.W; }
+          else { const int ty = ra[i].a - kh, tx = ra[i].b - kw; ok = ty >= 0 && tx >= 0 && !((ty | tx) & sh) && (ty >> sh) < g.a.OH && (tx >> sh) < g.a.OW; }
+          mk |= ((ok && ra[i].valid) ? 1u : 0u) << (kh * g.a.KW + kw);
         }
       rmask[i] = mk;
     }
@@ -410,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
     char* As = smem + buf * TILE; char* Bs = As + BM * RB;
     if (fast) {
       const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
-      const int tapoff = (MODE == MODE_CONV_FWD ? (f_kh * IW + f_kw) : -(f_kh * IW + f_kw)) * g.a.C + f_c0;
+      const int sh = (MODE == MODE_CONV_BWD && g.a.stride == 2) ? 1 : 0;
+      const int tapoff = (MODE == MODE_CONV_FWD ? (f_kh * IW + f_kw) : -((f_kh >> sh) * IW + (f_kw >> sh))) * g.a.C + f_c0;
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         const T* sp = (const T*)g.a.ptr + (rofs[i] + tapoff);
@@ -865,7 +868,7 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
     const long long src_elems = imgs * (a_mode == MODE_CONV_FWD ? (long long)a_rows->H * a_rows->W : (long long)a_rows->OH * a_rows->OW) * a_rows->C;
     static const bool no_fast = getenv("AVEC_NO_FAST_CONV") != nullptr;
     g.fast_conv = !no_fast && a_rows->C % KE == 0 && a_rows->KH * a_rows->KW <= 32 && src_elems + (long long)(a_rows->W + a_rows->OW + 2) * a_rows->C * 4 < (1ll << 31) &&
-                  (a_mode == MODE_CONV_FWD || a_rows->stride == 1);
+                  (a_mode == MODE_CONV_FWD || a_rows->stride == 1 || a_rows->stride == 2);
   }
   Epi& e = g.e;
   e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
