@@ -55,6 +55,32 @@ def cpu_baseline(budget_s=20.0):
             "sample": "oracle fwd+bwd, B=2 x %d iterations (best), fp32, %d host cores visible" % (len(times), os.cpu_count())}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 --pmc summary (profiles/r01_pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  None when the summary is absent or has no kernel of that family."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not family or not os.path.exists(path):
+        return None
+    want_tn = family.startswith("gemm_tn")
+    want_mode = {"plain": 0, "conv_fwd": 1, "conv_bwd_data": 2, "conv_wgrad": 1}.get(family[family.find("<") + 1:-1])
+    if want_mode is None:
+        return None
+    tot, n = 0.0, 0
+    for name, v in json.load(open(path))["kernels"].items():
+        m = re.match(r"void (gemm_nt_glds_kernel|gemm_nt_kernel|gemm_tn_kernel|gemm_tn_tr_kernel)<(.*)>\(", name)
+        if not m or m.group(1).startswith("gemm_tn") != want_tn:
+            continue
+        args = [a.strip() for a in m.group(2).split(",")]
+        mode = int(args[2] if m.group(1) == "gemm_tn_tr_kernel" else args[3])
+        if mode != want_mode:
+            continue
+        tot += v["launches"] * (v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0))
+        n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +166,9 @@ def main():
         value = utt / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         roof = ops.KERNEL_TIMER.summary(peak)
+        if roof is not None and args.dtype == "bf16" and args.batch == 32:
+            roof["traffic"] = pmc_traffic(roof["kernel"])
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
         out = {
             "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
