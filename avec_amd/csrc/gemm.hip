@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 // TN: O[i][j] += sum_m P[m][i] * Q[m][j];   P plain [M][I] (T), Q via row loader ([M][J], plain or im2col)
 // LDS images are [i][m] / [j][m] (reduction index contiguous) filled by transposing stores.
 // ------------------------------------------------------------------------------------------------
-struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block;   // Iq/Jq: load bounds (>= I/J when rows are padded)
+struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block; float* pcs;   // pcs: optional column sums of P (bias gradient), transposed-read kernel only
+                  // Iq/Jq: load bounds (>= I/J when rows are padded)
                 int split, nb_inner; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
 
 // LDS image of a TN operand: [col][word], word = reduction-row pair (bf16: rows 2p,2p+1 packed in 32 bits) or row (fp32), 32 words
@@ -740,6 +741,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
 #pragma unroll
     for (int j = 0; j < MTJ; ++j) { const int cb = wj * (BJ / 2) + j * 32 + 16 * (g4 & 1); offb[j][h] = PBYTES + row * (BJ * 2) + ((((cb >> 3) + ((t & 3) >> 1)) ^ tr_swz<BJ>(row)) << 4) + (t & 1) * 8; }
   }
+  // optional column sums of P (= bias gradient of the layer whose weight gradient this is), by the workgroups of the first J tile: lane =
+  // (physical chunk pc, row class r4 = m & 3, row subgroup rs); rows of one class share the swizzle, so a lane always sees the same 8 columns
+  constexpr int CS_RF = 64 / (CPI * 4), CS_N = (KT / 4) / (4 * CS_RF);
+  const bool do_cs = g.pcs != nullptr && blockIdx.y == 0;
+  const int cs_pc = lane % CPI, cs_r4 = (lane / CPI) & 3, cs_rs = lane / (CPI * 4);
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int LPT = NLI + NLJ;
 #define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
   const int KTN = (int)((me - mb + KT - 1) / KT);
@@ -754,6 +761,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < KTN) issue(mb + (long long)(kt + STAGES - 1) * KT, (kt + STAGES - 1) % STAGES);
     const char* S = smem + (kt % STAGES) * TILE;
+    if (do_cs) {
+#pragma unroll
+      for (int n = 0; n < CS_N; ++n) {
+        const int m = cs_r4 + 4 * (wave * CS_RF + cs_rs + 4 * CS_RF * n);
+        const chunk16 c = *(const chunk16*)(S + m * (BI * 2) + (cs_pc << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[2 * e] += __uint_as_float(c.w[e] << 16); cs[2 * e + 1] += __uint_as_float(c.w[e] & 0xffff0000u); }
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < KT / 16; ++kk) {
       chunk16 fa[MTI], fb[MTJ];
@@ -768,6 +784,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
     }
   }
 #undef AVEC_WAIT_VM
+  if (do_cs) {                                           // workgroup-uniform: reduce the 16 partials per column in LDS, then one global atomic per column
+    float* red = (float*)smem;
+    __syncthreads();                                     // the ring is free
+    if (tid < BI) red[tid] = 0.f;
+    __syncthreads();
+    const int cl = (cs_pc ^ tr_swz<BI>(cs_r4)) << 3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(red + cl + e, cs[e]);
+    __syncthreads();
+    if (tid < BI && i0 + tid < g.I) atomicAdd(g.pcs + i0 + tid, red[tid]);
+  }
 #pragma unroll
   for (int j = 0; j < MTJ; ++j) {
     const int col = j0 + wj * (BJ / 2) + j * 32 + (lane & 31);
@@ -918,6 +945,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
 #undef LT
     }
   }
+  if (g.pcs) { if (int r = avec_colsum(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, st)) return r; }     // kernels without the fused column sums
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
@@ -928,7 +956,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
 }
 
 static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
-                        float* O, long long ldo, long long M, int I, int J, int nb_outer, int nb_inner, const long long* strides, hipStream_t stream) {
+                        float* O, long long ldo, long long M, int I, int J, int nb_outer, int nb_inner, const long long* strides, float* p_colsum, hipStream_t stream) {
   AVEC_CHECK_ARG(dtype == AVEC_F32 || dtype == AVEC_BF16, "gemm_tn: bad dtype %d", dtype);
   AVEC_CHECK_ARG(P && Q && O && q_rows, "gemm_tn: null pointer");
   AVEC_CHECK_ARG(M > 0 && I > 0 && J > 0 && nb_outer > 0 && nb_inner > 0, "gemm_tn: bad dims");
@@ -941,7 +969,7 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   AVEC_CHECK_ARG(q_mode != MODE_PLAIN || dtype == AVEC_F32 || q_rows->ld % 2 == 0, "gemm_tn: ldq must be even");
   AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_rows->C % vec == 0, "gemm_tn: conv C=%d must be a multiple of %d", q_rows->C, vec);
   AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
-  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0;
+  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0; g.pcs = p_colsum;
   g.split = 1; g.nb_inner = nb_inner;
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
@@ -964,12 +992,17 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
 
 extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
                             float* O, long long ldo, long long M, int I, int J, hipStream_t stream) {
-  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, stream);
+  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, nullptr, stream);
+}
+extern "C" int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
+                                 float* O, long long ldo, float* p_colsum, long long M, int I, int J, hipStream_t stream) {
+  AVEC_CHECK_ARG(!p_colsum || (I % 4 == 0 && ldp % 4 == 0), "gemm_tn_bias: column sums need I %% 4 == 0 and ldp %% 4 == 0");
+  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, p_colsum, stream);
 }
 
 extern "C" int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                                     int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream) {
   avec_rows_t rows = {}; rows.ld = ldq;
   AVEC_CHECK_ARG(strides6, "gemm_tn_batched: null strides");
-  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, O, ldo, M, I, J, nb_outer, nb_inner, strides6, stream);
+  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, O, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
 }

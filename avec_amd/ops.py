@@ -114,13 +114,13 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     return out
 
 
-def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None):
-    """O[I][J] (fp32) += P[M][I]^T Q[M][J]"""
+def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None, p_colsum=None):
+    """O[I][J] (fp32) += P[M][I]^T Q[M][J];  optionally p_colsum[I] += column sums of P (the bias gradient, fused into the same launch)"""
     if q_rows is None:
         q_rows = rows_plain(J)
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-    lib.gemm_tn(rt.dt() if dtype is None else dtype, P.data_ptr(), I if ldp is None else ldp, Q.data_ptr(), _byref(q_rows), q_mode,
-                int(q_f32), O.data_ptr(), J if ldo is None else ldo, M, I, J, rt.stream())
+    lib.gemm_tn_bias(rt.dt() if dtype is None else dtype, P.data_ptr(), I if ldp is None else ldp, Q.data_ptr(), _byref(q_rows), q_mode,
+                     int(q_f32), O.data_ptr(), J if ldo is None else ldo, _p(p_colsum), M, I, J, rt.stream())
     if ev is not None:
         KERNEL_TIMER.stop(ev, (1, q_mode), 2.0 * M * I * J)
 
@@ -174,9 +174,10 @@ def linear_fwd(x2d, weight, bias, M, *, in_f32, out_f32, act=ACT_NONE, out_pre=N
     return out
 
 
-def linear_bwd_weight(dacc, x2d, weight, M, *, q_f32=False, q_rows=None, ldp=None):
+def linear_bwd_weight(dacc, x2d, weight, M, *, q_f32=False, q_rows=None, ldp=None, bias=None):
+    """dW += dacc^T x;  with `bias`: db += column sums of dacc, out of the same GEMM launch"""
     sh = rt.shadow(weight)
-    gemm_tn(dacc, x2d, grad_of(weight), M, sh.A, sh.Tm * sh.C, q_f32=q_f32, q_rows=q_rows, ldp=ldp)
+    gemm_tn(dacc, x2d, grad_of(weight), M, sh.A, sh.Tm * sh.C, q_f32=q_f32, q_rows=q_rows, ldp=ldp, p_colsum=None if bias is None else grad_of(bias))
 
 
 def linear_bwd_input(dacc, weight, M, *, out_f32, res=None, res_act=False, dact_z=None, dact=0, drop_p=0.0, sid=0, colsum_to=None, lda=None, out=None):
@@ -209,13 +210,8 @@ class LinearFn(torch.autograd.Function):
         N = weight.shape[0]
         dy = dy.reshape(M, N)
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        if out_f32:
-            dacc = grad_prep(dy, M, N, dbias=None if bias is None else grad_of(bias))
-        else:
-            dacc = dy
-            if bias is not None:
-                colsum(dacc, N, grad_of(bias), M, N)
-        linear_bwd_weight(dacc, x2, weight, M, q_f32=in_f32)
+        dacc = grad_prep(dy, M, N) if out_f32 else dy
+        linear_bwd_weight(dacc, x2, weight, M, q_f32=in_f32, bias=bias)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_bwd_input(dacc, weight, M, out_f32=in_f32).view(shp)
@@ -293,10 +289,10 @@ class FeedForwardFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp = ctx.saved
         dy = _f32c(dy.reshape(M, D))
-        dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2, dbias=grad_of(b2))
-        linear_bwd_weight(dacc, h1, w2, M)
-        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1, colsum_to=grad_of(b1))
-        linear_bwd_weight(dz, h0, w1, M)
+        dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2)
+        linear_bwd_weight(dacc, h1, w2, M, bias=b2)
+        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1)
+        linear_bwd_weight(dz, h0, w1, M, bias=b1)
         dh0 = linear_bwd_input(dz, w1, M, out_f32=False)
         dx = layernorm_bwd(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy)
         return (dx.view(shp),) + (None,) * 11
@@ -394,10 +390,9 @@ class AttentionModuleFn(torch.autograd.Function):
             doo = empty((Mp, D), adt, dy)
             rng = rt.rng_state(dy.device).data_ptr() if drop_p > 0 else None
             lib.patch_unpool_bwd(rt.dt(), dy.data_ptr(), doo.data_ptr(), drop_p, rng, sid, B, T, D, patch, rt.stream())
-            colsum(doo, D, grad_of(bo), Mp, D)
         else:
-            doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid, dbias=grad_of(bo))
-        linear_bwd_weight(doo, o, wo, Mp)
+            doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid)
+        linear_bwd_weight(doo, o, wo, Mp, bias=bo)
         do = linear_bwd_input(doo, wo, Mp, out_f32=False)
         dqkv = empty((Mp, 3 * D), adt, dy)
         de = torch.zeros((2 * Tp - 1, D), dtype=torch.float32, device=dy.device)
@@ -429,13 +424,11 @@ class AttentionModuleFn(torch.autograd.Function):
         dhp = None
         for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
             g = dqkv[:, i * D:]
-            colsum(g, 3 * D, grad_of(b), Mp, D)
-            linear_bwd_weight(g, hp, w, Mp, ldp=3 * D)
+            linear_bwd_weight(g, hp, w, Mp, ldp=3 * D, bias=b)
             dhp = linear_bwd_input(g, w, Mp, out_f32=False, lda=3 * D, res=dhp, res_act=True, out=dhp)
         dea = empty((2 * Tp - 1, D), adt, dy)
         lib.cast_rows(rt.dt(), de.data_ptr(), D, dea.data_ptr(), D, 2 * Tp - 1, D, rt.stream())
-        colsum(dea, D, grad_of(bp), 2 * Tp - 1, D)
-        linear_bwd_weight(dea, pe, wp, 2 * Tp - 1)
+        linear_bwd_weight(dea, pe, wp, 2 * Tp - 1, bias=bp)
         if patch > 1:
             dh = empty((M, D), adt, dy)
             lib.patch_pool_bwd(rt.dt(), dhp.data_ptr(), dh.data_ptr(), B, T, D, patch, rt.stream())
@@ -553,8 +546,8 @@ class ConvModuleFn(torch.autograd.Function):
         ln, pw1, dw, bn, pw2 = mod.layers[0], mod.layers[1], mod.layers[3], mod.layers[4], mod.layers[6]
         M, Mo, adt = B * T, B * To, rt.act_dtype()
         dy = _f32c(dy.reshape(Mo, Dp))
-        dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid, dbias=grad_of(pw2.bias))
-        linear_bwd_weight(dacc, a, pw2.weight, Mo)
+        dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid)
+        linear_bwd_weight(dacc, a, pw2.weight, Mo, bias=pw2.bias)
         da = linear_bwd_input(dacc, pw2.weight, Mo, out_f32=False)
         if use_batch:
             dc, _ = bn_backward(bn, st, cptr, Mo, da, c, None, ACT_SWISH, Mo)
@@ -563,16 +556,15 @@ class ConvModuleFn(torch.autograd.Function):
         du = empty((M, 2 * Dp), adt, dy)
         lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), dw.weight.data_ptr(), du.data_ptr(), grad_of(dw.weight).data_ptr(),
                            None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, rt.stream())
-        colsum(du, 2 * Dp, grad_of(pw1.bias), M, 2 * Dp)
-        linear_bwd_weight(du, h, pw1.weight, M)
+        linear_bwd_weight(du, h, pw1.weight, M, bias=pw1.bias)
         dh = linear_bwd_input(du, pw1.weight, M, out_f32=False)
         if res_conv is None:
             dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D, dres=dy)
         else:
             rs = res_conv.stride[0]
             dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D)
-            dracc = grad_prep(dy, Mo, Dp, dbias=grad_of(res_conv.bias))
-            linear_bwd_weight(dracc, x2, res_conv.weight, Mo, q_f32=(adt != torch.float32), q_rows=rows_plain(D, To, T, rs) if rs > 1 else None)
+            dracc = grad_prep(dy, Mo, Dp)
+            linear_bwd_weight(dracc, x2, res_conv.weight, Mo, q_f32=(adt != torch.float32), q_rows=rows_plain(D, To, T, rs) if rs > 1 else None, bias=res_conv.bias)
             dxr = linear_bwd_input(dracc, res_conv.weight, Mo, out_f32=True)
             lib.strided_rows_add(dx.data_ptr(), dxr.data_ptr(), B, T, To, D, rs, rt.stream())
         return dx.view(B, T, D), None, None, None, None, None, None
@@ -616,14 +608,14 @@ class InterCTCFn(torch.autograd.Function):
         x2, logits, probs, w1, b1, w2, b2, B, T, D, V, conv = ctx.saved
         M = B * T
         dy = _f32c(dy.reshape(M, D))
-        dacc = grad_prep(dy, M, D, dbias=grad_of(b2))
-        linear_bwd_weight(dacc, probs, w2, M)
+        dacc = grad_prep(dy, M, D)
+        linear_bwd_weight(dacc, probs, w2, M, bias=b2)
         dprobs = linear_bwd_input(dacc, w2, M, out_f32=False)
         dl = empty((M, V), torch.float32, dy)
         dext = None if dlogits_ext is None else _f32c(dlogits_ext.reshape(M, V))
         lib.softmax_bwd(rt.dt(), dprobs.data_ptr(), logits.data_ptr(), dl.data_ptr(), _p(dext), M, V, rt.stream())
-        dla = grad_prep(dl, M, V, dbias=grad_of(b1))
-        linear_bwd_weight(dla, x2, w1, M, q_f32=conv)
+        dla = grad_prep(dl, M, V)
+        linear_bwd_weight(dla, x2, w1, M, q_f32=conv, bias=b1)
         dx = linear_bwd_input(dla, w1, M, out_f32=True, res=dy)
         return dx.view(B, T, D), None, None, None, None
 
@@ -653,10 +645,10 @@ class FusionFn(torch.autograd.Function):
         xc, z, h, w1, b1, w2, b2, B, T, Da, Dv, F = ctx.saved
         M, N = B * T, w2.shape[0]
         dy = _f32c(dy.reshape(M, N))
-        dacc = grad_prep(dy, M, N, dbias=grad_of(b2))
-        linear_bwd_weight(dacc, h, w2, M)
-        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, colsum_to=grad_of(b1))
-        linear_bwd_weight(dz, xc, w1, M)
+        dacc = grad_prep(dy, M, N)
+        linear_bwd_weight(dacc, h, w2, M, bias=b2)
+        dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH)
+        linear_bwd_weight(dz, xc, w1, M, bias=b1)
         sh = rt.shadow(w1)                     # bwd shadow [Da+Dv][F]: rows 0..Da-1 -> d(audio), rest -> d(video)
         da = empty((M, Da), torch.float32, dy)
         dv = empty((M, Dv), torch.float32, dy)

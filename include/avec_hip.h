@@ -79,6 +79,10 @@ int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const a
                  float* O, long long ldo, long long M, int I, int J, hipStream_t stream);
 /* batched form: batch = outer * nb_inner + inner; strides6 = element strides {P_outer, P_inner, Q_outer, Q_inner, O_outer, O_inner}.
  * Used for the attention backward bmm's (dK = dS^T Q, dV = P^T dO per (batch, head); dE_h = sum_b skew(dS)^T Q), nnet/attentions.py:300-315. */
+/* avec_gemm_tn plus p_colsum[i] += sum_m P[m][i] (fp32, optional): the bias gradient of a Linear / 1x1 conv comes out of its weight-gradient GEMM
+ * (nn.Linear backward: grad_bias = grad_output.sum(0)) */
+int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
+                      float* O, long long ldo, float* p_colsum, long long M, int I, int J, hipStream_t stream);
 int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                          int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 
