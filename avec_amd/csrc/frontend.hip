@@ -176,12 +176,126 @@ __global__ __launch_bounds__(256) void audio_stem_bwd_params_kernel(const T* __r
     if (cc < s.C && v != 0.f) { if (q < 9) atomicAdd(dw + cc * 9 + q, v); else if (dbias) atomicAdd(dbias + cc, v); }
   }
 }
+// ---- 8-wide audio stem (Fo % 8 == 0): workgroup = AS_ROWS consecutive output rows (b, to); the 3 mel columns a row touches are staged
+// zero-padded in LDS ([NM + 2][3]), thread = 8 consecutive fo of one channel (one 16-byte store); per-channel sums accumulate in LDS
+// over the block's rows and leave through the two-pass reduction workspace (vec.h) when one is registered.
+static constexpr int AS_ROWS = 16;
+__device__ __forceinline__ void stage_mel_patch(float* patch, const float* mel, long long b, int to, const StemA& s) {
+  for (int idx = threadIdx.x; idx < (s.NM + 2) * 3; idx += 256) {
+    const int fi = idx / 3 - 1, kw = idx - (fi + 1) * 3; const int ti = 2 * to + kw - 1;
+    patch[idx] = (fi >= 0 && fi < s.NM && ti >= 0 && ti < s.F) ? mel[(b * s.NM + fi) * s.F + ti] : 0.f;
+  }
+}
+__device__ __forceinline__ void as_commit(const float* lsum, int n, float* const* dst, int ndst, int W, const ColWs& ws) {   // lsum: [ndst][W] in LDS
+  if (ws.partial) { float* mine = ws_slot(ws, 0, blockIdx.x, gridDim.x, n); for (int i = threadIdx.x; i < n; i += 256) mine[i] = lsum[i]; }
+  else for (int i = threadIdx.x; i < n; i += 256) { const int q = i / W; if (dst[q] && lsum[i] != 0.f) atomicAdd(dst[q] + (i - q * W), lsum[i]); }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_conv8_kernel(const float* __restrict__ mel, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               T* __restrict__ y, float* stats, StemA s, ColWs ws) {
+  extern __shared__ float asm_[];
+  float* patch = asm_; float* lw = patch + (s.NM + 2) * 3; float* lsum = lw + s.C * 10;      // lw: [C][9 taps | bias], lsum: [2][C]
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  for (int i = threadIdx.x; i < s.C * 10; i += 256) { const int c = i / 10, q = i - c * 10; lw[i] = q < 9 ? w[c * 9 + q] : (bias ? bias[c] : 0.f); }
+  for (int i = threadIdx.x; i < 2 * s.C; i += 256) lsum[i] = 0.f;
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    __syncthreads();
+    stage_mel_patch(patch, mel, b, to, s);
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+      const int c = ch / F8, fo0 = (ch - c * F8) * 8; const float* wk = lw + c * 10;
+      float acc[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* pp = patch + (2 * (fo0 + e)) * 3; float a = wk[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) a += wk[q] * pp[q];          // patch rows 2fo .. 2fo+2 are contiguous: [kh][kw]
+        acc[e] = a; s1 += a; s2 += a * a;
+      }
+      st8<T>(y + row * J + c * s.Fo + fo0, acc);
+      if (stats) { atomicAdd(lsum + c, s1); atomicAdd(lsum + s.C + c, s2); }
+    }
+  }
+  __syncthreads();
+  if (stats) { float* const dst[2] = {stats, stats + s.C}; as_commit(lsum, 2 * s.C, dst, 2, s.C, ws); }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_reduce8_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ ss, float* dstats, StemA s, ColWs ws) {
+  extern __shared__ float asm_[];
+  float* lsum = asm_;
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  for (int i = threadIdx.x; i < 2 * s.C; i += 256) lsum[i] = 0.f;
+  __syncthreads();
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+      const int c = ch / F8, fo0 = (ch - c * F8) * 8; const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c];
+      float d[8], v[8], s1 = 0.f, s2 = 0.f; ld8<T>(da + row * J + c * s.Fo + fo0, d); ld8<T>(y + row * J + c * s.Fo + fo0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dr = d[e] * dswishf_(v[e] * sc + sh); s1 += dr; s2 += dr * (v[e] - mu) * rs; }
+      atomicAdd(lsum + c, s1); atomicAdd(lsum + s.C + c, s2);
+    }
+  }
+  __syncthreads();
+  float* const dst[2] = {dstats, dstats + s.C}; as_commit(lsum, 2 * s.C, dst, 2, s.C, ws);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_params8_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ mel, const float* __restrict__ ss,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
+                                                                     float* dw, float* dbias, float* dgamma, float* dbeta, StemA s, ColWs ws) {
+  extern __shared__ float asm_[];
+  float* patch = asm_; float* lsum = patch + (s.NM + 2) * 3;                  // lsum: [10][C] = 9 taps, then the bias gradient
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < s.C; c += 256) { atomicAdd(dgamma + c, dstats[s.C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  for (int i = threadIdx.x; i < 10 * s.C; i += 256) lsum[i] = 0.f;
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    __syncthreads();
+    stage_mel_patch(patch, mel, b, to, s);
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+      const int c = ch / F8, fo0 = (ch - c * F8) * 8;
+      const float sc = ss[c], sh = ss[s.C + c], mu = ss[2 * s.C + c], rs = ss[3 * s.C + c], g = gamma[c];
+      const float m1 = dstats[c] * inv_n, m2 = dstats[s.C + c] * inv_n;
+      float d[8], v[8], aw[9], ab = 0.f; ld8<T>(da + row * J + c * s.Fo + fo0, d); ld8<T>(y + row * J + c * s.Fo + fo0, v);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) aw[q] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dr = d[e] * dswishf_(v[e] * sc + sh); const float dy = g * rs * (dr - m1 - (v[e] - mu) * rs * m2);
+        ab += dy; const float* pp = patch + (2 * (fo0 + e)) * 3;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) aw[q] += dy * pp[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) atomicAdd(lsum + q * s.C + c, aw[q]);
+      atomicAdd(lsum + 9 * s.C + c, ab);
+    }
+  }
+  __syncthreads();
+  if (ws.partial) { float* mine = ws_slot(ws, 0, blockIdx.x, gridDim.x, 10 * s.C); for (int i = threadIdx.x; i < 10 * s.C; i += 256) mine[i] = lsum[i]; }
+  else for (int i = threadIdx.x; i < 10 * s.C; i += 256) { const int q = i / s.C, c = i - q * s.C; if (q < 9) atomicAdd(dw + c * 9 + q, lsum[i]); else if (dbias) atomicAdd(dbias + c, lsum[i]); }
+}
+static bool as8_ok(const StemA& s) { return s.Fo % 8 == 0 && ((size_t)(s.NM + 2) * 3 + (size_t)s.C * 12) * 4 <= 60 * 1024; }
+static unsigned as8_blocks(const StemA& s) { return (unsigned)(((long long)s.B * s.To + AS_ROWS - 1) / AS_ROWS); }
 static StemA stemA(int B, int NM, int F, int C) { StemA s; s.B = B; s.NM = NM; s.F = F; s.C = C; s.Fo = (NM - 1) / 2 + 1; s.To = (F - 1) / 2 + 1; return s; }
 static dim3 stem_grid(const StemA& s) { long long M = (long long)s.B * s.To; unsigned gx = (s.C * s.Fo + 255) / 256; long long gy = 2048 / gx; if (gy > M) gy = M; if (gy < 1) gy = 1; return dim3(gx, (unsigned)gy); }
 
 extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float* w, const float* bias, void* y, float* stats, int B, int n_mels, int F, int C, hipStream_t st) {
   AVEC_CHECK_ARG(mel && w && y && B > 0 && n_mels > 0 && F > 0 && C > 0, "audio_stem_conv_fwd: bad arguments");
   StemA s = stemA(B, n_mels, F, C);
+  if (as8_ok(s)) {
+    const unsigned nb = as8_blocks(s); ColWs ws = stats ? avec_reduce_ws((size_t)nb * 2 * C) : ColWs{nullptr};
+    const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 12) * 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv8_kernel<T>, dim3(nb), dim3(256), lds, st, mel, w, bias, (T*)y, stats, s, ws));
+    AVEC_LAUNCH_CHECK();
+    if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv_kernel<T>, stem_grid(s), dim3(256), 0, st, mel, w, bias, (T*)y, stats, s));
   AVEC_LAUNCH_CHECK(); return 0;
 }
@@ -196,6 +310,27 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
                                    int B, int n_mels, int F, int C, hipStream_t st) {
   AVEC_CHECK_ARG(da && y && mel && ss && gamma && dstats && (phase == 0 || (dw != nullptr)), "audio_stem_bwd: bad arguments");
   StemA s = stemA(B, n_mels, F, C);
+  if (as8_ok(s)) {
+    const unsigned nb = as8_blocks(s);
+    if (phase == 0) {
+      ColWs ws = avec_reduce_ws((size_t)nb * 2 * C);
+      DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
+      AVEC_LAUNCH_CHECK();
+      if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
+    } else {
+      ColWs ws = avec_reduce_ws((size_t)nb * 10 * C);
+      const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 10) * 4;
+      DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params8_kernel<T>, dim3(nb), dim3(256), lds, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count,
+                                           dw, dbias, dgamma, dbeta, s, ws));
+      AVEC_LAUNCH_CHECK();
+      if (ws.partial) {      // partial rows are [10][C]: taps 0..8 go to dw[c*9 + q] (element stride 9), row 9 to dbias
+        float* dst[10]; for (int q = 0; q < 9; ++q) dst[q] = dw + q; dst[9] = nullptr;
+        if (int r = col_finalize(ws, 1, nb, 10, C, dst, C, st, 9)) return r;
+        if (dbias) { for (int q = 0; q < 9; ++q) dst[q] = nullptr; dst[9] = dbias; return col_finalize(ws, 1, nb, 10, C, dst, C, st, 1); }
+      }
+    }
+    return 0;
+  }
   if (phase == 0) { DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce_kernel<T>, stem_grid(s), dim3(256), 0, st, (const T*)da, (const T*)y, ss, dstats, s)); }
   else { DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params_kernel<T>, stem_grid(s), dim3(256), 0, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count, dw, dbias, dgamma, dbeta, s)); }
   AVEC_LAUNCH_CHECK(); return 0;

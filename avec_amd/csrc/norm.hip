@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(ColFin f) {
     float* d = nullptr;
 #pragma unroll
     for (int i = 0; i < FIN_MAXNV; ++i) if (i == n) d = f.dst[i];
-    if (d && col < f.C) atomicAdd(d + col, t);
+    if (d && col < f.C) atomicAdd(d + (long long)col * f.dstride, t);
   }
 }
-int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st) {
-  ColFin f; f.partial = ws.partial; f.NV = NV; f.W = W; f.C = C; f.nslots = (int)nslots;
+int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st, int dstride) {
+  ColFin f; f.partial = ws.partial; f.NV = NV; f.W = W; f.C = C; f.nslots = (int)nslots; f.dstride = dstride;
   for (int i = 0; i < FIN_MAXNV; ++i) f.dst[i] = i < NV ? dst[i] : nullptr;
   dim3 grid((unsigned)((NV * W + 15) / 16), colblocks, (nslots + 127) / 128);
   hipLaunchKernelGGL(col_finalize_kernel, grid, dim3(256), 0, st, f);

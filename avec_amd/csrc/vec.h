@@ -54,10 +54,10 @@ __device__ __forceinline__ float* ws_slot(const ColWs& ws, unsigned colblock, un
   return ws.partial + ((size_t)colblock * nslots + slot) * ncols;
 }
 static constexpr int FIN_MAXNV = 20;
-struct ColFin { const float* partial; float* dst[FIN_MAXNV]; int NV, W, C, nslots; };
+struct ColFin { const float* partial; float* dst[FIN_MAXNV]; int NV, W, C, nslots, dstride; };   // dstride: element stride of the destination columns (1 = dense)
 // grid (ceil(NV*W/16), colblocks, ceil(nslots/128)); thread = (column cw = tid & 15, slot lane sl = tid >> 4)
 __global__ __launch_bounds__(256) void col_finalize_kernel(ColFin f);     // norm.hip
-int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st);   // norm.hip
+int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st, int dstride = 1);   // norm.hip
 
 // =============================================================================================
 // column-wise block reduction helper: block = 32 column groups (x4) x 8 row lanes
