@@ -245,7 +245,7 @@ extern "C" int avec_adam_step(float* params, float* grads, float* exp_avg, float
 // shadow refresh: for every GEMM weight (master fp32, logical [A][Tm][C]) write
 //   fwd shadow  (act) = same order                         -> NT forward   (rows = A, K = Tm*C)
 //   bwd shadow  (act) [C][Tm][A] (axes 0 and 2 swapped)    -> NT backward-data (rows = C, K = Tm*A)
-// table entry (10 x int64): src_off, fwd_off (-1: none), bwd_off (-1: none), A, Tm, C, first_block, n_blocks, C_pad, reserved
+// table entry (10 x int64): src_off, fwd_off (-1: none), bwd_off (-1: none), A, Tm, C, first_block, n_blocks, C_pad, bwd row pitch (0: Tm*A)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ master, T* __restrict__ shadow, const long long* __restrict__ table, int n_entries) {
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ m
     if (i >= n) break;
     if (fwd >= 0) stf(shadow + fwd + ((Cp > C && Tm == 1) ? (i / C) * Cp + (i % C) : i), master[src + i]);
     if (bwd >= 0) { const long long a = i % A; const long long r = i / A; const long long t = r % Tm; const long long c = r / Tm;
-      stf(shadow + bwd + i, master[src + (a * Tm + t) * C + c]); }
+      const long long ldb = e[9] > 0 ? e[9] : Tm * A;                  // row pitch of the bwd shadow (> Tm*A: weights fused side by side, e.g. Q|K|V)
+      stf(shadow + bwd + c * ldb + t * A + a, master[src + (a * Tm + t) * C + c]); }
   }
 }
 extern "C" int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t st) {

@@ -158,10 +158,27 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float* __restrict_
   if (dbias) colreduce_atomic<1>(part, dst, col, N, ws);
 }
 
+// flat variant without the bias-gradient column sums (those now come out of the weight-gradient GEMM): plain elementwise grid
+template <typename T>
+__global__ __launch_bounds__(256) void grad_prep_flat_kernel(const float* __restrict__ dout, long long ldd, T* __restrict__ dacc, float alpha, float p,
+                                                             const unsigned long long* rng, unsigned stream, long long M, int N) {
+  const int N4 = N >> 2; const long long n4 = M * N4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long row = i / N4; const int col = (int)(i - row * N4) * 4;
+    float v[4]; ld4<float>(dout + row * ldd + col, v);
+    for (int e = 0; e < 4; ++e) v[e] *= alpha * drop_scale(rng, stream, (unsigned long long)row * N + col + e, p);
+    st4<T>(dacc + row * N + col, v);
+  }
+}
 extern "C" int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
                               unsigned rng_stream, float* dbias, long long M, int N, hipStream_t st) {
   AVEC_CHECK_ARG(dout && dacc && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "grad_prep: bad arguments (N=%d ld=%lld)", N, ld);
   AVEC_CHECK_ARG(!(drop_p > 0.f) || rng, "grad_prep: dropout without rng");
+  if (!dbias) {
+    long long nb = (M * (N / 4) + 255) / 256; if (nb > 8192) nb = 8192;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_flat_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, M, N));
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   dim3 grid = col_grid(M, N); ColWs ws = dbias ? col_ws_if(grid, 1, N) : ColWs{nullptr};
   DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_kernel<T>, grid, dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, dbias, M, N, ws));
   AVEC_LAUNCH_CHECK();

@@ -25,6 +25,8 @@ class MultiHeadAttention(nn.Module):
         self.query_layer = layers.Linear(D, D, weight_init=weight_init, bias_init=bias_init)
         self.key_layer = layers.Linear(D, D, weight_init=weight_init, bias_init=bias_init)
         self.value_layer = layers.Linear(D, D, weight_init=weight_init, bias_init=bias_init)
+        rt.fuse_linears(self, (self.query_layer.weight, self.key_layer.weight, self.value_layer.weight),
+                        (self.query_layer.bias, self.key_layer.bias, self.value_layer.bias))      # one Q|K|V GEMM per pass (runtime.FusedLinears)
         self.output_layer = layers.Linear(D, D, weight_init=weight_init, bias_init=bias_init)
 
     patch_size = 1

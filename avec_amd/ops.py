@@ -185,7 +185,7 @@ def linear_bwd_input(dacc, weight, M, *, out_f32, res=None, res_act=False, dact_
     N, K = sh.Tm * sh.C, sh.A            # bwd shadow is [C*Tm][A]
     if out is None:
         out = empty((M, N), torch.float32 if out_f32 else rt.act_dtype(), dacc)
-    gemm_nt(dacc, sh.bwd, out, M, N, K, rows=rows_plain(K if lda is None else lda), res=res, res_act=res_act, dact_z=dact_z, dact=dact,
+    gemm_nt(dacc, sh.bwd, out, M, N, K, rows=rows_plain(K if lda is None else lda), ldw=sh.ldb, res=res, res_act=res_act, dact_z=dact_z, dact=dact,
             drop_p=drop_p, sid=sid, colsum=colsum_to, out_f32=out_f32)
     return out
 
@@ -357,9 +357,13 @@ class AttentionModuleFn(torch.autograd.Function):
             mask = mask.reshape(mask.shape[0], T, T) if patch == 1 else _pool_mask(mask, T, patch)
             mask = mask.float().contiguous()
         qkv = empty((Mp, 3 * D), adt, x2)
-        for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-            sh = rt.shadow(w)
-            gemm_nt(hp, sh.fwd, qkv[:, i * D:], Mp, D, D, bias=b, ldo=3 * D)
+        grp = rt.fused_group(wq)
+        if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
+            gemm_nt(hp, grp.fwd, qkv, Mp, 3 * D, D, bias=grp.bias)               # Q|K|V in one launch
+        else:
+            for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                sh = rt.shadow(w)
+                gemm_nt(hp, sh.fwd, qkv[:, i * D:], Mp, D, D, bias=b, ldo=3 * D)
         pe = rel_pos_table(Tp, D, x.device)
         e = linear_fwd(pe, wp, bp, 2 * Tp - 1, in_f32=False, out_f32=False)
         o = empty((Mp, D), adt, x2)
@@ -422,10 +426,16 @@ class AttentionModuleFn(torch.autograd.Function):
                                 L6(0, B * Tp * Rld, 0, d, 0, d), rt.stream())
             lib.cast_rows(rt.dt(), dkv32.data_ptr(), 2 * D, dqkv.data_ptr() + D * esz, 3 * D, Mp, 2 * D, rt.stream())
         dhp = None
-        for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-            g = dqkv[:, i * D:]
-            linear_bwd_weight(g, hp, w, Mp, ldp=3 * D, bias=b)
-            dhp = linear_bwd_input(g, w, Mp, out_f32=False, lda=3 * D, res=dhp, res_act=True, out=dhp)
+        grp = rt.fused_group(wq)
+        if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
+            gemm_tn(dqkv, hp, grp.wgrad, Mp, 3 * D, D, p_colsum=grp.bgrad)                       # d(Wq|Wk|Wv), d(bq|bk|bv)
+            dhp = empty((Mp, D), adt, dy)
+            gemm_nt(dqkv, grp.bwd, dhp, Mp, D, 3 * D)                                            # d(input) = dQ Wq + dK Wk + dV Wv
+        else:
+            for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                g = dqkv[:, i * D:]
+                linear_bwd_weight(g, hp, w, Mp, ldp=3 * D, bias=b)
+                dhp = linear_bwd_input(g, w, Mp, out_f32=False, lda=3 * D, res=dhp, res_act=True, out=dhp)
         dea = empty((2 * Tp - 1, D), adt, dy)
         lib.cast_rows(rt.dt(), de.data_ptr(), D, dea.data_ptr(), D, 2 * Tp - 1, D, rt.stream())
         linear_bwd_weight(dea, pe, wp, 2 * Tp - 1, bias=bp)

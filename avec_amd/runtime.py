@@ -105,8 +105,8 @@ def require_gpu(t):
 # weight shadows
 # --------------------------------------------------------------------------------------------
 class Shadow:
-    """Compute-dtype copies of one GEMM weight: `fwd` = physical order [A][Tm][C], `bwd` = [C][Tm][A]."""
-    __slots__ = ("A", "Tm", "C", "Cp", "need_bwd", "fwd", "bwd", "stamp", "arena", "_table")
+    """Compute-dtype copies of one GEMM weight: `fwd` = physical order [A][Tm][C], `bwd` = [C][Tm][A] (row pitch `ldb`)."""
+    __slots__ = ("A", "Tm", "C", "Cp", "need_bwd", "fwd", "bwd", "stamp", "arena", "_table", "ldb", "group")
 
     def __init__(self, A, Tm, C, need_bwd=True, c_pad=None):
         self.A, self.Tm, self.C, self.need_bwd = A, Tm, C, need_bwd
@@ -116,6 +116,29 @@ class Shadow:
         self.stamp = None
         self.arena = None
         self._table = None
+        self.ldb = None          # row pitch of `bwd` when it is a column slice of a fused group's [C][G*A] matrix
+        self.group = None        # FusedLinears this weight belongs to (arena only)
+
+
+class FusedLinears:
+    """G Linear layers that consume the same input (the Q, K, V projections): inside the arena their weights are stored back to back, so
+    one [G*A][C] forward shadow, one [C][G*A] backward shadow, one [G*A][C] gradient and one [G*A] bias / bias-gradient vector exist and
+    the three GEMMs of the forward pass, the backward-data pass and the weight-gradient pass become one each."""
+    __slots__ = ("weights", "biases", "A", "C", "G", "fwd", "bwd", "wgrad", "bias", "bgrad")
+
+
+def fuse_linears(module, weights, biases):
+    """Declare that `weights` (same shape [A][C]) and `biases` should be laid out contiguously by ParamArena (state_dict names are unchanged)."""
+    groups = module.__dict__.setdefault("_avec_fused", [])
+    groups.append((tuple(weights), tuple(biases)))
+
+
+def fused_group(weight):
+    sh = getattr(weight, "_avec_shadow", None)
+    if sh is None or sh.arena is None or sh.group is None:
+        return None
+    sh.arena.ensure_fresh()
+    return sh.group
 
 
 def register_weight(param, A, Tm, C, need_bwd=True, c_pad=None):
@@ -158,10 +181,27 @@ class ParamArena:
     def __init__(self, module):
         params = []
         seen = set()
+        # fused groups (FusedLinears) are emitted together, in declaration order, at the position of their first member
+        lead, self._fused = {}, []
+        own = {id(p) for p in module.parameters()}
+        for m in module.modules():
+            for ws, bs in m.__dict__.get("_avec_fused", []):
+                if not all(id(t) in own for t in ws + bs):
+                    continue
+                ok = all(w.shape == ws[0].shape and w.numel() % 8 == 0 and getattr(w, "_avec_shadow", None) is not None and w._avec_shadow.Tm == 1
+                         and w._avec_shadow.Cp == w._avec_shadow.C and w._avec_shadow.need_bwd for w in ws) and all(b is not None and b.numel() % 4 == 0 for b in bs)
+                if ok and not any(id(t) in lead for t in ws + bs):
+                    self._fused.append((ws, bs))
+                    for grp in (ws, bs):
+                        for t in grp:
+                            lead[id(t)] = grp
         for p in module.parameters():
-            if id(p) not in seen:
-                seen.add(id(p))
-                params.append(p)
+            if id(p) in seen:
+                continue
+            for q in lead.get(id(p), (p,)):
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    params.append(q)
         assert params and all(p.is_cuda for p in params), "ParamArena needs the model on a GPU"
         dev = params[0].device
         self.params = params
@@ -187,19 +227,35 @@ class ParamArena:
     def _build_shadows(self):
         adt = act_dtype()
         rows, soff, blocks = [], 0, 0
+        member = {}                               # id(weight) -> (group index, position)
+        for gi, (ws, _) in enumerate(self._fused):
+            for k, w in enumerate(ws):
+                member[id(w)] = (gi, k)
+        gfwd, gbwd = {}, {}
         for p, o in zip(self.params, self.offsets):
             sh = getattr(p, "_avec_shadow", None)
             if sh is None:
                 continue
             n = sh.A * sh.Tm * sh.C
-            fwd = soff
-            soff += (sh.A * sh.Tm * sh.Cp + 7) // 8 * 8
-            bwd = -1
-            if sh.need_bwd:
-                bwd = soff
-                soff += (n + 7) // 8 * 8
+            ldb = 0
+            if id(p) in member:                   # fused: forward shadows back to back, backward shadows side by side in one [C][G*A] matrix
+                gi, k = member[id(p)]
+                G = len(self._fused[gi][0])
+                if k == 0:
+                    gfwd[gi] = soff
+                    soff += G * n
+                    gbwd[gi] = soff
+                    soff += G * n
+                fwd, bwd, ldb = gfwd[gi] + k * n, gbwd[gi] + k * sh.A, G * sh.A
+            else:
+                fwd = soff
+                soff += (sh.A * sh.Tm * sh.Cp + 7) // 8 * 8
+                bwd = -1
+                if sh.need_bwd:
+                    bwd = soff
+                    soff += (n + 7) // 8 * 8
             nb = (n + 1023) // 1024
-            rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb, sh.Cp, 0])
+            rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb, sh.Cp, ldb])
             blocks += nb
         self.shadow = torch.zeros(max(soff, 8), dtype=adt, device=self.device)
         self.table = torch.tensor(rows, dtype=torch.int64, device=self.device)
@@ -209,12 +265,29 @@ class ParamArena:
             sh = getattr(p, "_avec_shadow", None)
             if sh is None:
                 continue
-            _, fwd, bwd, A, Tm, C, _, _, Cp, _ = rows[i]
+            _, fwd, bwd, A, Tm, C, _, _, Cp, ldb = rows[i]
             n = A * Tm * C
             sh.fwd = self.shadow[fwd:fwd + A * Tm * Cp]
-            sh.bwd = self.shadow[bwd:bwd + n] if bwd >= 0 else None
+            if ldb:
+                sh.bwd, sh.ldb = self.shadow[bwd:bwd + (C - 1) * ldb + A].as_strided((C, A), (ldb, 1)), ldb
+            else:
+                sh.bwd, sh.ldb = (self.shadow[bwd:bwd + n] if bwd >= 0 else None), None
             sh.arena = self
+            sh.group = None
             i += 1
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        for gi, (ws, bs) in enumerate(self._fused):
+            g = FusedLinears()
+            g.weights, g.biases, g.G = ws, bs, len(ws)
+            g.A, g.C = ws[0]._avec_shadow.A, ws[0]._avec_shadow.C
+            n = g.A * g.C
+            g.fwd = self.shadow[gfwd[gi]:gfwd[gi] + g.G * n]
+            g.bwd = self.shadow[gbwd[gi]:gbwd[gi] + g.G * n]
+            ow, ob = off_of[id(ws[0])], off_of[id(bs[0])]
+            assert all(off_of[id(w)] == ow + k * n for k, w in enumerate(ws)) and all(off_of[id(b)] == ob + k * g.A for k, b in enumerate(bs))
+            g.wgrad, g.bias, g.bgrad = self.grad[ow:ow + g.G * n], self.master[ob:ob + g.G * g.A], self.grad[ob:ob + g.G * g.A]
+            for w in ws:
+                w._avec_shadow.group = g
         self._shadow_dtype = compute_dtype()
         self.dirty = True
 
