@@ -197,9 +197,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
   float* const dst[1] = {out};
   colreduce_atomic<1>(part, dst, col, N, ws);
 }
-extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t st) {
+extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N, hipStream_t st) { return colsum_launch(dtype, x, ld, out, M, N, true, st); }
+// use_ws = false: plain atomics (callers that may run concurrently with other users of the reduction workspace, e.g. weight gradients on the side stream)
+int colsum_launch(int dtype, const void* x, long long ld, float* out, long long M, int N, bool use_ws, hipStream_t st) {
   AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: bad arguments");
-  dim3 grid = col_grid(M, N); ColWs ws = col_ws_if(grid, 1, N);
+  dim3 grid = col_grid(M, N); if (!use_ws && grid.y > 16) grid.y = 16; ColWs ws = use_ws ? col_ws_if(grid, 1, N) : ColWs{nullptr};
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ld, out, M, N, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[1] = {out}; return col_finalize(ws, grid.x, grid.y, 1, 128, dst, N, st); }

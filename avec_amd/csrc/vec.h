@@ -57,6 +57,7 @@ static constexpr int FIN_MAXNV = 20;
 struct ColFin { const float* partial; float* dst[FIN_MAXNV]; int NV, W, C, nslots, dstride; };   // dstride: element stride of the destination columns (1 = dense)
 // grid (ceil(NV*W/16), colblocks, ceil(nslots/128)); thread = (column cw = tid & 15, slot lane sl = tid >> 4)
 __global__ __launch_bounds__(256) void col_finalize_kernel(ColFin f);     // norm.hip
+int colsum_launch(int dtype, const void* x, long long ld, float* out, long long M, int N, bool use_ws, hipStream_t st);   // norm.hip
 int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, int W, float* const* dst, int C, hipStream_t st, int dstride = 1);   // norm.hip
 
 // =============================================================================================

@@ -114,13 +114,18 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     return out
 
 
-def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None, p_colsum=None):
-    """O[I][J] (fp32) += P[M][I]^T Q[M][J];  optionally p_colsum[I] += column sums of P (the bias gradient, fused into the same launch)"""
+def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None, p_colsum=None, side=False):
+    """O[I][J] (fp32) += P[M][I]^T Q[M][J];  optionally p_colsum[I] += column sums of P (the bias gradient, fused into the same launch).
+    side=True (weight gradients): launched on the side stream (runtime.wgrad_fork), joined at the end of the backward pass."""
     if q_rows is None:
         q_rows = rows_plain(J)
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+    st = rt.stream()
+    if side and not KERNEL_TIMER.enabled:
+        sd = rt.wgrad_fork(P, Q)
+        st = st if sd is None else sd.cuda_stream
     lib.gemm_tn_bias(rt.dt() if dtype is None else dtype, P.data_ptr(), I if ldp is None else ldp, Q.data_ptr(), _byref(q_rows), q_mode,
-                     int(q_f32), O.data_ptr(), J if ldo is None else ldo, _p(p_colsum), M, I, J, rt.stream())
+                     int(q_f32), O.data_ptr(), J if ldo is None else ldo, _p(p_colsum), M, I, J, st)
     if ev is not None:
         KERNEL_TIMER.stop(ev, (1, q_mode), 2.0 * M * I * J)
 
@@ -177,7 +182,7 @@ def linear_fwd(x2d, weight, bias, M, *, in_f32, out_f32, act=ACT_NONE, out_pre=N
 def linear_bwd_weight(dacc, x2d, weight, M, *, q_f32=False, q_rows=None, ldp=None, bias=None):
     """dW += dacc^T x;  with `bias`: db += column sums of dacc, out of the same GEMM launch"""
     sh = rt.shadow(weight)
-    gemm_tn(dacc, x2d, grad_of(weight), M, sh.A, sh.Tm * sh.C, q_f32=q_f32, q_rows=q_rows, ldp=ldp, p_colsum=None if bias is None else grad_of(bias))
+    gemm_tn(dacc, x2d, grad_of(weight), M, sh.A, sh.Tm * sh.C, q_f32=q_f32, q_rows=q_rows, ldp=ldp, p_colsum=None if bias is None else grad_of(bias), side=True)
 
 
 def linear_bwd_input(dacc, weight, M, *, out_f32, res=None, res_act=False, dact_z=None, dact=0, drop_p=0.0, sid=0, colsum_to=None, lda=None, out=None):
@@ -428,7 +433,7 @@ class AttentionModuleFn(torch.autograd.Function):
         dhp = None
         grp = rt.fused_group(wq)
         if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
-            gemm_tn(dqkv, hp, grp.wgrad, Mp, 3 * D, D, p_colsum=grp.bgrad)                       # d(Wq|Wk|Wv), d(bq|bk|bv)
+            gemm_tn(dqkv, hp, grp.wgrad, Mp, 3 * D, D, p_colsum=grp.bgrad, side=True)                    # d(Wq|Wk|Wv), d(bq|bk|bv)
             dhp = empty((Mp, D), adt, dy)
             gemm_nt(dqkv, grp.bwd, dhp, Mp, D, 3 * D)                                            # d(input) = dQ Wq + dK Wk + dV Wv
         else:
@@ -722,7 +727,7 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     pad = (KH - 1) // 2
     M = N * OH * OW
     sh = rt.shadow(weight)
-    gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD)
+    gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD, side=True)
     if not need_dx:
         return None
     dx = empty((N * H * W, Cin), rt.act_dtype(), dy)
@@ -830,7 +835,7 @@ class VideoStemFn(torch.autograd.Function):
             gw = gb = None
         dy = empty((M, C), rt.act_dtype(), v)
         lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), _p(gw), _p(gb), B * T, OH, OW, C, rt.stream())
-        gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]))
+        gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]), side=True)
         if conv.bias is not None:
             grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
         return None, None, None, None, None
