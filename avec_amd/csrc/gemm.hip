@@ -850,10 +850,15 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   // thousands of tiles, -16 % on the deep-K / few-tile ones (512-channel 3x3 stage): chosen by tile count.  AVEC_NT_RB=64/128 forces it.
   const long long ntiles = (long long)grid.x * grid.y;
   const bool rb64 = sizeof(T) == 2 && (rb_env_set ? rb_env == 64 : ntiles >= 1536);
-#define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
+  static const int stg_env = getenv("AVEC_NT_STG") ? atoi(getenv("AVEC_NT_STG")) : 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
+#define G3(MODE, S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
+#define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
+    if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
   if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G2
+#undef G3
 #undef G
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
