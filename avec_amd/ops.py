@@ -4,6 +4,7 @@ Every Function writes parameter gradients straight into `param.grad` (accumulati
 arena when the model owns one) and returns None for them, so the backward pass is a fixed sequence of
 HIP launches on the current stream (graph-capturable)."""
 import ctypes
+import os
 
 import torch
 
@@ -793,6 +794,9 @@ class ResNetBlockFn(torch.autograd.Function):
         return (dx.view(N, H, W, Cin) if dx is not None else None), None, None, None
 
 
+STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels
+
+
 class VideoStemFn(torch.autograd.Function):
     """Conv3d(1->C,(5,7,7),s(1,2,2),'same',bias) + BatchNorm3d + ReLU + MaxPool3d((1,3,3),s(1,2,2),'same')
     video fp32 [B,T,H,W] -> act NHWC [B*T, H/4, W/4, C]      (nnet/networks.py:459-470)"""
@@ -808,12 +812,17 @@ class VideoStemFn(torch.autograd.Function):
         sh = rt.shadow(conv.weight)
         st = BNState(C, v)
         K, Kp = sh.Tm * sh.C, sh.Cp
-        # im2col once (shared by the forward GEMM and the weight-gradient GEMM), then a plain MFMA GEMM with K padded to Kp
-        A = empty((M, Kp), rt.act_dtype(), v)
-        lib.stem_im2col(rt.dt(), v.data_ptr(), A.data_ptr(), B, T, H, W, Kp, rt.stream())
         y = empty((M, C), rt.act_dtype(), v)
-        gemm_nt(A, sh.fwd, y, M, C, Kp, bias=conv.bias, stats=st.stats if training else None)
-        r = A
+        if STEM3D_DIRECT and rt.compute_dtype() == "bf16" and C == 64 and K == 245 and lib.raw("avec_stem3d_supported")(B, T, H, W):
+            # direct kernels (stem3d.hip): the input band is staged in LDS, no im2col matrix in HBM
+            lib.stem3d_fwd(v.data_ptr(), sh.fwd.data_ptr(), Kp, _p(conv.bias), y.data_ptr(), st.stats.data_ptr() if training else None, B, T, H, W, rt.stream())
+            r = None
+        else:
+            # im2col once (shared by the forward GEMM and the weight-gradient GEMM), then a plain MFMA GEMM with K padded to Kp
+            A = empty((M, Kp), rt.act_dtype(), v)
+            lib.stem_im2col(rt.dt(), v.data_ptr(), A.data_ptr(), B, T, H, W, Kp, rt.stream())
+            gemm_nt(A, sh.fwd, y, M, C, Kp, bias=conv.bias, stats=st.stats if training else None)
+            r = A
         cp = bn_finalize(bn, st, M, training)
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         out = empty((B * T, PH, PW, C), rt.act_dtype(), v)
@@ -835,7 +844,11 @@ class VideoStemFn(torch.autograd.Function):
             gw = gb = None
         dy = empty((M, C), rt.act_dtype(), v)
         lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), _p(gw), _p(gb), B * T, OH, OW, C, rt.stream())
-        gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]), side=True)
+        if r is None:
+            H, W = v.shape[2], v.shape[3]
+            lib.stem3d_wgrad(v.data_ptr(), dy.data_ptr(), grad_of(conv.weight).data_ptr(), B, T, H, W, rt.stream())
+        else:
+            gemm_tn(dy, r, grad_of(conv.weight), M, C, K, q_rows=rows_plain(r.shape[1]), side=True)
         if conv.bias is not None:
             grad_of(conv.bias)   # d(bias) before training-mode BatchNorm is analytically zero: left at 0
         return None, None, None, None, None

@@ -105,7 +105,7 @@ def wgrad_join():
 
 
 _WORKSPACE = {}
-WORKSPACE_BYTES = 32 << 20
+WORKSPACE_BYTES = 64 << 20
 
 
 def _register_workspace(dev):
