@@ -92,16 +92,14 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const float* __restrict_
   const int oh0 = hh * G.ohn; const int nrows = min(G.ohn, G.OH - oh0); const int npx = nrows * G.OW;
   if (tid < 128) lsum[tid] = 0.f;
   stage_slab(slab, video, clip, fr, oh0, G);
-  // weight fragments: B operand of k-step s, channel tile j: W[32j + pl][16s + 8g .. +8]
-  chunk16 wf[16][2];
+  // The reduction runs over (kd,kh) rows of 8 slots (7 taps kw + one zero-weight slot): the 8 operand elements of a lane are then 8
+  // CONSECUTIVE bf16 of one staged row = four aligned 32-bit LDS reads (an element-by-element gather costs 8 reads + 8 selects + 4 packs).
+  // k-step s covers rows 2s (lane half g = 0) and 2s + 1 (g = 1); w8 = [64][36 rows][8] with row 35 and slot 7 zero.
+  chunk16 wf[18][2];
 #pragma unroll
-  for (int s = 0; s < 16; ++s)
+  for (int s = 0; s < 18; ++s)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k0 = 16 * s + 8 * g;
-      chunk16 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0u;
-      wf[s][j] = (k0 + 8 <= ldw) ? ldg16(wsh + (long long)(32 * j + pl) * ldw + k0) : z;
-    }
+    for (int j = 0; j < 2; ++j) wf[s][j] = ldg16(wsh + (long long)(32 * j + pl) * ldw + (2 * s + g) * 8);
   int rowoff[35];
 #pragma unroll
   for (int r = 0; r < 35; ++r) rowoff[r] = ((r / 7) * G.SH + (r % 7)) * G.WP;
@@ -117,20 +115,10 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      chunk16 fa;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        uint32_t h[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int kA = 16 * s + e + q, kB = kA + 8;                     // this lane's tap for g = 0 / g = 1
-          const int rA = kA / 7 > 34 ? 34 : kA / 7, rB = kB / 7 > 34 ? 34 : kB / 7;
-          const int offA = rowoff[rA] + kA % 7, offB = rowoff[rB] + kB % 7;
-          h[q] = pix[g ? offB : offA];
-        }
-        fa.w[e >> 1] = h[0] | (h[1] << 16);
-      }
+    for (int s = 0; s < 18; ++s) {
+      const int offA = rowoff[2 * s > 34 ? 34 : 2 * s], offB = rowoff[2 * s + 1 > 34 ? 34 : 2 * s + 1];
+      const uint32_t* rp = (const uint32_t*)(pix + (g ? offB : offA));          // even element index: 4-byte aligned
+      chunk16 fa; fa.w[0] = rp[0]; fa.w[1] = rp[1]; fa.w[2] = rp[2]; fa.w[3] = rp[3];
       acc[0] = mma16(fa, wf[s][0], acc[0]);
       acc[1] = mma16(fa, wf[s][1], acc[1]);
     }
@@ -273,7 +261,7 @@ extern "C" int avec_stem3d_supported(long long clips, int T_, int H, int W) {
 }
 
 extern "C" int avec_stem3d_fwd(const float* video, const void* w_shadow, int ldw, const float* bias, void* y, float* stats, long long clips, int T_, int H, int W, hipStream_t st) {
-  AVEC_CHECK_ARG(video && w_shadow && y && ldw >= 248 && ldw % 8 == 0, "stem3d_fwd: bad arguments");
+  AVEC_CHECK_ARG(video && w_shadow && y && ldw == 288, "stem3d_fwd: the weight must be repacked as bf16 [64][36][8] (ldw = 288; row 35 and slot 7 zero)");
   Stem3 G; size_t sb;
   AVEC_CHECK_ARG(stem3_geom(G, clips, T_, H, W, &sb), "stem3d_fwd: frame %dx%d too large for the LDS band (use avec_stem_im2col + avec_gemm_nt)", H, W);
   const size_t lds = sb + (size_t)4 * 32 * 72 * 2 + 128 * 4;

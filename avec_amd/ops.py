@@ -815,7 +815,9 @@ class VideoStemFn(torch.autograd.Function):
         y = empty((M, C), rt.act_dtype(), v)
         if STEM3D_DIRECT and rt.compute_dtype() == "bf16" and C == 64 and K == 245 and lib.raw("avec_stem3d_supported")(B, T, H, W):
             # direct kernels (stem3d.hip): the input band is staged in LDS, no im2col matrix in HBM
-            lib.stem3d_fwd(v.data_ptr(), sh.fwd.data_ptr(), Kp, _p(conv.bias), y.data_ptr(), st.stats.data_ptr() if training else None, B, T, H, W, rt.stream())
+            w8 = torch.zeros((C, 36, 8), dtype=sh.fwd.dtype, device=v.device)         # (kd,kh) rows of 7 taps + a zero slot (stem3d.hip)
+            w8[:, :35, :7] = sh.fwd.view(C, Kp)[:, :K].view(C, 35, 7)
+            lib.stem3d_fwd(v.data_ptr(), w8.data_ptr(), 288, _p(conv.bias), y.data_ptr(), st.stats.data_ptr() if training else None, B, T, H, W, rt.stream())
             r = None
         else:
             # im2col once (shared by the forward GEMM and the weight-gradient GEMM), then a plain MFMA GEMM with K padded to Kp

@@ -167,7 +167,7 @@ int avec_audio_stem_bwd(int dtype, const void* da, const void* y, const float* m
 /* im2col of the Cin=1 (5,7,7)/(1,2,2) stem: video fp32 [clips][T][H][W] -> A act [clips*T*OH*OW][ldk] (k = (kd*7+kh)*7+kw, zero padded to ldk) */
 int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, int T, int H, int W, int ldk, hipStream_t stream);
 /* Direct (no im2col) bf16 MFMA kernels for the same stem (avec_amd/csrc/stem3d.hip): the input band is staged once in LDS and the operands are
- * gathered from it.  w_shadow: bf16 [64][ldw] (k = (kd*7+kh)*7+kw, zero padded, ldw >= 248); y: bf16 [clips*T*OH*OW][64]; stats (optional):
+ * gathered from it.  w_shadow: bf16 [64][36][8] = per (kd,kh) row the 7 kw taps + a zero slot, row 35 zero (ldw = 288); y: bf16 [clips*T*OH*OW][64]; stats (optional):
  * fp32 [2*64] += (sum, sum of squares) of y per channel; dw: fp32 [64][245] +=.  avec_stem3d_supported() tells whether the frame size fits. */
 int avec_stem3d_supported(long long clips, int T, int H, int W);
 int avec_stem3d_fwd(const float* video, const void* w_shadow, int ldw, const float* bias, void* y, float* stats, long long clips, int T, int H, int W, hipStream_t stream);
