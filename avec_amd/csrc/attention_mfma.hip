@@ -32,7 +32,7 @@ __device__ __forceinline__ chunk16 tr8(const char* p0, const char* p1) {
   const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
   chunk16 f; f.w[0] = ua.x; f.w[1] = ua.y; f.w[2] = ub.x; f.w[3] = ub.y; return f;
 }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32x2_to_bf16x2(lo, hi); }
 
 // stage `nrows` rows x d channels of a bf16 matrix into the swizzled LDS image (zero outside [0, limit) and beyond d)
 template <int PITCH, int NTHR>

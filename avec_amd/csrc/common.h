@@ -11,11 +11,13 @@ typedef unsigned short bf16_raw;  // storage type for bfloat16
 struct bf16 { bf16_raw v; };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_raw h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {  // round-to-nearest-even (NaN preserved)
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_raw)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the compiler emits it for a __bf16 cast
+// (a software RNE costs 5 VALU per element, which dominated the epilogues of the small kernels)
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) { return __builtin_bit_cast(bf16_raw, (__bf16)f); }
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+  typedef float f32x2_ __attribute__((ext_vector_type(2))); typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
 template <typename T> struct Elt;

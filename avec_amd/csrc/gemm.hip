@@ -100,8 +100,8 @@ __device__ __forceinline__ chunk16 finish_load(const Pend& p) {
   if (SRC_F32 && sizeof(T) == 2) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      o.w[e] = (uint32_t)f32_to_bf16(__uint_as_float(p.lo.w[2 * e])) | ((uint32_t)f32_to_bf16(__uint_as_float(p.lo.w[2 * e + 1])) << 16);
-      o.w[2 + e] = (uint32_t)f32_to_bf16(__uint_as_float(p.hi.w[2 * e])) | ((uint32_t)f32_to_bf16(__uint_as_float(p.hi.w[2 * e + 1])) << 16);
+      o.w[e] = f32x2_to_bf16x2(__uint_as_float(p.lo.w[2 * e]), __uint_as_float(p.lo.w[2 * e + 1]));
+      o.w[2 + e] = f32x2_to_bf16x2(__uint_as_float(p.hi.w[2 * e]), __uint_as_float(p.hi.w[2 * e + 1]));
     }
     if (sh) { o.w[2] = 0u; o.w[3] = 0u; }
   } else {

@@ -14,8 +14,8 @@ template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float v[4])
 template <typename T> __device__ __forceinline__ void st4(T* p, const float v[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float v[4]) {
-  uint2 t; t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  uint2 t; t.x = f32x2_to_bf16x2(v[0], v[1]);
+  t.y = f32x2_to_bf16x2(v[2], v[3]);
   *(uint2*)p = t;
 }
 
@@ -31,8 +31,8 @@ template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]
 template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) { st4<float>(p, v); st4<float>(p + 4, v + 4); }
 template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float v[8]) {
   uint4 t;
-  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16); t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16); t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  t.x = f32x2_to_bf16x2(v[0], v[1]); t.y = f32x2_to_bf16x2(v[2], v[3]);
+  t.z = f32x2_to_bf16x2(v[4], v[5]); t.w = f32x2_to_bf16x2(v[6], v[7]);
   *(uint4*)p = t;
 }
 
