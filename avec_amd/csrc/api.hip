@@ -16,8 +16,10 @@ extern "C" int avec_version() { return AVEC_ABI_VERSION; }
 // ---------------------------------------------------------------------------------------------
 // reduction workspace (vec.h: two-pass column reductions).  One registration per device.
 // ---------------------------------------------------------------------------------------------
-static constexpr int WS_MAX_DEV = 64;
+static constexpr int WS_MAX_DEV = 64, WS_MAX_STREAMS = 4;
 static struct { void* base; size_t bytes; } g_ws[WS_MAX_DEV];
+static struct { hipStream_t st; int dev; void* base; size_t bytes; } g_ws_stream[WS_MAX_STREAMS];      // extra workspaces bound to specific streams
+static int g_n_ws_stream = 0;
 
 extern "C" int avec_set_reduce_workspace(void* base, long long bytes) {
   int dev = 0; hipError_t e = hipGetDevice(&dev);
@@ -27,11 +29,23 @@ extern "C" int avec_set_reduce_workspace(void* base, long long bytes) {
   g_ws[dev].base = base; g_ws[dev].bytes = (size_t)bytes;
   return 0;
 }
-ColWs avec_reduce_ws(size_t partial_floats) {
+extern "C" int avec_set_reduce_workspace_stream(void* base, long long bytes, hipStream_t stream) {
+  int dev = 0; hipError_t e = hipGetDevice(&dev);
+  AVEC_CHECK_ARG(e == hipSuccess && base != nullptr && bytes >= (1 << 16) && ((size_t)base & 255) == 0, "set_reduce_workspace_stream: bad arguments");
+  for (int i = 0; i < g_n_ws_stream; ++i) if (g_ws_stream[i].st == stream && g_ws_stream[i].dev == dev) { g_ws_stream[i].base = base; g_ws_stream[i].bytes = (size_t)bytes; return 0; }
+  AVEC_CHECK_ARG(g_n_ws_stream < WS_MAX_STREAMS, "set_reduce_workspace_stream: at most %d stream-bound workspaces", WS_MAX_STREAMS);
+  g_ws_stream[g_n_ws_stream].st = stream; g_ws_stream[g_n_ws_stream].dev = dev; g_ws_stream[g_n_ws_stream].base = base; g_ws_stream[g_n_ws_stream].bytes = (size_t)bytes; ++g_n_ws_stream;
+  return 0;
+}
+ColWs avec_reduce_ws(size_t partial_floats, hipStream_t st) {
   ColWs ws{nullptr};
   static const bool off = getenv("AVEC_NO_TREE") != nullptr;
   if (off) return ws;
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return ws;
+  for (int i = 0; i < g_n_ws_stream; ++i) if (g_ws_stream[i].st == st && g_ws_stream[i].dev == dev) {
+    if (partial_floats * sizeof(float) <= g_ws_stream[i].bytes) ws.partial = (float*)g_ws_stream[i].base;
+    return ws;
+  }
   if (!g_ws[dev].base || partial_floats * sizeof(float) > g_ws[dev].bytes) return ws;
   ws.partial = (float*)g_ws[dev].base;
   return ws;

@@ -110,7 +110,7 @@ extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, con
   AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "glu_dwconv_fwd: bad arguments (C=%d K=%d)", C, K);
   const int To = (T_ - 1) / stride + 1;
   const int nchunks = (To + DW_TT - 1) / DW_TT;
-  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = stats ? col_ws_if(grid, 2, C) : ColWs{nullptr};
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = stats ? col_ws_if(grid, 2, C, st) : ColWs{nullptr};
   const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   AVEC_CHECK_ARG(lds <= 64 * 1024, "glu_dwconv_fwd: stride %d too large", stride);
   DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), lds, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, nchunks, ws));
@@ -124,7 +124,7 @@ extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, con
   const int To = (T_ - 1) / stride + 1;
   long long n4 = (long long)B * T_ * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   const int nchunks = (To + DW_TT - 1) / DW_TT;
-  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C);
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C, st);
   const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
   DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To);

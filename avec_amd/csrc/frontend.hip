@@ -289,7 +289,7 @@ extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float
   AVEC_CHECK_ARG(mel && w && y && B > 0 && n_mels > 0 && F > 0 && C > 0, "audio_stem_conv_fwd: bad arguments");
   StemA s = stemA(B, n_mels, F, C);
   if (as8_ok(s)) {
-    const unsigned nb = as8_blocks(s); ColWs ws = stats ? avec_reduce_ws((size_t)nb * 2 * C) : ColWs{nullptr};
+    const unsigned nb = as8_blocks(s); ColWs ws = stats ? avec_reduce_ws((size_t)nb * 2 * C, st) : ColWs{nullptr};
     const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 12) * 4;
     DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv8_kernel<T>, dim3(nb), dim3(256), lds, st, mel, w, bias, (T*)y, stats, s, ws));
     AVEC_LAUNCH_CHECK();
@@ -313,12 +313,12 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
   if (as8_ok(s)) {
     const unsigned nb = as8_blocks(s);
     if (phase == 0) {
-      ColWs ws = avec_reduce_ws((size_t)nb * 2 * C);
+      ColWs ws = avec_reduce_ws((size_t)nb * 2 * C, st);
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
       AVEC_LAUNCH_CHECK();
       if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
     } else {
-      ColWs ws = avec_reduce_ws((size_t)nb * 10 * C);
+      ColWs ws = avec_reduce_ws((size_t)nb * 10 * C, st);
       const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 10) * 4;
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params8_kernel<T>, dim3(nb), dim3(256), lds, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count,
                                            dw, dbias, dgamma, dbeta, s, ws));
@@ -506,7 +506,7 @@ extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned c
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   if (C % 8 == 0 && C <= 2048) {
     if (phase == 0) {
-      ColWs ws; const unsigned nb8 = col8_cfg(frames * H * W, C, 2, &ws);
+      ColWs ws; const unsigned nb8 = col8_cfg(frames * H * W, C, 2, &ws, st);
       DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce8_kernel<T>, dim3(nb8), dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats,
                                            frames, H, W, C, OH, OW, ws));
       AVEC_LAUNCH_CHECK();
@@ -520,7 +520,7 @@ extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned c
     AVEC_LAUNCH_CHECK(); return 0;
   }
   if (phase == 0) {
-    dim3 grid = col_grid(frames * H * W, C); ColWs ws = col_ws_if(grid, 2, C);
+    dim3 grid = col_grid(frames * H * W, C); ColWs ws = col_ws_if(grid, 2, C, st);
     DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dpool, idx, (const T*)y, ss, dstats, frames, H, W, C, OH, OW, ws));
     AVEC_LAUNCH_CHECK();
     if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }

@@ -127,7 +127,7 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
   long long nb = (M + 15) / 16; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
-  ColWs ws = avec_reduce_ws((size_t)nb * 2 * D);
+  ColWs ws = avec_reduce_ws((size_t)nb * 2 * D, st);
   if (!ws.partial && nb > 128) nb = 128;
   const size_t lds = (size_t)2 * D * sizeof(float);
   if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws);
@@ -179,7 +179,7 @@ extern "C" int avec_grad_prep(int dtype, const float* dout, long long ld, void* 
     DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_flat_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, M, N));
     AVEC_LAUNCH_CHECK(); return 0;
   }
-  dim3 grid = col_grid(M, N); ColWs ws = dbias ? col_ws_if(grid, 1, N) : ColWs{nullptr};
+  dim3 grid = col_grid(M, N); ColWs ws = dbias ? col_ws_if(grid, 1, N, st) : ColWs{nullptr};
   DISPATCH_T(dtype, hipLaunchKernelGGL(grad_prep_kernel<T>, grid, dim3(256), 0, st, dout, ld, (T*)dacc, alpha, drop_p, rng, rng_stream, dbias, M, N, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[1] = {dbias}; return col_finalize(ws, grid.x, grid.y, 1, 128, dst, N, st); }
@@ -201,7 +201,7 @@ extern "C" int avec_colsum(int dtype, const void* x, long long ld, float* out, l
 // use_ws = false: plain atomics (callers that may run concurrently with other users of the reduction workspace, e.g. weight gradients on the side stream)
 int colsum_launch(int dtype, const void* x, long long ld, float* out, long long M, int N, bool use_ws, hipStream_t st) {
   AVEC_CHECK_ARG(x && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: bad arguments");
-  dim3 grid = col_grid(M, N); if (!use_ws && grid.y > 16) grid.y = 16; ColWs ws = use_ws ? col_ws_if(grid, 1, N) : ColWs{nullptr};
+  dim3 grid = col_grid(M, N); if (!use_ws && grid.y > 16) grid.y = 16; ColWs ws = use_ws ? col_ws_if(grid, 1, N, st) : ColWs{nullptr};
   DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ld, out, M, N, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[1] = {out}; return col_finalize(ws, grid.x, grid.y, 1, 128, dst, N, st); }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
 }
 extern "C" int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && stats && M > 0 && C > 0 && C % 4 == 0, "bn_stats: bad arguments");
-  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C);
+  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C, st);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, grid, dim3(256), 0, st, (const T*)y, stats, M, C, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict
 extern "C" int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && ss && dstats && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
   if (col8_ok(C)) {
-    ColWs ws; const unsigned nb = col8_cfg(M, C, 2, &ws);
+    ColWs ws; const unsigned nb = col8_cfg(M, C, 2, &ws, st);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C, ws));
     AVEC_LAUNCH_CHECK();
     if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
     return 0;
   }
-  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C);
+  dim3 grid = col_grid(M, C); ColWs ws = col_ws_if(grid, 2, C, st);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, grid, dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }

@@ -266,7 +266,7 @@ extern "C" int avec_stem3d_fwd(const float* video, const void* w_shadow, int ldw
   AVEC_CHECK_ARG(stem3_geom(G, clips, T_, H, W, &sb), "stem3d_fwd: frame %dx%d too large for the LDS band (use avec_stem_im2col + avec_gemm_nt)", H, W);
   const size_t lds = sb + (size_t)4 * 32 * 72 * 2 + 128 * 4;
   if (int r = s3_set_lds(stem3_fwd_kernel, lds)) return r;
-  ColWs ws = stats ? avec_reduce_ws((size_t)G.items * 128) : ColWs{nullptr};
+  ColWs ws = stats ? avec_reduce_ws((size_t)G.items * 128, st) : ColWs{nullptr};
   hipLaunchKernelGGL(stem3_fwd_kernel, dim3((unsigned)G.items), dim3(256), lds, st, video, (const bf16*)w_shadow, ldw, bias, (bf16*)y, stats ? 1 : 0, G, ws, stats);
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {stats, stats + S3_C}; return col_finalize(ws, 1, (unsigned)G.items, 2, S3_C, dst, S3_C, st); }
@@ -280,7 +280,7 @@ extern "C" int avec_stem3d_wgrad(const float* video, const void* dy, float* dw, 
   const size_t lds = sb + (size_t)128 * 128;
   if (int r = s3_set_lds(stem3_wgrad_kernel, lds)) return r;
   unsigned nb = 512; if ((long long)nb > G.items) nb = (unsigned)G.items;
-  ColWs ws = avec_reduce_ws((size_t)nb * S3_C * S3_K);
+  ColWs ws = avec_reduce_ws((size_t)nb * S3_C * S3_K, st);
   hipLaunchKernelGGL(stem3_wgrad_kernel, dim3(nb), dim3(256), lds, st, video, (const bf16*)dy, dw, G, ws);
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[1] = {dw}; return col_finalize(ws, 1, nb, 1, S3_C * S3_K, dst, S3_C * S3_K, st); }

@@ -48,7 +48,7 @@ template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float v[8])
 // The workspace is registered per device with avec_set_reduce_workspace() and must not be shared by concurrent streams.
 // =============================================================================================
 struct ColWs { float* partial; };
-ColWs avec_reduce_ws(size_t partial_floats);     // api.hip; {nullptr} when none registered / too small
+ColWs avec_reduce_ws(size_t partial_floats, hipStream_t st);     // api.hip; the workspace registered for stream `st` (else the device default); {nullptr} when none / too small
 
 __device__ __forceinline__ float* ws_slot(const ColWs& ws, unsigned colblock, unsigned slot, unsigned nslots, int ncols) {
   return ws.partial + ((size_t)colblock * nslots + slot) * ncols;
@@ -84,11 +84,11 @@ __device__ __forceinline__ void colreduce_atomic(float (&part)[NV][4], float* co
   }
 }
 // workspace for a col_grid launch with NV reduced quantities (finish with col_finalize(ws, grid.x, grid.y, NV, 128, dst, C, st))
-static inline ColWs col_ws(dim3 grid, int NV) { return avec_reduce_ws((size_t)grid.x * grid.y * NV * 128); }
+static inline ColWs col_ws(dim3 grid, int NV, hipStream_t st) { return avec_reduce_ws((size_t)grid.x * grid.y * NV * 128, st); }
 // ... only when the one-pass version would issue many atomics (the second pass costs a launch)
-static inline ColWs col_ws_if(dim3 grid, int NV, int C) {
+static inline ColWs col_ws_if(dim3 grid, int NV, int C, hipStream_t st) {
   const long long atomics = (long long)grid.y * NV * C;
-  return atomics > 16384 ? col_ws(grid, NV) : ColWs{nullptr};
+  return atomics > 16384 ? col_ws(grid, NV, st) : ColWs{nullptr};
 }
 
 static inline dim3 col_grid(long long M, int C) {
@@ -132,9 +132,9 @@ static inline long long col8_cap() { static long long cap = 0; if (!cap) { const
 static inline unsigned col8_blocks(long long M, int C) { const int R = 256 / (C / 8); long long nb = (M + R - 1) / R; if (nb > col8_cap()) nb = col8_cap(); return (unsigned)nb; }
 // grid size + workspace of a flat 8-wide launch (finish with col_finalize(ws, 1, nb, NV, C, dst, C, st)); without a workspace the
 // block count is kept low (every block issues NV*C atomics)
-static inline unsigned col8_cfg(long long M, int C, int NV, ColWs* ws) {
+static inline unsigned col8_cfg(long long M, int C, int NV, ColWs* ws, hipStream_t st) {
   unsigned nb = col8_blocks(M, C);
-  *ws = avec_reduce_ws((size_t)nb * NV * C);
+  *ws = avec_reduce_ws((size_t)nb * NV * C, st);
   if (!ws->partial && nb > 256) nb = 256;
   return nb;
 }

@@ -182,8 +182,26 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
         self.head = layers.Linear(dim_model, vocab_size) if include_head else nn.Identity()
 
     def forward(self, video, video_len, audio, audio_len):
-        video, video_len, v_inter = self.video_encoder(video, video_len)
-        audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+        side = rt.branch_stream() if (video.is_cuda and audio.is_cuda) else None
+        if side is None:
+            video, video_len, v_inter = self.video_encoder(video, video_len)
+            audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+        else:
+            # the two encoders are independent: the audio branch runs on a second stream beside the visual one (runtime.branch_stream)
+            main = torch.cuda.current_stream()
+            rt.stream()                                   # default reduction workspace registered before the fork
+            rt.ensure_shadows_fresh(self)
+            side.wait_stream(main)
+            for t in (audio, audio_len):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+            video, video_len, v_inter = self.video_encoder(video, video_len)
+            main.wait_stream(side)
+            for t in [audio, audio_len] + [u for v in a_inter.values() for u in (v if isinstance(v, (list, tuple)) else [v])]:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
         x = self.fusion_module(audio, video)
         x, lengths, inter = self.audio_visual_encoder(x, audio_len)
         inter.update(v_inter)

@@ -104,6 +104,37 @@ def wgrad_join():
     _SIDE["pending"].clear()
 
 
+# ---- second stream for the audio branch of the audio-visual encoder ------------------------------------------------------------------------
+# The audio and the visual encoder are independent until the fusion module.  The audio branch consists of ~1000 small kernels (M = B*T <= 6400
+# rows: a few hundred workgroups each) that cannot fill 256 CUs; running it on its own HIP stream lets them execute beside the ResNet kernels of
+# the visual branch (one fork and one join per pass; autograd replays each backward node on the stream of its forward).  The side stream gets
+# its own reduction workspace.  AVEC_BRANCH_STREAMS=0 disables it.
+_BRANCH = {"streams": {}, "ws": {}, "enabled": os.environ.get("AVEC_BRANCH_STREAMS", "1") != "0"}
+
+
+def branch_stream():
+    if not _BRANCH["enabled"] or not torch.cuda.is_available():
+        return None
+    dev = torch.cuda.current_device()
+    side = _BRANCH["streams"].get(dev)
+    if side is None:
+        side = _BRANCH["streams"][dev] = torch.cuda.Stream(device=dev)
+        buf = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", dev))
+        with torch.cuda.device(dev):
+            lib.set_reduce_workspace_stream(buf.data_ptr(), WORKSPACE_BYTES, side.cuda_stream)
+        _BRANCH["ws"][dev] = buf
+    return None if torch.cuda.current_stream() == side else side
+
+
+def ensure_shadows_fresh(module):
+    """Refresh the arena's weight shadows on the CURRENT stream (before work is forked to other streams)."""
+    for p in module.parameters():
+        sh = getattr(p, "_avec_shadow", None)
+        if sh is not None and sh.arena is not None:
+            sh.arena.ensure_fresh()
+            return
+
+
 _WORKSPACE = {}
 WORKSPACE_BYTES = 64 << 20
 

@@ -43,6 +43,9 @@ const char* avec_last_error(void);
  * to one float atomic per column per workgroup.  The buffer must stay alive and must not be used by two streams at once.
  * (base = NULL, bytes = 0 unregisters.) */
 int avec_set_reduce_workspace(void* base, long long bytes);
+/* A second workspace bound to one stream: kernels launched on `stream` use it instead of the device default, so two streams (the audio and the
+ * visual branch of the AV encoder) can run reductions concurrently. */
+int avec_set_reduce_workspace_stream(void* base, long long bytes, hipStream_t stream);
 
 /* ---- row sources for the GEMM family ------------------------------------------------------ */
 enum { AVEC_ROWS_PLAIN = 0, AVEC_ROWS_CONV_FWD = 1, AVEC_ROWS_CONV_BWD = 2 };
