@@ -112,6 +112,11 @@ def wgrad_join():
 _BRANCH = {"streams": {}, "ws": {}, "enabled": os.environ.get("AVEC_BRANCH_STREAMS", "1") != "0"}
 
 
+def set_branch_streams(flag):
+    """Enable / disable the second stream of the audio branch (bench.py times kernels one by one with the streams off)."""
+    _BRANCH["enabled"] = bool(flag)
+
+
 def branch_stream():
     if not _BRANCH["enabled"] or not torch.cuda.is_available():
         return None

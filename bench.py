@@ -149,11 +149,15 @@ def main():
     if not args.no_kernel_timing:
         # roofline leg: the same step, eagerly, with HIP events around every GEMM-family launch (events cannot be recorded inside a graph).
         # Every rank runs it (the step contains collectives); only rank 0 records events.
+        # The audio branch's second stream is switched off for this leg, so that an event pair brackets exactly one kernel.
+        from avec_amd import runtime as rt
+        rt.set_branch_streams(False)
         ops.KERNEL_TIMER.reset(enabled=(rank == 0))
         for _ in range(min(args.steps, 3)):
             model.train_step(inputs, targets, precision=precision)
         barrier()
         ops.KERNEL_TIMER.enabled = False
+        rt.set_branch_streams(os.environ.get("AVEC_BRANCH_STREAMS", "1") != "0")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
