@@ -950,7 +950,10 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
 #undef LT
     }
   }
-  if (g.pcs) { if (int r = colsum_launch(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, false, st)) return r; }     // kernels without the fused column sums
+  if (g.pcs) {      // kernels without the fused column sums: a separate pass (plain atomics only when weight gradients run on their own stream)
+    static const bool side_wgrad = getenv("AVEC_WGRAD_STREAM") && getenv("AVEC_WGRAD_STREAM")[0] == '1';
+    if (int r = colsum_launch(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, !side_wgrad, st)) return r;
+  }     // kernels without the fused column sums
 #define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }

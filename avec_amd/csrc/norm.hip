@@ -292,7 +292,10 @@ template <typename T>
 __device__ __forceinline__ void bn_dr(const T* dout, const T* y, const T* out, const float* ss, int act, long long off, int c, int C, float dr[4], float yh[4]) {
   float d[4], v[4], mu[4], rs[4]; ld4<T>(dout + off, d); ld4<T>(y + off, v); ld4<float>(ss + 2 * C + c, mu); ld4<float>(ss + 3 * C + c, rs);
   for (int e = 0; e < 4; ++e) yh[e] = (v[e] - mu[e]) * rs[e];
-  if (act == 2) { float o[4]; ld4<T>(out + off, o); for (int e = 0; e < 4; ++e) dr[e] = o[e] > 0.f ? d[e] : 0.f; }
+  if (act == 2) {      // ReLU: mask from the saved output when there is one (residual added before the ReLU), else from the recomputed pre-activation
+    if (out) { float o[4]; ld4<T>(out + off, o); for (int e = 0; e < 4; ++e) dr[e] = o[e] > 0.f ? d[e] : 0.f; }
+    else { float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh); for (int e = 0; e < 4; ++e) dr[e] = (v[e] * sc[e] + sh[e]) > 0.f ? d[e] : 0.f; }
+  }
   else if (act == 1) { float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh); for (int e = 0; e < 4; ++e) dr[e] = d[e] * dswishf_(v[e] * sc[e] + sh[e]); }
   else { for (int e = 0; e < 4; ++e) dr[e] = d[e]; }
 }
@@ -319,13 +322,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict
   if (m.active) {
     const int c = m.l * 8;
     float mu[8], rs[8], sc[8], sh[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
-    if (act == 1) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
+    if (act == 1 || (act == 2 && !out)) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
     for (long long row = (long long)blockIdx.x * m.R + m.r; row < M; row += (long long)gridDim.x * m.R) {
       const long long off = row * C + c;
       float d[8], v[8]; ld8<T>(dout + off, d); ld8<T>(y + off, v);
-      if (act == 2) { float o[8]; ld8<T>(out + off, o);
+      if (act == 2 && out) { float o[8]; ld8<T>(out + off, o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f; }
+      else if (act == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (v[e] * sc[e] + sh[e]) > 0.f ? d[e] : 0.f; }
       else if (act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] *= dswishf_(v[e] * sc[e] + sh[e]); }
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict
   colreduce8_atomic<2>(part, dst, m, ws);
 }
 extern "C" int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t st) {
-  AVEC_CHECK_ARG(dout && y && ss && dstats && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
+  AVEC_CHECK_ARG(dout && y && ss && dstats && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
   if (col8_ok(C)) {
     ColWs ws; const unsigned nb = col8_cfg(M, C, 2, &ws, st);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, act, dstats, M, C, ws));
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 extern "C" int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
                                  const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
-  AVEC_CHECK_ARG(dout && y && ss && gamma && dstats && dy && (act != 2 || out) && M > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+  AVEC_CHECK_ARG(dout && y && ss && gamma && dstats && dy && M > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
   long long n4 = M * C / 4; long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, gamma, dstats,
                                        count_ptr, count, act, (T*)dy, (T*)dres, dgamma, dbeta, n4, C));

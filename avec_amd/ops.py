@@ -782,7 +782,7 @@ class ResNetBlockFn(torch.autograd.Function):
         assert training, "ResNetBlock backward is implemented for training-mode BatchNorm"
         dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True)
         da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW)
-        dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, a1, ACT_RELU, Mo)
+        dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, None, ACT_RELU, Mo)      # no residual before this ReLU: the mask is recomputed from y1 (one tensor less to read)
         need_dx = ctx.needs_input_grad[0]
         if has_proj:
             convr, bnr = blk.residual[0], blk.residual[1]

@@ -221,12 +221,17 @@ def register_weight(param, A, Tm, C, need_bwd=True, c_pad=None):
     return param
 
 
+def _shadow_blocks(sh):
+    """workgroups of avec_shadow_refresh for one weight: one per 32 x 32 (A x C) tile and tap"""
+    return sh.Tm * ((sh.A + 31) // 32) * ((sh.C + 31) // 32)
+
+
 def _refresh_single(param, sh):
     n = sh.A * sh.Tm * sh.C
     nf = sh.A * sh.Tm * sh.Cp
     adt = act_dtype()
     buf = torch.zeros(nf + (n if sh.need_bwd else 0), dtype=adt, device=param.device)
-    blocks = (n + 1023) // 1024
+    blocks = _shadow_blocks(sh)
     table = torch.tensor([0, 0, nf if sh.need_bwd else -1, sh.A, sh.Tm, sh.C, 0, blocks, sh.Cp, 0], dtype=torch.int64, device=param.device)
     src = param.detach()
     assert is_dense(src)
@@ -329,7 +334,7 @@ class ParamArena:
                 if sh.need_bwd:
                     bwd = soff
                     soff += (n + 7) // 8 * 8
-            nb = (n + 1023) // 1024
+            nb = _shadow_blocks(sh)
             rows.append([o, fwd, bwd, sh.A, sh.Tm, sh.C, blocks, nb, sh.Cp, ldb])
             blocks += nb
         self.shadow = torch.zeros(max(soff, 8), dtype=adt, device=self.device)

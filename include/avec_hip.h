@@ -190,7 +190,9 @@ int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStre
 /* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */
 int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t stream);
-/* table entry = 10 x int64: src_off, fwd_off|-1, bwd_off|-1, A, Tm, C, first_block, n_blocks, C_pad (row stride of the fwd shadow when Tm==1), 0 */
+/* Compute-dtype copies of the GEMM weights (master fp32 [A][Tm][C]): fwd = same order, bwd = [C][Tm][A].  table entry = 10 x int64: src_off, fwd_off|-1,
+ * bwd_off|-1, A, Tm, C, first_block, n_blocks = Tm*ceil(A/32)*ceil(C/32) (one workgroup per 32x32 tile and tap), C_pad (row stride of the fwd
+ * shadow when Tm==1), bwd row pitch (0: Tm*A; larger when several weights share one [C][G*A] backward matrix, e.g. Q|K|V) */
 int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t stream);
 
 #ifdef __cplusplus
