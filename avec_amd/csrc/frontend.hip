@@ -348,10 +348,16 @@ __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict_
     const int c = (int)(i % (C / 4)) * 4; long long r = i / (C / 4); const int ow = (int)(r % OW); r /= OW; const int oh = (int)(r % OH); const long long fr = r / OH;
     float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh);
     float best[4] = {0.f, 0.f, 0.f, 0.f}; unsigned bi[4] = {255u, 255u, 255u, 255u};
-    for (int kh = 0; kh < 3; ++kh) { const int h = 2 * oh + kh - 1; if (h < 0 || h >= H) continue;
-      for (int kw = 0; kw < 3; ++kw) { const int w = 2 * ow + kw - 1; if (w < 0 || w >= W) continue;
-        float v[4]; ld4<T>(y + ((fr * H + h) * W + w) * C + c, v);
-        for (int e = 0; e < 4; ++e) { const float a = v[e] * sc[e] + sh[e]; if (a > best[e]) { best[e] = a; bi[e] = kh * 3 + kw; } } } }
+    float v[9][4]; bool ok[9];                          // unconditional (clamped) loads first: loads under divergent `continue`s are serialised
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int kh = q / 3, kw = q - kh * 3; const int h = 2 * oh + kh - 1, w = 2 * ow + kw - 1;
+      ok[q] = h >= 0 && h < H && w >= 0 && w < W;
+      ld4<T>(y + ((fr * H + (ok[q] ? h : 0)) * W + (ok[q] ? w : 0)) * C + c, v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      for (int e = 0; e < 4; ++e) { const float a = v[q][e] * sc[e] + sh[e]; if (ok[q] && a > best[e]) { best[e] = a; bi[e] = q; } }
     st4<T>(out + i * 4, best);
     *(uint32_t*)(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
   }
@@ -384,19 +390,32 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_reduce_kernel(const T* __re
   colreduce_atomic<2>(part, dst, col, C, ws);
 }
 // 8-channel variants (C % 8 == 0): 16 B accesses, every lane busy for C = 64
+// Input row h lies in the 3-row windows oh = h>>1 (slot kh = 1 for even h, 2 for odd h) and, for odd h, oh = (h>>1)+1 (kh = 0); likewise for
+// columns: at most 4 candidate windows.  All four (idx, dpool) pairs are fetched unconditionally at clamped addresses and masked afterwards
+// -- loads issued under divergent `continue`s are serialised by the compiler (one s_waitcnt vmcnt(0) per probe).
 template <typename T>
 __device__ __forceinline__ void stem_dr8(const T* dp, const unsigned char* idx, long long fr, int h, int w, int c, int C, int OH, int OW, float dr[8]) {
+  const int ohA = h >> 1, owA = w >> 1, khA = 1 + (h & 1), kwA = 1 + (w & 1);
+  int oh[2], ow[2], kh[2], kw[2]; bool vh[2], vw[2];
+  oh[0] = ohA; kh[0] = khA; vh[0] = ohA < OH; oh[1] = ohA + 1; kh[1] = 0; vh[1] = (h & 1) && ohA + 1 < OH;
+  ow[0] = owA; kw[0] = kwA; vw[0] = owA < OW; ow[1] = owA + 1; kw[1] = 0; vw[1] = (w & 1) && owA + 1 < OW;
+  uint2 sel[4]; float g[4][8]; unsigned slot[4]; bool ok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = q >> 1, b = q & 1;
+    ok[q] = vh[a] && vw[b]; slot[q] = (unsigned)(kh[a] * 3 + kw[b]);
+    const long long o = ((fr * OH + (vh[a] ? oh[a] : 0)) * OW + (vw[b] ? ow[b] : 0)) * C + c;
+    sel[q] = *(const uint2*)(idx + o); ld8<T>(dp + o, g[q]);
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) dr[e] = 0.f;
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) { const int t = h + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= OH) continue;
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) { const int u = w + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= OW) continue;
-      const long long o = ((fr * OH + oh) * OW + ow) * C + c;
-      const uint2 sel = *(const uint2*)(idx + o); float g[8]; ld8<T>(dp + o, g);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { if (((sel.x >> (8 * e)) & 255u) == (unsigned)(kh * 3 + kw)) dr[e] += g[e];
-                                    if (((sel.y >> (8 * e)) & 255u) == (unsigned)(kh * 3 + kw)) dr[4 + e] += g[4 + e]; } } }
+    for (int e = 0; e < 4; ++e) {
+      if (ok[q] && ((sel[q].x >> (8 * e)) & 255u) == slot[q]) dr[e] += g[q][e];
+      if (ok[q] && ((sel[q].y >> (8 * e)) & 255u) == slot[q]) dr[4 + e] += g[q][4 + e];
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bwd_reduce8_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ y, const float* __restrict__ ss,
