@@ -259,6 +259,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
   const float rs = rsqrtf(var + eps);
   ss[c] = gamma[c] * rs; ss[C + c] = beta[c] - mean * gamma[c] * rs; ss[2 * C + c] = mean; ss[3 * C + c] = rs;
 }
+// SyncBatchNorm helpers (one launch each instead of three small framework kernels per layer and pass):
+//   collapse : out[0..2C) = sum over the n_replicas partial [sum | sumsq] vectors, out[2C] = count      (the vector that is all-reduced)
+//   affine   : dgamma += dstats[C..2C), dbeta += dstats[0..C)                                            (LOCAL sums, before dstats is all-reduced)
+__global__ __launch_bounds__(256) void bn_collapse_kernel(const float* __restrict__ stats, int nrep, float count, float* __restrict__ out, int C2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C2) { float s = 0.f; for (int r = 0; r < nrep; ++r) s += stats[(long long)r * C2 + c]; out[c] = s; }
+  if (c == 0) out[C2] = count;
+}
+__global__ __launch_bounds__(256) void bn_affine_grads_kernel(const float* __restrict__ dstats, float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) { dgamma[c] += dstats[C + c]; dbeta[c] += dstats[c]; }
+}
+extern "C" int avec_bn_collapse(const float* stats, int n_replicas, float count, float* out, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(stats && out && n_replicas > 0 && C > 0, "bn_collapse: bad arguments");
+  hipLaunchKernelGGL(bn_collapse_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, stats, n_replicas, count, out, 2 * C);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_bn_affine_grads(const float* dstats, float* dgamma, float* dbeta, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dstats && dgamma && dbeta && C > 0, "bn_affine_grads: bad arguments");
+  hipLaunchKernelGGL(bn_affine_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dstats, dgamma, dbeta, C);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
 extern "C" int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t st) {
   AVEC_CHECK_ARG(gamma && beta && ss && C > 0 && (training ? (stats != nullptr) : (running_mean && running_var)), "bn_finalize: bad arguments");

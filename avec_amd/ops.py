@@ -519,8 +519,7 @@ def _add_local_affine_grads(dstats, gw, gb, C):
     SyncBatchNorm does); only the statistics entering dx are global.  Adds the local sums, then all-reduces `dstats`.  Returns True if it did."""
     if not rt.sync_batchnorm():
         return False
-    gw.add_(dstats[C:2 * C].view_as(gw))
-    gb.add_(dstats[:C].view_as(gb))
+    lib.bn_affine_grads(dstats.data_ptr(), gw.data_ptr(), gb.data_ptr(), C, rt.stream())
     _sync_stats(dstats)
     return True
 

@@ -406,6 +406,10 @@ def sync_bn_stats(stats, nrep, C, count):
     """SyncBatchNorm statistic exchange: collapse the `nrep` replicated [sum | sumsq] partials, append the local element count and sum
     the (2C+1)-vector over ranks.  Returns the reduced vector (global sum, global sumsq, global count)."""
     import torch.distributed as dist
-    red = torch.cat([stats.view(nrep, 2 * C).sum(0), torch.full((1,), float(count), dtype=stats.dtype, device=stats.device)])
+    if stats.is_cuda:
+        red = torch.empty(2 * C + 1, dtype=torch.float32, device=stats.device)
+        lib.bn_collapse(stats.data_ptr(), nrep, float(count), red.data_ptr(), C, stream())
+    else:       # (CPU tensors: the gloo unit tests of the exchange itself)
+        red = torch.cat([stats.view(nrep, 2 * C).sum(0), torch.full((1,), float(count), dtype=stats.dtype, device=stats.device)])
     dist.all_reduce(red, op=dist.ReduceOp.SUM)
     return red

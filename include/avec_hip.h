@@ -104,6 +104,10 @@ int avec_strided_rows_add(float* dx, const float* src, int B, int T, int To, int
 /* BatchNorm{1,2,3}d over channels-last [M][C] (aten::native_batch_norm(_backward), nnet/normalizations.py:42-170).
  * stats = n_replicas x [sum | sumsq] (the GEMM epilogue spreads its atomics over AVEC_STAT_REPLICAS copies); ss = [scale | shift | mean | rstd]; SyncBatchNorm (:172-249) = all-reduce stats/count/dstats between calls. */
 int avec_bn_stats(int dtype, const void* y, float* stats, long long M, int C, hipStream_t stream);
+/* SyncBatchNorm glue (normalizations.SyncBatchNorm, nnet/normalizations.py:172-249): out[2C+1] = collapsed [sum | sumsq] + local count (the vector
+ * the caller all-reduces); dgamma/dbeta += the LOCAL sums of dstats before dstats is all-reduced */
+int avec_bn_collapse(const float* stats, int n_replicas, float count, float* out, int C, hipStream_t stream);
+int avec_bn_affine_grads(const float* dstats, float* dgamma, float* dbeta, int C, hipStream_t stream);
 int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t stream);
 int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t stream);
