@@ -350,11 +350,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char avec_zero16[64];
 
-template <int RB> __device__ __forceinline__ int glds_swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int RB> __device__ __forceinline__ int glds_swz(int row) { return RB == 256 ? (row & 15) : RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
 // RB: bytes of K per LDS row (128: 8 chunks, swizzle (row>>1)&7;  64: 4 chunks, swizzle (row>>2)&3 -- half the ring, twice the resident workgroups)
 template <typename T, int BM, int BN, int MODE, int STAGES, bool FASTC = false, int RB = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
+  static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = RB / (int)sizeof(T);
   constexpr int CPR = RB / 16, RPP = 256 / CPR;      // chunks per row, rows per DMA pass
@@ -465,22 +466,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
     if (STAGES <= 2 || newer <= 0) AVEC_WAIT_VM(0);
     else if (newer == 1) AVEC_WAIT_VM(LPT);
     else if (newer == 2) AVEC_WAIT_VM(2 * LPT);
-    else AVEC_WAIT_VM(3 * LPT);
+    else if (newer == 3) AVEC_WAIT_VM(3 * LPT);
+    else if (newer == 4) AVEC_WAIT_VM(4 * LPT);
+    else if (newer == 5) AVEC_WAIT_VM(5 * LPT);
+    else AVEC_WAIT_VM(6 * LPT);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
     const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * RB;
+    // all operand fragments of the step are requested before the first MFMA (small tiles otherwise wait one LDS latency per MFMA:
+    // the compiler keeps the reads next to their consumer); at most 2 K-substeps of fragments are held at a time for the big tiles
+    constexpr int KK = RB / 32, KG = (MT * NT == 1) ? KK : (KK < 2 ? KK : 2);
 #pragma unroll
-    for (int kk = 0; kk < RB / 32; ++kk) {
-      chunk16 fa[MT], fb[NT];
+    for (int k0 = 0; k0 < KK; k0 += KG) {
+      chunk16 fa[KG][MT], fb[KG][NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + offa[i] + (((kk * 2 + gsel) ^ swa[i]) << 4));
+      for (int q = 0; q < KG; ++q) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + offb[j] + (((kk * 2 + gsel) ^ swb[j]) << 4));
+        for (int i = 0; i < MT; ++i) fa[q][i] = *(const chunk16*)(As + offa[i] + ((((k0 + q) * 2 + gsel) ^ swa[i]) << 4));
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j) fb[q][j] = *(const chunk16*)(Bs + offb[j] + ((((k0 + q) * 2 + gsel) ^ swb[j]) << 4));
+      }
+      asm volatile("" ::: "memory");            // keeps the reads above the MFMAs (the scheduler otherwise sinks each pair next to its consumer)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+      for (int q = 0; q < KG; ++q)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) Mma<T>::run(fa[q][i], fb[q][j], acc[i][j]);
     }
   }
 #undef AVEC_WAIT_VM
@@ -853,6 +866,18 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   static const int stg_env = getenv("AVEC_NT_STG") ? atoi(getenv("AVEC_NT_STG")) : 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
 #define G3(MODE, S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
     if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  static const int small_env = getenv("AVEC_NT_SMALL") ? atoi(getenv("AVEC_NT_SMALL")) : 0;     // experiment: 64x64 plain tiles, 64-byte rows, ring of 6 / 8
+#define G4(S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  if (a16 && !f32src && sizeof(T) == 2 && mode == MODE_PLAIN && (BM + BN) <= 128 && g.K % 32 == 0) { if (small_env == 6) G4(6); if (small_env == 8) G4(8); }
+#undef G4
+  // few-tile plain products (the conformer layers at M = B*T <= 6400: at most ~2 workgroups per CU, so occupancy is not the issue): 256-byte rows
+  // = 128 K-elements per ring step halve the number of barrier / wait / issue rounds
+#define G5(S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 256; \
+    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 256>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 256>), grid, dim3(256), l2, st, g); return 0; } while (0)
+  if (a16 && !f32src && sizeof(T) == 2 && mode == MODE_PLAIN && (BM + BN) <= 128 && (long long)grid.x * grid.y <= 640 && g.K >= 256) {
+    if (small_env == 2) G5(2); if (small_env == 3) G5(3); if (small_env == 4) G5(4); }
+#undef G5
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
