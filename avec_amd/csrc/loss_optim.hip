@@ -183,6 +183,29 @@ extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, cons
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+// nn.CrossEntropyLoss(ignore_index, reduction='none') as losses.SoftmaxCrossEntropy uses it (nnet/losses.py:258-290): one wave per row,
+//   loss[m] = logsumexp(x[m]) - x[m][y[m]]  (0 when y[m] == ignore_index);  mean_out += loss[m] / M  (Reduction('mean') = mean over ALL rows);
+//   grad[m] = softmax(x[m]) - onehot(y[m])  (zero row when ignored)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ x, const long long* __restrict__ y, long long ignore, float* __restrict__ loss,
+                                                         float* mean_out, float* __restrict__ grad, long long M, int V) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * V; const long long t = y[row]; const bool ign = t == ignore || t < 0 || t >= V;
+  float mx = -INFINITY; for (int c = lane; c < V; c += 64) mx = fmaxf(mx, xr[c]);
+  mx = wave_max(mx);
+  float se = 0.f; for (int c = lane; c < V; c += 64) se += __expf(xr[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se);
+  const float l = ign ? 0.f : lse - xr[t];
+  if (lane == 0) { loss[row] = l; if (mean_out) atomicAdd(mean_out, l / (float)M); }
+  if (grad) for (int c = lane; c < V; c += 64) grad[row * V + c] = ign ? 0.f : (__expf(xr[c] - lse) - (c == (int)t ? 1.f : 0.f));
+}
+extern "C" int avec_softmax_ce(const float* logits, const long long* targets, long long ignore_index, float* loss, float* mean_out, float* grad, long long M, int V, hipStream_t st) {
+  AVEC_CHECK_ARG(logits && targets && loss && M > 0 && V > 0, "softmax_ce: bad arguments");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, logits, targets, ignore_index, loss, mean_out, grad, M, V);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // out = g * (*s) * mul    (upstream scalar gradient applied to the saved CTC gradient)
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ g, const float* __restrict__ s, float mul, float* __restrict__ out, long long n) {
   const float f = (s ? *s : 1.f) * mul;

@@ -23,4 +23,21 @@ class CTCLoss(nn.Module):
         return loss * logits.shape[0] if self.reduction == "sum" else loss
 
 
-loss_dict = {"CTC": CTCLoss}
+class SoftmaxCrossEntropy(nn.Module):
+    """nnet/losses.py:258-290: nn.CrossEntropyLoss(ignore_index, reduction='none') followed by Reduction('mean' = mean over every element, ignored
+    ones counting as 0 | 'sum').  logits (..., V), or (B, T, V) with transpose_logits=True (the reference transposes them to class-dim 1)."""
+
+    def __init__(self, ignore_index=-1, transpose_logits=False, reduction="mean"):
+        super().__init__()
+        assert reduction in ("mean", "sum"), "hot path: 'mean' / 'sum'"
+        self.ignore_index, self.transpose_logits, self.reduction = ignore_index, transpose_logits, reduction
+
+    def forward(self, targets, outputs):
+        logits = outputs
+        assert logits.dim() == 2 or self.transpose_logits, "logits (M, V); (B, T, V) needs transpose_logits=True"
+        V = logits.shape[-1]
+        loss = ops.SoftmaxCEFn.apply(logits.reshape(-1, V), targets.reshape(-1), self.ignore_index)
+        return loss * (logits.numel() // V) if self.reduction == "sum" else loss
+
+
+loss_dict = {"CTC": CTCLoss, "SoftmaxCrossEntropy": SoftmaxCrossEntropy}

@@ -30,4 +30,23 @@ class WordErrorRate(nn.Module):
         return 100.0 * errs / max(words, 1)
 
 
-metric_dict = {"WordErrorRate": WordErrorRate}
+class CategoricalAccuracy(nn.Module):
+    """nnet/metrics.py:40-69: 100 * (# argmax(y_pred) == y_true over positions whose target is not ignore_index) / (# such positions)."""
+
+    def __init__(self, ignore_index=-1, dim_argmax=-1, name="acc"):
+        super().__init__()
+        self.name, self.dim_argmax, self.ignore_index = name, dim_argmax, ignore_index
+
+    def forward(self, y_true, y_pred):
+        import torch
+        from .. import ops
+        if self.dim_argmax is not None:
+            assert self.dim_argmax in (-1, y_pred.dim() - 1), "argmax over the last axis"
+            y_pred = ops.argmax_rows(y_pred.float()) if y_pred.is_cuda else y_pred.argmax(dim=-1)
+        y_true = y_true.to(y_pred.device)
+        keep = y_true != self.ignore_index
+        n = int(keep.sum())
+        return 100.0 * float(((y_pred.reshape(y_true.shape) == y_true) & keep).sum()) / max(n, 1)
+
+
+metric_dict = {"WordErrorRate": WordErrorRate, "CategoricalAccuracy": CategoricalAccuracy}

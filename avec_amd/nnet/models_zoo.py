@@ -10,6 +10,29 @@ def _default_adam(model):
     return optimizers.Adam(params=model.parameters(), lr=lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
 
 
+class VisualEfficientConformerCE(Model):
+    """nnet/models_zoo.py:33-62: the LRW word classifier -- visual encoder without InterCTC, head to `vocab_size` classes, logits averaged over time."""
+
+    def __init__(self, vocab_size=500):
+        super().__init__(name="Visual Efficient Conformer CE")
+        self.encoder = networks.VisualEfficientConformerEncoder(vocab_size=vocab_size, interctc_blocks=[])
+
+    def forward(self, inputs):
+        from .. import ops
+        x = self.encoder(inputs, lengths=None)[0]
+        return ops.TimeMeanFn.apply(x) if x.is_cuda else x.mean(dim=1)
+
+    def compile(self, losses=None, loss_weights=None, optimizer="Adam", metrics="default", decoders=None):
+        from . import metrics as M
+        if losses is None:
+            losses = L.SoftmaxCrossEntropy()
+        if metrics == "default":
+            metrics = M.CategoricalAccuracy()
+        if optimizer == "Adam":
+            optimizer = _default_adam(self)
+        super().compile(losses=losses, loss_weights=loss_weights, optimizer=optimizer, metrics=metrics, decoders=decoders)
+
+
 class _InterCTCModel(Model):
     default_loss_weights = None
 

@@ -707,6 +707,54 @@ class CTCLossFn(torch.autograd.Function):
         return out, None, None, None, None, None
 
 
+class TimeMeanFn(torch.autograd.Function):
+    """mean over the time axis of fp32 (B, T, V) logits (VisualEfficientConformerCE.forward, nnet/models_zoo.py:41) = the channels-last average pool"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .lib import F32
+        rt.require_gpu(x)
+        B, T, V = x.shape
+        x = _f32c(x)
+        y = empty((B, V), torch.float32, x)
+        lib.avgpool_fwd(F32, x.data_ptr(), y.data_ptr(), B, T, V, rt.stream())
+        ctx.saved = (B, T, V)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .lib import F32
+        B, T, V = ctx.saved
+        dy = _f32c(dy)
+        dx = empty((B, T, V), torch.float32, dy)
+        lib.avgpool_bwd(F32, dy.data_ptr(), dx.data_ptr(), B, T, V, rt.stream())
+        return dx
+
+
+class SoftmaxCEFn(torch.autograd.Function):
+    """mean over rows of cross-entropy(logits[M,V], targets[M]) with ignore_index (losses.SoftmaxCrossEntropy, nnet/losses.py:258-290)"""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        rt.require_gpu(logits)
+        M, V = logits.shape
+        lg = _f32c(logits)
+        tg = targets.to(device=lg.device, dtype=torch.int64).contiguous()
+        loss = empty((M,), torch.float32, lg)
+        mean = torch.zeros((), dtype=torch.float32, device=lg.device)
+        grad = empty((M, V), torch.float32, lg) if ctx.needs_input_grad[0] else None
+        lib.softmax_ce(lg.data_ptr(), tg.data_ptr(), int(ignore_index), loss.data_ptr(), mean.data_ptr(), _p(grad), M, V, rt.stream())
+        ctx.saved = (grad, M)
+        return mean
+
+    @staticmethod
+    def backward(ctx, dloss):
+        grad, M = ctx.saved
+        out = torch.empty_like(grad)
+        lib.scale_by_scalar(grad.data_ptr(), dloss.float().contiguous().data_ptr(), 1.0 / M, out.data_ptr(), grad.numel(), rt.stream())
+        return out, None, None
+
+
 # ============================================================================================
 # convolutions on channels-last activations (ResNet-18 front-end, nnet/blocks.py:29-91, nnet/networks.py:32-146)
 # ============================================================================================
@@ -942,8 +990,8 @@ def spec_augment_(mel, lens, mF, Fp, mT, pS, sid):
 
 
 def argmax_rows(logits):
-    B, T, V = logits.shape
+    lead, V = logits.shape[:-1], logits.shape[-1]
     lg = _f32c(logits)
-    out = torch.empty((B, T), dtype=torch.int64, device=lg.device)
-    lib.argmax_rows(lg.data_ptr(), out.data_ptr(), B * T, V, rt.stream())
+    out = torch.empty(lead, dtype=torch.int64, device=lg.device)
+    lib.argmax_rows(lg.data_ptr(), out.data_ptr(), out.numel(), V, rt.stream())
     return out

@@ -189,6 +189,9 @@ long long avec_ctc_workspace_floats(int B, int T, int Lmax);
 int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
                   float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
 int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t stream);
+/* losses.SoftmaxCrossEntropy (nnet/losses.py:258-290; the LRW word classifier): per-row cross entropy of fp32 logits [M][V] against int64 targets,
+ * rows with target == ignore_index give 0; mean_out (optional) += loss/M; grad (optional) = softmax - onehot */
+int avec_softmax_ce(const float* logits, const long long* targets, long long ignore_index, float* loss, float* mean_out, float* grad, long long M, int V, hipStream_t stream);
 /* CTCGreedySearchDecoder argmax (nnet/decoders.py:97-120) */
 int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStream_t stream);
 /* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */

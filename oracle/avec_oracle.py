@@ -342,6 +342,23 @@ def av_forward(sd, video, video_len, audio, audio_len, train=True, stats_out=Non
     return out
 
 
+def lrw_forward(sd, video, train=True, stats_out=None):
+    """nnet/models_zoo.py:33-41 (VisualEfficientConformerCE): visual encoder (nnet/networks.py:442-512, num_blocks [6,6], no InterCTC, lengths None = no
+    mask) -> head -> mean over time.  video: (B,1,T,H,W) -> logits (B, vocab)."""
+    p = "encoder"
+    v = visual_frontend(sd, p + ".front_end", video, train, stats_out)
+    v, _, _ = conformer_interctc(sd, p + ".back_end", v, None, [6, 6], (), "ctc", [1, 1], train, stats_out)
+    return linear(sd, p + ".head", v).mean(dim=1)
+
+
+def softmax_cross_entropy(logits, targets, ignore_index=-1):
+    """nnet/losses.py:258-290: per-element cross entropy (0 where the target is ignore_index), then the mean over ALL elements."""
+    lp = F.log_softmax(logits.float(), dim=-1)
+    keep = targets != ignore_index
+    nll = -lp.gather(-1, targets.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    return torch.where(keep, nll, torch.zeros_like(nll)).mean()
+
+
 def ao_forward(sd, audio, audio_len, train=True, stats_out=None, interctc=(3, 6, 10, 13), num_blocks=(5, 6, 5)):
     """nnet/models_zoo.py:64-97 + nnet/networks.py:411-440 (att_type='patch')."""
     p = "encoder"

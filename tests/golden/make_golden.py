@@ -242,7 +242,38 @@ def full_model_case():
     print("wrote ao_cfg1_seed0.json")
 
 
+def lrw_case():
+    """BASELINE config 1: the LRW word classifier (VisualEfficientConformerCE), synthetic 29x88x88 clips, seed-0 init, train-mode BatchNorm, dropout off"""
+    torch.manual_seed(0)
+    model = nnet.VisualEfficientConformerCE(vocab_size=500)
+    model.compile()
+    nodrop(model).train()
+    sd = model.state_dict()
+    info = {"state_dict": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()],
+            "n_params": sum(p.numel() for p in model.parameters()),
+            "param_checksums": {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items() if v.is_floating_point()}}
+    torch.manual_seed(3)
+    video = torch.randn(2, 1, 29, 88, 88)
+    labels = torch.randint(0, 500, (2,))
+    logits = model(video)
+    losses, metrics, _, _ = model.forward_model(video, labels)
+    losses["loss"].backward()
+    info["logits_shape"] = list(logits.shape)
+    info["logits_head"] = logits[:, :8].tolist()
+    info["loss"] = float(losses["loss"])
+    info["labels"] = labels.tolist()
+    info["input_seed"] = 3
+    info["grad_norms"] = {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None and k in
+                          ("encoder.head.weight", "encoder.back_end.conformer_blocks.11.feed_forward_module2.layers.4.weight",
+                           "encoder.front_end.3.head.1.weight", "encoder.front_end.0.layers.0.0.weight")}
+    json.dump(info, open(os.path.join(HERE, "lrw_ce_seed0.json"), "w"))
+    print("wrote lrw_ce_seed0.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lrw":
+        lrw_case()
+        sys.exit(0)
     conformer_block_case("block_relpos", 32, 32, 20, 1, 1, [20, 13, 7], 1)
     conformer_block_case("block_patch", 32, 32, 20, 1, 3, [20, 16, 4], 2)
     conformer_block_case("block_strided_patch", 32, 48, 21, 2, 3, [21, 10], 3)

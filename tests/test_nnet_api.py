@@ -116,3 +116,20 @@ def test_c_abi_argument_validation_without_gpu():
         lib.layernorm_fwd(0, None, None, None, None, 0, None, None, 4, 8, 1e-6, None)
     with pytest.raises(RuntimeError, match="bad dims"):
         lib.ctc_loss(1, 1, 1, 1, 1, None, None, 1, 0, 5, 4, 2, 0, 1, None)
+
+
+def test_lrw_classifier_api_and_seeded_init_match_reference():
+    """BASELINE config 1 (VisualEfficientConformerCE, nnet/models_zoo.py:33-62): state_dict keys/shapes, parameter count and the seed-0
+    initial values equal the reference's (tests/golden/lrw_ce_seed0.json, written by tests/golden/make_golden.py lrw)."""
+    import nnet
+    g = load_json("lrw_ce_seed0")
+    torch.manual_seed(0)
+    model = nnet.VisualEfficientConformerCE(vocab_size=500)
+    model.compile()
+    sd = model.state_dict()
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()] == g["state_dict"]
+    assert sum(p.numel() for p in model.parameters()) == g["n_params"] == 40489740
+    for k, (s1, s2) in g["param_checksums"].items():
+        v = sd[k].double()
+        assert abs(float(v.sum()) - s1) <= 1e-6 * max(1.0, abs(s1)) and abs(float(v.abs().sum()) - s2) <= 1e-6 * max(1.0, abs(s2)), k
+    assert nnet.CategoricalAccuracy()(torch.tensor([1, 2, -1]), torch.tensor([[0., 1., 0.], [0., 1., 0.], [1., 0., 0.]])) == 50.0

@@ -176,3 +176,22 @@ def test_adam_steps():
     for s in range(3):
         p, m, v = O.adam_update(p, g["g"][s], m, v, s + 1, O.noam_lr(s + 1))
         assert torch.allclose(p, g["p"][s], rtol=1e-6, atol=1e-9)
+
+
+def test_lrw_classifier_oracle_matches_reference_golden():
+    """oracle.lrw_forward + softmax_cross_entropy on the seed-0 LRW classifier against the reference's own logits / loss
+    (tests/golden/lrw_ce_seed0.json): pins the oracle for BASELINE config 1."""
+    import nnet
+    g = load_json("lrw_ce_seed0")
+    torch.manual_seed(0)
+    model = nnet.VisualEfficientConformerCE(vocab_size=500)      # seeded init == reference (tests/test_nnet_api.py)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(g["input_seed"])
+    video = torch.randn(2, 1, 29, 88, 88)
+    labels = torch.randint(0, 500, (2,))
+    assert labels.tolist() == g["labels"]
+    with torch.no_grad():
+        logits = O.lrw_forward(sd, video, train=True, stats_out={})
+    assert list(logits.shape) == g["logits_shape"]
+    assert rel_err(logits[:, :8], torch.tensor(g["logits_head"])) < 1e-4
+    assert abs(float(O.softmax_cross_entropy(logits, labels)) - g["loss"]) < 1e-4 * g["loss"]
