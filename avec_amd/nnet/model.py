@@ -247,7 +247,7 @@ class Model(Module):
                 losses, _, acc_step = self.train_step(inputs, targets, precision, None, accumulated_steps, acc_step, eval_training)
                 n += 1
                 if self.rank == 0 and step % step_log_period == 0:
-                    print("epoch %d step %d model_step %d loss %.4f" % (epoch + 1, step, int(self.model_step), float(losses["loss"])))
+                    print("epoch %d step %d model_step %d loss %.4f" % (epoch + 1, step, int(self.model_step), float(losses["loss"].detach())))
                 if steps_per_epoch is not None and step + 1 >= steps_per_epoch:
                     break
             if self.rank == 0:
@@ -258,6 +258,9 @@ class Model(Module):
                 self.evaluate(dataset_eval, eval_steps)
 
     def evaluate(self, dataset_eval, eval_steps=None, verbose=0, eval_loss=True, recompute_metrics=False):
+        if isinstance(dataset_eval, (list, tuple)):          # several evaluation sets (the reference configs list LRS2 and LRS3 test sets)
+            res = [self.evaluate(d, eval_steps, verbose, eval_loss, recompute_metrics) for d in dataset_eval]
+            return res[0] if len(res) == 1 else res
         self.eval()
         sums, count = {}, 0
         for step, batch in enumerate(dataset_eval):
@@ -272,6 +275,8 @@ class Model(Module):
         return {k: v / max(count, 1) for k, v in sums.items()}
 
     def eval_time(self, dataset_eval, eval_steps=None, **kwargs):
+        if isinstance(dataset_eval, (list, tuple)):
+            return sum(self.eval_time(d, eval_steps, **kwargs) for d in dataset_eval)
         self.eval()
         torch.cuda.synchronize()
         t0 = time.time()
