@@ -114,13 +114,21 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const float* __restrict_
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 18; ++s) {
+    // operands of 3 k-steps are requested ahead of the MFMAs that consume them (one wave per SIMD: nothing else hides the LDS latency)
+    chunk16 fa[18];
+    auto ldfrag = [&](int s) {
       const int offA = rowoff[2 * s > 34 ? 34 : 2 * s], offB = rowoff[2 * s + 1 > 34 ? 34 : 2 * s + 1];
       const uint32_t* rp = (const uint32_t*)(pix + (g ? offB : offA));          // even element index: 4-byte aligned
-      chunk16 fa; fa.w[0] = rp[0]; fa.w[1] = rp[1]; fa.w[2] = rp[2]; fa.w[3] = rp[3];
-      acc[0] = mma16(fa, wf[s][0], acc[0]);
-      acc[1] = mma16(fa, wf[s][1], acc[1]);
+      chunk16 f; f.w[0] = rp[0]; f.w[1] = rp[1]; f.w[2] = rp[2]; f.w[3] = rp[3]; return f;
+    };
+#pragma unroll
+    for (int s = 0; s < 3; ++s) fa[s] = ldfrag(s);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      if (s + 3 < 18) fa[s + 3] = ldfrag(s + 3);
+      asm volatile("" ::: "memory");
+      acc[0] = mma16(fa[s], wf[s][0], acc[0]);
+      acc[1] = mma16(fa[s], wf[s][1], acc[1]);
     }
     // epilogue: + bias, statistics, bf16, staged through LDS for 16-byte row stores
     unsigned short* stw = stage + wave * 32 * 72;
