@@ -149,6 +149,7 @@ class Model(Module):
     # -- one optimisation micro-step (nnet/model.py:346-409) ---------------------------------------
     def train_step(self, inputs, targets, precision=torch.float32, grad_scaler=None, accumulated_steps=1, acc_step=0, eval_training=False):
         rt.set_compute_dtype(precision)
+        rt.reset_zero_pool(self.device)
         batch_losses, batch_metrics, _, _ = self.forward_model(inputs, targets, compute_metrics=eval_training)
         (batch_losses["loss"] / accumulated_steps).backward()
         rt.advance_rng(self.device)
@@ -179,6 +180,7 @@ class Model(Module):
         static_tg = tuple(t.clone() for t in targets)
 
         def body():
+            rt.reset_zero_pool(self.device)
             losses, _, _, _ = self.forward_model(static_in, static_tg, compute_metrics=False)
             losses["loss"].backward()
             rt.advance_rng(self.device)

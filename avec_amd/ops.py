@@ -476,7 +476,7 @@ class BNState:
     NREP = 64      # AVEC_STAT_REPLICAS: the GEMM epilogue spreads its statistic atomics over this many [2C] copies
 
     def __init__(self, C, ref):
-        self.stats = torch.zeros(self.NREP * 2 * C, dtype=torch.float32, device=ref.device)
+        self.stats = rt.zeros_scratch(self.NREP * 2 * C, ref.device)
         self.red = None
         self.ss = torch.empty(4 * C, dtype=torch.float32, device=ref.device)
         self.C = C
@@ -502,7 +502,7 @@ def bn_finalize(bn, st, count, training):
 def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
     C = st.C
     adt = rt.act_dtype()
-    dstats = torch.zeros(2 * C, dtype=torch.float32, device=dout.device)
+    dstats = rt.zeros_scratch(2 * C, dout.device)
     lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
     gw, gb = grad_of(bn.weight), grad_of(bn.bias)
     if _add_local_affine_grads(dstats, gw, gb, C):

@@ -131,6 +131,44 @@ def branch_stream():
     return None if torch.cuda.current_stream() == side else side
 
 
+# ---- pool of pre-zeroed scratch --------------------------------------------------------------------------------------------------------
+# BatchNorm statistic accumulators (64 replicas x 2C floats per layer, 2C per layer in backward) must start at zero; ~90 of them per step
+# would each cost a fill launch.  They are carved out of one buffer that a training step zeroes ONCE at its start (Model.train_step / the
+# captured graph body); allocations only move forward inside a step, so nothing handed out is reused before the next reset.  Outside a
+# training step (evaluation, direct op calls) the pool is never reset: once exhausted, plain torch.zeros takes over.
+_ZPOOL = {"buf": {}, "off": {}, "floats": 4 << 20}
+
+
+def zeros_scratch(n, device):
+    """fp32 [n], zero-initialised; valid until the next reset_zero_pool() on this device"""
+    key = str(device)
+    buf = _ZPOOL["buf"].get(key)
+    if buf is None:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    off = _ZPOOL["off"][key]
+    n4 = (n + 3) // 4 * 4
+    if off + n4 > buf.numel():
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    _ZPOOL["off"][key] = off + n4
+    return buf[off:off + n]
+
+
+def reset_zero_pool(device):
+    """start of a training step: every scratch buffer of the previous step is dead (same-stream order); re-zero what was handed out"""
+    key = str(device)
+    buf = _ZPOOL["buf"].get(key)
+    if buf is None:
+        buf = _ZPOOL["buf"][key] = torch.zeros(_ZPOOL["floats"], dtype=torch.float32, device=device)
+        _ZPOOL["off"][key] = 0
+        _ZPOOL.setdefault("hi", {})[key] = 0
+        return
+    hi = max(_ZPOOL["hi"].get(key, 0), _ZPOOL["off"][key])      # under graph capture the memset must cover what any replay can use: the high-water mark
+    _ZPOOL["hi"][key] = hi
+    if hi:
+        buf[:hi].zero_()
+    _ZPOOL["off"][key] = 0
+
+
 def ensure_shadows_fresh(module):
     """Refresh the arena's weight shadows on the CURRENT stream (before work is forked to other streams)."""
     for p in module.parameters():
