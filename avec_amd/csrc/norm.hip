@@ -302,8 +302,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     st4<T>(out + off, v);
   }
 }
+// 8-wide variant (C % 8 == 0, < 2^31 chunks): 16-byte accesses, 32-bit index arithmetic (the 4-wide kernel pays a 64-bit modulo per access)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,
+                                                        T* __restrict__ out, unsigned n8, int C) {
+  const unsigned C8 = (unsigned)C >> 3;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) {
+    const long long off = (long long)i * 8; const int c = (int)(i % C8) * 8;
+    float v[8], sc[8], sh[8]; ld8<T>(y + off, v); ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (res) { float r[8]; ld8<T>(res + off, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e]; }
+    if (act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+    } else if (act == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    st8<T>(out + off, v);
+  }
+}
 extern "C" int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: bad arguments");
+  if (C % 8 == 0 && M * C / 8 < (1ll << 31)) {
+    const long long n8 = M * C / 8; long long nb8 = (n8 + 255) / 256; if (nb8 > 8192) nb8 = 8192;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, act, (T*)out, (unsigned)n8, C));
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   long long n4 = M * C / 4; long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, act, (T*)out, n4, C));
   AVEC_LAUNCH_CHECK(); return 0;
@@ -396,9 +424,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     if (dres) st4<T>(dres + off, dr);
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count, int act,
+                                                            T* __restrict__ dy, T* __restrict__ dres, float* dgamma, float* dbeta, unsigned n8, int C) {
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  const unsigned C8 = (unsigned)C >> 3;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) {
+    const long long off = (long long)i * 8; const int c = (int)(i % C8) * 8;
+    float d[8], v[8], mu[8], rs[8], g[8], s1[8], s2[8], o[8];
+    ld8<T>(dout + off, d); ld8<T>(y + off, v); ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
+    if (act == 2 && out) { float q[8]; ld8<T>(out + off, q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = q[e] > 0.f ? d[e] : 0.f;
+    } else if (act != 0) {
+      float sc[8], sh[8]; ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float pre = v[e] * sc[e] + sh[e]; d[e] = act == 1 ? d[e] * dswishf_(pre) : (pre > 0.f ? d[e] : 0.f); }
+    }
+    ld8<float>(gamma + c, g); ld8<float>(dstats + c, s1); ld8<float>(dstats + C + c, s2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = g[e] * rs[e] * (d[e] - s1[e] * inv_n - (v[e] - mu[e]) * rs[e] * s2[e] * inv_n);
+    st8<T>(dy + off, o);
+    if (dres) st8<T>(dres + off, d);
+  }
+}
 extern "C" int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
                                  const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && ss && gamma && dstats && dy && M > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+  if (C % 8 == 0 && M * C / 8 < (1ll << 31)) {
+    const long long n8 = M * C / 8; long long nb8 = (n8 + 255) / 256; if (nb8 > 8192) nb8 = 8192;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, gamma, dstats,
+                                         count_ptr, count, act, (T*)dy, (T*)dres, dgamma, dbeta, (unsigned)n8, C));
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   long long n4 = M * C / 4; long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, gamma, dstats,
                                        count_ptr, count, act, (T*)dy, (T*)dres, dgamma, dbeta, n4, C));
