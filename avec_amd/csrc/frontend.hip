@@ -124,7 +124,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_act_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ a, long long M, int J, int Fo, int C) {
   const long long total = M * J;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % J) / Fo; stf(a + i, swishf_(ldf(y + i) * ss[c] + ss[C + c]));
+    const int c = (int)((unsigned)(i % (long long)J)) / Fo; stf(a + i, swishf_(ldf(y + i) * ss[c] + ss[C + c]));
   }
 }
 // pass 1: dstats[c] += sum dr, dstats[C+c] += sum dr*yhat   with dr = da * swish'(pre)
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict_
                                                             long long Fr, int H, int W, int C, int OH, int OW) {
   const long long n4 = Fr * OH * OW * (C / 4);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % (C / 4)) * 4; long long r = i / (C / 4); const int ow = (int)(r % OW); r /= OW; const int oh = (int)(r % OH); const long long fr = r / OH;
+    const unsigned iu = (unsigned)i, C4 = (unsigned)C >> 2;      // host-checked: fewer than 2^31 work items -> 32-bit divisions
+    const int c = (int)(iu % C4) * 4; unsigned r = iu / C4; const int ow = (int)(r % (unsigned)OW); r /= (unsigned)OW; const int oh = (int)(r % (unsigned)OH); const long long fr = r / (unsigned)OH;
     float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh);
     float best[4] = {0.f, 0.f, 0.f, 0.f}; unsigned bi[4] = {255u, 255u, 255u, 255u};
     float v[9][4]; bool ok[9];                          // unconditional (clamped) loads first: loads under divergent `continue`s are serialised
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_reduce8_kernel(const T* __r
     const int c = m.l * 8;
     float mu[8], rs[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
     for (long long row = (long long)blockIdx.x * m.R + m.r; row < M; row += (long long)gridDim.x * m.R) {
-      const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+      const unsigned ru = (unsigned)row; const int w = (int)(ru % (unsigned)W); const unsigned r = ru / (unsigned)W; const int h = (int)(r % (unsigned)H); const long long fr = r / (unsigned)H;
       float dr[8], v[8]; stem_dr8<T>(dp, idx, fr, h, w, c, C, OH, OW, dr); ld8<T>(y + row * C + c, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { part[0][e] += dr[e]; part[1][e] += dr[e] * (v[e] - mu[e]) * rs[e]; }
@@ -446,8 +447,8 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_apply8_kernel(const T* __re
   if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
   const int C8 = C / 8; const long long n8 = Fr * H * W * C8;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C8) * 8; const long long row = i / C8;
-    const int w = (int)(row % W); long long r = row / W; const int h = (int)(r % H); const long long fr = r / H;
+    const unsigned iu = (unsigned)i; const int c = (int)(iu % (unsigned)C8) * 8; const unsigned rowu = iu / (unsigned)C8; const long long row = rowu;
+    const int w = (int)(rowu % (unsigned)W); const unsigned r = rowu / (unsigned)W; const int h = (int)(r % (unsigned)H); const long long fr = r / (unsigned)H;
     float dr[8], v[8], mu[8], rs[8], g[8], s1[8], s2[8], o[8];
     stem_dr8<T>(dp, idx, fr, h, w, c, C, OH, OW, dr); ld8<T>(y + row * C + c, v);
     ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs); ld8<float>(gamma + c, g); ld8<float>(dstats + c, s1); ld8<float>(dstats + C + c, s2);
@@ -514,14 +515,14 @@ extern "C" int avec_stem_im2col(int dtype, const float* video, void* A, long lon
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t st) {
-  AVEC_CHECK_ARG(y && ss && out && idx && frames > 0 && H > 0 && W > 0 && C % 4 == 0, "stem_pool_fwd: bad arguments");
+  AVEC_CHECK_ARG(y && ss && out && idx && frames > 0 && H > 0 && W > 0 && C % 4 == 0 && frames * H * W * (C / 4) < (1ll << 31), "stem_pool_fwd: bad arguments");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; long long n4 = frames * OH * OW * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
   DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)out, idx, frames, H, W, C, OH, OW));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                                   const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t st) {
-  AVEC_CHECK_ARG(dpool && idx && y && ss && gamma && dstats && (phase == 0 || dy) && frames > 0 && C % 4 == 0, "stem_pool_bwd: bad arguments");
+  AVEC_CHECK_ARG(dpool && idx && y && ss && gamma && dstats && (phase == 0 || dy) && frames > 0 && C % 4 == 0 && frames * H * W * (C / 4) < (1ll << 31), "stem_pool_bwd: bad arguments");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   if (C % 8 == 0 && C <= 2048) {
     if (phase == 0) {

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void grad_prep_flat_kernel(const float* __rest
                                                              const unsigned long long* rng, unsigned stream, long long M, int N) {
   const int N4 = N >> 2; const long long n4 = M * N4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const long long row = i / N4; const int col = (int)(i - row * N4) * 4;
+    const long long row = n4 < (1ll << 31) ? (long long)((unsigned)i / (unsigned)N4) : i / N4; const int col = (int)(i - row * N4) * 4;
     float v[4]; ld4<float>(dout + row * ldd + col, v);
     for (int e = 0; e < 4; ++e) v[e] *= alpha * drop_scale(rng, stream, (unsigned long long)row * N + col + e, p);
     st4<T>(dacc + row * N + col, v);
