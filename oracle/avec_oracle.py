@@ -342,6 +342,19 @@ def av_forward(sd, video, video_len, audio, audio_len, train=True, stats_out=Non
     return out
 
 
+def vo_forward(sd, video, video_len, train=True, stats_out=None, interctc=(3, 6, 9)):
+    """nnet/models_zoo.py:99-147 + nnet/networks.py:442-512 (VisualEfficientConformerInterCTC): video (B,T,H,W,1) -> {"outputs", "ctc_2", "ctc_5", "ctc_8"}."""
+    p = "encoder"
+    v = visual_frontend(sd, p + ".front_end", video.permute(0, 4, 1, 2, 3), train, stats_out)
+    v, vlen, inter = conformer_interctc(sd, p + ".back_end", v, video_len, [6, 6], interctc, "ctc", [1, 1], train, stats_out)
+    out = {"outputs": [linear(sd, p + ".head", v), vlen]}
+    out.update(inter)
+    return out
+
+
+VO_LOSS_WEIGHTS = [0.5 / 3, 0.5 / 3, 0.5 / 3, 0.5]      # list, mapped positionally onto (outputs, ctc_2, ctc_5, ctc_8): nnet/models_zoo.py:124, nnet/model.py:119-149
+
+
 def lrw_forward(sd, video, train=True, stats_out=None):
     """nnet/models_zoo.py:33-41 (VisualEfficientConformerCE): visual encoder (nnet/networks.py:442-512, num_blocks [6,6], no InterCTC, lengths None = no
     mask) -> head -> mean over time.  video: (B,1,T,H,W) -> logits (B, vocab)."""

@@ -270,7 +270,34 @@ def lrw_case():
     print("wrote lrw_ce_seed0.json")
 
 
+def vo_case():
+    """visual-only VisualEfficientConformerInterCTC (default InterCTC after blocks 3, 6, 9), seed-0 init, train-mode BatchNorm, dropout off, ragged lengths"""
+    torch.manual_seed(0)
+    model = nnet.VisualEfficientConformerInterCTC()
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
+    nodrop(model).train()
+    sd = model.state_dict()
+    info = {"state_dict": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()], "n_params": sum(p.numel() for p in model.parameters())}
+    torch.manual_seed(5)
+    video = torch.randn(2, 40, 88, 88, 1)
+    vlen = torch.tensor([40, 27])
+    labels, llen = torch.randint(1, 256, (2, 6)), torch.tensor([6, 4])
+    outputs = model([video, vlen])
+    losses, _, _, _ = model.forward_model([video, vlen], (labels, llen), compute_metrics=False)
+    info["losses"] = {k: float(v) for k, v in losses.items()}
+    info["output_lengths"] = {k: v[1].tolist() for k, v in outputs.items()}
+    info["output_shapes"] = {k: list(v[0].shape) for k, v in outputs.items()}
+    info["logits_head"] = {k: v[0][0, :2, :6].tolist() for k, v in outputs.items()}
+    info["labels"] = labels.tolist()
+    info["input_seed"] = 5
+    json.dump(info, open(os.path.join(HERE, "vo_interctc_seed0.json"), "w"))
+    print("wrote vo_interctc_seed0.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "vo":
+        vo_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lrw":
         lrw_case()
         sys.exit(0)

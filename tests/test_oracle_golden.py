@@ -195,3 +195,29 @@ def test_lrw_classifier_oracle_matches_reference_golden():
     assert list(logits.shape) == g["logits_shape"]
     assert rel_err(logits[:, :8], torch.tensor(g["logits_head"])) < 1e-4
     assert abs(float(O.softmax_cross_entropy(logits, labels)) - g["loss"]) < 1e-4 * g["loss"]
+
+
+def test_vo_interctc_oracle_matches_reference_golden():
+    """oracle.vo_forward + CTC losses on the seed-0 visual-only InterCTC model against the reference's own outputs (tests/golden/vo_interctc_seed0.json)"""
+    import nnet
+    g = load_json("vo_interctc_seed0")
+    torch.manual_seed(0)
+    model = nnet.VisualEfficientConformerInterCTC()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()] == g["state_dict"]
+    torch.manual_seed(g["input_seed"])
+    video = torch.randn(2, 40, 88, 88, 1)
+    vlen = torch.tensor([40, 27])
+    labels, llen = torch.randint(1, 256, (2, 6)), torch.tensor([6, 4])
+    assert labels.tolist() == g["labels"]
+    with torch.no_grad():
+        out = O.vo_forward(sd, video, vlen, train=True, stats_out={})
+    total = 0.0
+    for w, k in zip(O.VO_LOSS_WEIGHTS, out):          # positional mapping of the weight list
+        lg, ln = out[k]
+        assert list(lg.shape) == g["output_shapes"][k] and [int(x) for x in ln] == g["output_lengths"][k]
+        assert rel_err(lg[0, :2, :6], torch.tensor(g["logits_head"][k])) < 1e-4
+        l = float(O.ctc_nll(lg, ln, labels, llen).mean())
+        assert abs(l - g["losses"]["loss_" + k]) < 1e-4 * g["losses"]["loss_" + k]
+        total += w * l
+    assert abs(total - g["losses"]["loss"]) < 1e-4 * g["losses"]["loss"]
