@@ -64,7 +64,7 @@ def pmc_traffic(family):
     if not family or not os.path.exists(path):
         return None
     want_tn = family.startswith("gemm_tn")
-    want_mode = {"plain": 0, "conv_fwd": 1, "conv_bwd_data": 2, "conv_wgrad": 1}.get(family[family.find("<") + 1:-1])
+    want_mode = {"plain": 0, "conv_fwd": 1, "conv_bwd_data": 2, "conv_wgrad": 1}.get(family[family.find("<") + 1:-1]) if "<" in family else "all"
     if want_mode is None:
         return None
     tot, n = 0.0, 0
@@ -74,7 +74,7 @@ def pmc_traffic(family):
             continue
         args = [a.strip() for a in m.group(2).split(",")]
         mode = int(args[2] if m.group(1) == "gemm_tn_tr_kernel" else args[3])
-        if mode != want_mode:
+        if want_mode != "all" and mode != want_mode:
             continue
         tot += v["launches"] * (v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0))
         n += v["launches"]
