@@ -150,6 +150,8 @@ class Model(Module):
     def train_step(self, inputs, targets, precision=torch.float32, grad_scaler=None, accumulated_steps=1, acc_step=0, eval_training=False):
         rt.set_compute_dtype(precision)
         rt.reset_zero_pool(self.device)
+        if self.is_distributed and self.arena is not None:       # overlap part of the gradient exchange with the backward pass of the last micro-step
+            self.arena.arm_early_all_reduce(acc_step + 1 >= accumulated_steps and os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0")
         batch_losses, batch_metrics, _, _ = self.forward_model(inputs, targets, compute_metrics=eval_training)
         (batch_losses["loss"] / accumulated_steps).backward()
         rt.advance_rng(self.device)

@@ -202,6 +202,16 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             for t in [audio, audio_len] + [u for v in a_inter.values() for u in (v if isinstance(v, (list, tuple)) else [v])]:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(main)
+        arena = rt.arena_of(self.fusion_module) if audio.is_cuda else None
+        if arena is not None and getattr(arena, "_early_armed", False):
+            # distributed training: when the gradient reaches these two tensors, the fusion module / audio-visual encoder / head gradients are final ->
+            # their all-reduce starts while the two encoders are still back-propagating; the audio encoder's follows when its own backward ends
+            r_f, r_h = arena.range_of(self.fusion_module), arena.range_of(self.head) if not isinstance(self.head, nn.Identity) else arena.range_of(self.audio_visual_encoder)
+            r_a = arena.range_of(self.audio_encoder)
+            arena._boundary_fired = False
+            arena._audio_range = r_a
+            if r_f is not None and r_h is not None and r_h[1] >= r_f[0]:
+                audio, video = rt.grad_boundary(audio, arena, r_f[0], r_h[1]), rt.grad_boundary(video, arena, r_f[0], r_h[1])
         x = self.fusion_module(audio, video)
         x, lengths, inter = self.audio_visual_encoder(x, audio_len)
         inter.update(v_inter)

@@ -966,6 +966,11 @@ class AudioStemFn(torch.autograd.Function):
             gw = gb = None
         lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
                            _p(gw), _p(gb), B, NM, F, C, rt.stream())
+        arena = rt.arena_of(bn)
+        if arena is not None and getattr(arena, "_early_armed", False) and getattr(arena, "_audio_range", None):
+            lo, hi = arena._audio_range                       # the stem is the first op of the audio encoder: its backward is the last one of that branch
+            arena._audio_range = None
+            arena.early_all_reduce(lo, hi)
         return None, None, None, None, None
 
 

@@ -169,6 +169,36 @@ def reset_zero_pool(device):
     _ZPOOL["off"][key] = 0
 
 
+class _GradBoundaryFn(torch.autograd.Function):
+    """identity; its backward runs when the gradient crosses the boundary, i.e. when everything downstream of it has been back-propagated"""
+
+    @staticmethod
+    def forward(ctx, x, arena, lo, hi):
+        ctx.saved = (arena, lo, hi)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        arena, lo, hi = ctx.saved
+        if not getattr(arena, "_boundary_fired", False):
+            arena._boundary_fired = True
+            arena.early_all_reduce(lo, hi)
+        return g, None, None, None
+
+
+def grad_boundary(x, arena, lo, hi):
+    """mark `x` as an input of the sub-network whose parameters live in arena[lo:hi) (distributed training only)"""
+    if arena is None or not getattr(arena, "_early_armed", False) or not x.requires_grad:
+        return x
+    return _GradBoundaryFn.apply(x, arena, lo, hi)
+
+
+def arena_of(module):
+    for p in module.parameters():
+        return getattr(p, "_avec_arena", None)
+    return None
+
+
 def ensure_shadows_fresh(module):
     """Refresh the arena's weight shadows on the CURRENT stream (before work is forked to other streams)."""
     for p in module.parameters():
@@ -337,6 +367,7 @@ class ParamArena:
             new.copy_(p.data)
             p.data = new
             p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+            p._avec_arena = self
         self.device = dev
         self._shadow_dtype = None
         self.dirty = True
@@ -423,10 +454,39 @@ class ParamArena:
     def zero_grad(self):
         self.grad.zero_()
 
+    def range_of(self, module):
+        """[lo, hi) of the arena occupied by `module`'s parameters, or None if they are not one contiguous block"""
+        ids = {id(p) for p in module.parameters()}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        last = idx[-1]
+        hi = self.offsets[last + 1] if last + 1 < len(self.offsets) else self.numel
+        return self.offsets[idx[0]], hi
+
+    def early_all_reduce(self, lo, hi):
+        """Start the gradient all-reduce of arena range [lo, hi) now (its gradients are final), on the current stream, asynchronously: the exchange
+        of the audio-visual encoder's and the audio encoder's gradients overlaps the rest of the backward pass.  No-op unless armed by train_step."""
+        if not getattr(self, "_early_armed", False) or hi <= lo:
+            return
+        import torch.distributed as dist
+        self._early.append((lo, hi, dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+
+    def arm_early_all_reduce(self, flag):
+        self._early_armed, self._early = bool(flag), []
+
     def all_reduce_grads(self, bucket_bytes=64 << 20):
         """DDP gradient averaging: sum over ranks in large contiguous buckets (RCCL over xGMI); the 1/world factor is
-        folded into the Adam kernel's grad_scale."""
-        all_reduce_flat(self.grad, bucket_bytes)
+        folded into the Adam kernel's grad_scale.  Ranges already started by early_all_reduce() are only waited for."""
+        early = sorted(getattr(self, "_early", []), key=lambda t: t[0])
+        pos = 0
+        for lo, hi, _ in early + [(self.numel, self.numel, None)]:
+            if lo > pos:
+                all_reduce_flat(self.grad[pos:lo], bucket_bytes)
+            pos = max(pos, hi)
+        for _, _, work in early:
+            work.wait()
+        self._early, self._early_armed = [], False
 
 
 def all_reduce_flat(flat, bucket_bytes=64 << 20):

@@ -162,7 +162,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    loss = float(last["loss"])
+    loss = float(last["loss"].detach())
     assert loss == loss and abs(loss) < 1e6, "training step produced a non-finite loss"
 
     if rank == 0:

@@ -19,6 +19,10 @@ def test_two_rank_step_equals_single_process(tmp_path):
                     "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", "gloo", "--share-gpu"],
                    check=True, env=env, timeout=900)
     a, b = torch.load(single), torch.load(ddp)
+    # the overlapped exchange really ran: (fusion + audio-visual encoder + head) and (audio encoder) ranges, disjoint, inside the arena
+    assert len(b["early"]) == 2 and not a["early"], b["early"]
+    (l0, h0), (l1, h1) = sorted(b["early"])
+    assert 0 <= l0 < h0 <= l1 < h1 <= b["numel"]
     assert abs(float(a["loss"]) - float(b["loss"])) < 1e-4 * abs(float(a["loss"]))
     # same math, different fp32 summation order (atomics, per-rank partial sums).  The BatchNorm-heavy visual front-end is ill-conditioned
     # in fp32 (the reference itself is several % from an fp64 evaluation there, see test_full_model_grads_match_oracle): looser bound.

@@ -39,8 +39,11 @@ def main():
     sl = slice(rank * B // world, (rank + 1) * B // world)
     inputs = [t[sl].to(dev) for t in (video, vlen, audio, alen)]
     targets = (labels[sl].to(dev), llen[sl].to(dev))
+    if world > 1:
+        model.arena.arm_early_all_reduce(True)               # as train_step does: two arena ranges are exchanged while backward is still running
     losses, _, _, _ = model.forward_model(inputs, targets, compute_metrics=False)
     losses["loss"].backward()
+    early = [(lo, hi) for lo, hi, _ in getattr(model.arena, "_early", [])]
     if world > 1:
         model.arena.all_reduce_grads()
     grad = model.arena.grad / world
@@ -50,8 +53,9 @@ def main():
         loss /= world
     if rank == 0:
         bn = model.encoder.video_encoder.front_end[3].blocks[0].layers[1]
-        names = {k: (o, p_.numel()) for (k, p_), o in zip(model.named_parameters(), model.arena.offsets)}
-        torch.save({"grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
+        off_of = {id(p_): o for p_, o in zip(model.arena.params, model.arena.offsets)}
+        names = {k: (off_of[id(p_)], p_.numel()) for k, p_ in model.named_parameters()}
+        torch.save({"early": early, "numel": model.arena.numel, "grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
