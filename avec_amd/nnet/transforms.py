@@ -26,16 +26,30 @@ class ImagesToVideos(nn.Module):
         return images_to_videos(images, self.video_frames if video_frames is None else video_frames)
 
 
+class NormalizeVideo(nn.Module):
+    """nnet/transforms.py:40-52 (host-side; the batched device version is avec_amd.input_pipeline)"""
+
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32).reshape(len(mean), 1, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float32).reshape(len(std), 1, 1, 1), persistent=False)
+
+    def forward(self, x):
+        return (x - self.mean) / self.std
+
+
 def align_video_to_audio(video, audio, video_frames_per_audio=640):
-    """nnet/transforms.py:169-180: Tv = Ta // 640 + 1 (crop or zero-pad the frames)."""
-    tv = audio.shape[-1] // video_frames_per_audio + 1
-    if video.shape[0] >= tv:
-        return video[:tv]
-    return torch.cat([video, video.new_zeros(tv - video.shape[0], *video.shape[1:])], dim=0)
+    """nnet/transforms.py:169-180: the clip (Tv,H,W,C) gets Ta // 640 + 1 - Tv zero frames, half in front (floor), the rest behind."""
+    tv = video.shape[0]
+    padding = audio.shape[0] // video_frames_per_audio + 1 - tv
+    left, right = padding // 2, padding // 2 + padding % 2
+    return torch.cat([video.new_zeros(left, *video.shape[1:]), video, video.new_zeros(right, *video.shape[1:])], dim=0)
 
 
 class TimeMaskSecond(nn.Module):
-    """host-side augmentation named by the AV config (nnet/transforms.py:108-126): per second of video, mask up to T_second seconds."""
+    """host-side augmentation named by the AV config (nnet/transforms.py:108-126): int(T / fps * num_mask_second) masks on the last axis, each drawn as
+    torchaudio.functional.mask_along_axis does (width = rand * T_mask, start = rand * (T - width), both truncated) and filled with the mean of the clip as it is
+    at that moment (mean_frame) or 0.  The batched device version is avec_amd.input_pipeline."""
 
     def __init__(self, T_second, num_mask_second, fps, mean_frame=False):
         super().__init__()
@@ -43,11 +57,12 @@ class TimeMaskSecond(nn.Module):
         self.num_mask_second, self.fps, self.mean_frame = num_mask_second, fps, mean_frame
 
     def forward(self, x):
-        n = int(self.num_mask_second * x.shape[-1] / self.fps)
-        for _ in range(n):
-            w = int(torch.randint(0, self.T + 1, (1,)))
-            if w == 0 or x.shape[-1] - w <= 0:
-                continue
-            s = int(torch.randint(0, x.shape[-1] - w, (1,)))
-            x[..., s:s + w] = x.mean() if self.mean_frame else 0.0
+        T = x.shape[-1]
+        for _ in range(int(T / self.fps * self.num_mask_second)):
+            fill = x.mean() if self.mean_frame else 0.0
+            width = torch.rand(1) * self.T
+            lo = torch.rand(1) * (T - width)
+            s, e = int(lo.long()), int(lo.long() + width.long())
+            x = x.clone()
+            x[..., s:e] = fill
         return x

@@ -183,6 +183,18 @@ int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, uns
 int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                        const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t stream);
 
+/* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
+/* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,
+ * NormalizeVideo (nnet/transforms.py:40-52), RandomCrop / CenterCrop + RandomHorizontalFlip (AV cfg:82-89), TimeMaskSecond (nnet/transforms.py:108-126),
+ * align_video_to_audio (nnet/transforms.py:169-180) and CollateFn's zero padding (nnet/collate_fn.py:143-146).
+ * clips: device uint8, clip b = [tv][H][W][channels] at byte offset clip_off[b];  geom: device int [B][8] = {tv, H, W, crop_y, crop_x, flip, zero frames in front, n_masks};
+ * masks: device int [B][max_masks][2] = (first, one-past-last) frame of each time mask, in clip frames, in application order (null when max_masks == 0);
+ * out: fp32 [B][Tout][OH][OW] (every frame outside [pad_left, pad_left + tv) is zero);  frame_ws: fp32 [2][B][Tout] scratch (only with masks).
+ * lut: device fp32 [channels][256] = w_c * (u / 255) with w = (0.2989, 0.587, 0.114) for RGB clips and 1 for gray ones (made with the reference's own fp32 operations, so
+ * that the device only adds the three terms, subtracts mean and divides by stdv: bit-identical pixels);  mean_frame != 0: mask k is filled with the mean of the clip as left by masks 0..k-1, else with 0. */
+int avec_video_input(const unsigned char* clips, const long long* clip_off, const int* geom, const int* masks, int max_masks, int channels, const float* lut, float mean, float stdv,
+                     int mean_frame, float* out, float* frame_ws, int B, int Tout, int OH, int OW, hipStream_t stream);
+
 /* ---- loss / optimizer (avec_amd/csrc/loss_optim.hip) ---------------------------------------- */
 /* CTCLoss.forward (nnet/losses.py:311-334): per-utterance -log p, batch mean, and d/dlogits (unscaled) */
 long long avec_ctc_workspace_floats(int B, int T, int Lmax);

@@ -294,7 +294,75 @@ def vo_case():
     print("wrote vo_interctc_seed0.json")
 
 
+def video_input_case():
+    """the reference's own NormalizeVideo / align_video_to_audio / TimeMaskSecond (nnet/transforms.py:40-52,108-126,169-180) on a small clip.
+    torchaudio is absent: TimeMaskSecond's call to torchaudio.functional.mask_along_axis is served by the restatement in oracle/video_input.py, so this pins the
+    reference's loop count and its "mean of the clip as masked so far" fill value, not torchaudio's interval draw."""
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import video_input as VO
+    rt = importlib.import_module("nnet.transforms")
+    torch.manual_seed(21)
+    u8 = torch.randint(0, 256, (60, 10, 12, 1), dtype=torch.uint8)
+    x = u8.permute(3, 0, 1, 2).to(torch.float32) / 255
+    xn = rt.NormalizeVideo(mean=(0.5,), std=(0.5,))(x)                          # (1,T,H,W)
+    aligned, pads = {}, []
+    for ta in (60 * 640 - 1, 60 * 640 + 5, 63 * 640 + 17, 66 * 640):
+        v = rt.align_video_to_audio(xn.permute(1, 2, 3, 0), torch.zeros(ta))
+        first = int((v.flatten(1).abs().sum(1) > 0).nonzero()[0])
+        pads.append([ta, v.shape[0], first])
+    aligned = rt.align_video_to_audio(xn.permute(1, 2, 3, 0), torch.zeros(63 * 640 + 17))
+    calls = []
+
+    def masker(spec, mask_param, mask_value, axis):
+        assert axis == 2 and spec.dim() == 4
+        out, se = VO.mask_along_time(spec, mask_param, mask_value)
+        calls.append(list(se) + [float(mask_value)])
+        return out
+    rt.torchaudio.functional.mask_along_axis = masker
+    torch.manual_seed(22)
+    tm = rt.TimeMaskSecond(T_second=0.4, num_mask_second=1.0, fps=25.0, mean_frame=True)
+    masked = tm(xn.permute(2, 3, 0, 1).clone()).permute(2, 3, 0, 1)             # (1,T,H,W)
+    save("video_input_ref", u8=u8, normalized=xn, aligned=aligned, pads=np.array(pads), masked=masked, mask_calls=np.array(calls), mask_seed=np.array([22]))
+
+
+def streaming_case():
+    """context-limited masks (nnet/attentions.py:656-733) and a conformer stack run with them (nnet/networks.py:271-298: the dense mask is strided
+    with the blocks; the patch attention min-pools it, nnet/attentions.py:354-362)."""
+    torch.manual_seed(31)
+    x = torch.randn(3, 14, 4)
+    lens = torch.tensor([14, 9, 3])
+    cases = {}
+    for name, kw in {"l3_r0": dict(left_context=3, right_context=0), "l5_r2": dict(left_context=5, right_context=2), "r1": dict(right_context=1),
+                     "l4": dict(left_context=4), "l2_r0_s4": dict(left_context=2, right_context=0, mask_start=4)}.items():
+        cases[name] = nnet.Mask(**kw)(x, lens)
+        cases[name + "_nolen"] = nnet.Mask(**kw)(x)
+    torch.manual_seed(32)
+    net = nodrop(nnet.ConformerInterCTC(dim_model=[32, 48], num_blocks=[2, 1], interctc_blocks=[1], vocab_size=16, loss_prefix="s_ctc",
+                                        att_params=[ATT("RelPosPatch1dMultiHeadAttention", patch_size=3), ATT("RelPos1dMultiHeadAttention")],
+                                        conv_params={"class": "Conv1d", "params": {"padding": "causal", "kernel_size": 15}}, ff_ratio=4, drop_rate=0.1,
+                                        mask=nnet.Mask(left_context=8, right_context=2), conv_stride=2)).train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    xs = torch.randn(3, 23, 32, requires_grad=True)
+    lengths = torch.tensor([23, 17, 5])
+    y, ylen, inter = net(xs, lengths)
+    w = torch.randn_like(y)
+    ((y * w).sum() + sum((lg * lg).sum() for lg, _ in inter.values())).backward()
+    flat = {}
+    for k, (lg, ln) in inter.items():
+        flat[k + ".logits"] = lg
+        flat[k + ".len"] = ln
+    save("streaming_stack", masks=cases, mask_lens=lens, x=xs, lengths=lengths, y=y, ylen=ylen, inter=flat, sd=sd0, w=w, dx=xs.grad,
+         grads=grads_of(net))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "video_input":
+        video_input_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "streaming":
+        streaming_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vo":
         vo_case()
         sys.exit(0)
@@ -316,3 +384,5 @@ if __name__ == "__main__":
     int_cases()
     adam_case()
     full_model_case()
+    video_input_case()
+    streaming_case()
