@@ -28,11 +28,10 @@ __device__ __forceinline__ void stage_glu(float* gs, const T* u, long long b, in
 }
 template <typename T>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-                                                             float* stats, int B, int Tn, int C, int K, int stride, int To, int nchunks, ColWs ws) {
+                                                             float* stats, int B, int Tn, int C, int K, int stride, int To, int padl, int nchunks, ColWs ws) {
   extern __shared__ __attribute__((aligned(16))) float gs[];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   const int b = blockIdx.y / nchunks, to0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, To - to0);
-  const int padl = (K - 1) / 2;
   stage_glu<T>(gs, u, b, Tn, C, col, to0 * stride - padl, (nto - 1) * stride + K);
   __syncthreads();
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -55,8 +54,8 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict
 // du (act [B*T][2C]) from dc (act [B*To][C])
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_input_kernel(const T* __restrict__ dc, const T* __restrict__ u, const float* __restrict__ w, T* __restrict__ du,
-                                                                   int B, int Tn, int C, int K, int stride, int To) {
-  const int padl = (K - 1) / 2; const long long n4 = (long long)B * Tn * (C / 4);
+                                                                   int B, int Tn, int C, int K, int stride, int To, int padl) {
+  const long long n4 = (long long)B * Tn * (C / 4);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int col = (int)(i % (C / 4)) * 4; const long long row = i / (C / 4); const int t = (int)(row % Tn); const long long b = row / Tn;
     float dg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -75,11 +74,10 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_input_kernel(const T* __re
 // dw[k][c] += sum dc * g(shifted);  dbias[c] += sum dc        (same tiling as the forward: GLU staged once per chunk in LDS)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ dc, const T* __restrict__ u, float* dw, float* dbias,
-                                                                int B, int Tn, int C, int K, int stride, int To, int nchunks, ColWs ws) {
+                                                                int B, int Tn, int C, int K, int stride, int To, int padl, int nchunks, ColWs ws) {
   extern __shared__ __attribute__((aligned(16))) float gs[];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   const int b = blockIdx.y / nchunks, to0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, To - to0);
-  const int padl = (K - 1) / 2;
   stage_glu<T>(gs, u, b, Tn, C, col, to0 * stride - padl, (nto - 1) * stride + K);
   __syncthreads();
   float part[KMAX + 1][4];
@@ -106,29 +104,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 }
 
 extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
-                                   int B, int T_, int C, int K, int stride, hipStream_t st) {
-  AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "glu_dwconv_fwd: bad arguments (C=%d K=%d)", C, K);
+                                   int B, int T_, int C, int K, int stride, int pad_left, hipStream_t st) {
+  AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0 && pad_left >= 0 && pad_left < K, "glu_dwconv_fwd: bad arguments (C=%d K=%d pad_left=%d)", C, K, pad_left);
   const int To = (T_ - 1) / stride + 1;
   const int nchunks = (To + DW_TT - 1) / DW_TT;
   dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = stats ? col_ws_if(grid, 2, C, st) : ColWs{nullptr};
   const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   AVEC_CHECK_ARG(lds <= 64 * 1024, "glu_dwconv_fwd: stride %d too large", stride);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), lds, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, nchunks, ws));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), lds, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, pad_left, nchunks, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
   return 0;
 }
 extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
-                                   int B, int T_, int C, int K, int stride, hipStream_t st) {
-  AVEC_CHECK_ARG(dc && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0, "dwconv_glu_bwd: bad arguments");
+                                   int B, int T_, int C, int K, int stride, int pad_left, hipStream_t st) {
+  AVEC_CHECK_ARG(dc && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0 && pad_left >= 0 && pad_left < K, "dwconv_glu_bwd: bad arguments");
   const int To = (T_ - 1) / stride + 1;
   long long n4 = (long long)B * T_ * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   const int nchunks = (To + DW_TT - 1) / DW_TT;
   dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C, st);
   const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To);
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), lds, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, nchunks, ws));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To, pad_left);
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), lds, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, pad_left, nchunks, ws));
   AVEC_LAUNCH_CHECK();
   if (ws.partial) {
     float* dst[KMAX + 1];

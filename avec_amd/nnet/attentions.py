@@ -72,24 +72,39 @@ class RelPosPatch1dMultiHeadAttention(RelPos1dMultiHeadAttention):
 
 
 class Mask(nn.Module):
-    """Binary mask, 1 = keep (nnet/attentions.py:656-733).  Returned for API compatibility; the conformer stack hands the lengths
-    straight to the attention kernel instead (no (B,1,T,T) tensor, no per-sample host loop)."""
+    """Binary mask, 1 = keep (nnet/attentions.py:656-733).  Without context limits it only encodes key padding and the conformer stack hands the lengths straight
+    to the attention kernels (no (B,1,T,T) tensor, no per-sample host loop).  With left_context / right_context (streaming) the band
+    j - i <= right_context, i - j <= left_context -- opened again on the first mask_start x mask_start block -- is materialised on the device, intersected with
+    the key padding, and consumed by the dense-mask attention path; the stack strides it with the blocks exactly as the reference does."""
 
     def __init__(self, left_context=None, right_context=None, seq_len_axis=1, mask_start=0, unsqueeze_head=True):
         super().__init__()
-        assert left_context is None and right_context is None, "context-limited (streaming) masks: SURVEY 8f rank 4"
+        self.left_context, self.right_context, self.mask_start = left_context, right_context, mask_start
         self.seq_len_axis = [seq_len_axis] if isinstance(seq_len_axis, int) else seq_len_axis
         self.unsqueeze_head = unsqueeze_head
+
+    @property
+    def has_context(self):
+        return self.left_context is not None or self.right_context is not None
 
     def forward(self, x, x_len=None):
         T = 1
         for ax in self.seq_len_axis:
             T *= x.size(ax)
+        i = torch.arange(T, device=x.device)[:, None]
+        j = torch.arange(T, device=x.device)[None, :]
+        keep = torch.ones(T, T, dtype=torch.bool, device=x.device)
+        if self.right_context is not None:
+            keep &= (j - i) <= self.right_context
+        if self.left_context is not None:
+            keep &= (i - j) <= self.left_context
+        if self.mask_start:
+            keep |= (i < self.mask_start) & (j < self.mask_start)
         if x_len is None:
-            m = x.new_ones(1, T, T)
+            m = keep[None]
         else:
-            keep = (torch.arange(T, device=x.device)[None, :] < x_len.to(x.device)[:, None]).to(x.dtype)
-            m = keep[:, None, :].expand(-1, T, T).contiguous()
+            m = keep[None] & (j[None] < x_len.to(x.device)[:, None, None])
+        m = m.to(x.dtype)
         return m[:, None] if self.unsqueeze_head else m
 
 

@@ -70,9 +70,18 @@ class ConformerInterCTC(nn.Module):
                     self.interctc_modules.append(modules.InterCTCResModule(dim_model=d_out, vocab_size=vocab_size))
                 i += 1
 
+        if any(getattr(m, "causal", False) for m in self.modules()):
+            # causal relative positions (nnet/attentions.py:234-256): for j <= i the reference reads E[i-j], as the full-context layout does; for j > i its
+            # rel_to_abs wraps around into the next query row.  Only a mask that hides every j > i makes that well defined -- required here, not reproduced.
+            ok = mask is not None and getattr(mask, "right_context", None) is not None and mask.right_context <= 0 and getattr(mask, "mask_start", 0) <= 1
+            assert ok, "causal=True attention needs a causal Mask (right_context <= 0, mask_start <= 1)"
+
     def forward(self, x, lengths):
         x = self.dropout(x)
-        mask = modules.LengthMask(lengths) if (self.mask is not None and lengths is not None) else None
+        if self.mask is not None and getattr(self.mask, "has_context", False):
+            mask = self.mask(x, lengths)              # streaming: dense (B or 1,1,T,T) band mask, strided with the blocks (nnet/networks.py:271-298)
+        else:
+            mask = modules.LengthMask(lengths) if (self.mask is not None and lengths is not None) else None
         inter, j = {}, 0
         for i, block in enumerate(self.conformer_blocks):
             x = block(x, mask=mask)
@@ -82,7 +91,7 @@ class ConformerInterCTC(nn.Module):
                 j += 1
             if block.stride > 1:
                 if mask is not None:
-                    mask = mask.strided(block.stride)
+                    mask = mask.strided(block.stride) if isinstance(mask, modules.LengthMask) else mask[:, :, ::block.stride, ::block.stride]
                 if lengths is not None:
                     lengths = torch.div(lengths - 1, block.stride, rounding_mode="floor") + 1
             if logits is not None:

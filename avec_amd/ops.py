@@ -531,6 +531,16 @@ def _add_local_affine_grads(dstats, gw, gb, C):
     return True
 
 
+
+def dw_pad_left(conv):
+    """zero frames in front of the sequence for the depthwise conv (nnet/layers.py:137-156): "same" = K // 2, "causal" = K - 1"""
+    K = conv.kernel_size[0]
+    kind = getattr(conv, "padding_type", "same")
+    if kind == "causal":
+        return K - 1
+    assert kind == "same", "the fused convolution module supports 'same' and 'causal' padding, got %r" % (kind,)
+    return K // 2
+
 class ConvModuleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, _anchor, mod, res_conv, drop_p, sid, training):
@@ -548,7 +558,7 @@ class ConvModuleFn(torch.autograd.Function):
         st = BNState(Dp, x2)
         use_batch = training and not getattr(bn, "frozen", False)
         lib.glu_dwconv_fwd(rt.dt(), u.data_ptr(), dw.weight.data_ptr(), _p(dw.bias), c.data_ptr(), st.stats.data_ptr() if use_batch else None,
-                           B, T, Dp, K, stride, rt.stream())
+                           B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
         cptr = bn_finalize(bn, st, Mo, use_batch)
         a = empty((Mo, Dp), adt, x2)
         lib.bn_apply_fwd(rt.dt(), c.data_ptr(), st.ss.data_ptr(), None, ACT_SWISH, a.data_ptr(), Mo, Dp, rt.stream())
@@ -577,7 +587,7 @@ class ConvModuleFn(torch.autograd.Function):
             dc = _bn_eval_backward(bn, st, da, c, ACT_SWISH, Mo)
         du = empty((M, 2 * Dp), adt, dy)
         lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), dw.weight.data_ptr(), du.data_ptr(), grad_of(dw.weight).data_ptr(),
-                           None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, rt.stream())
+                           None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
         linear_bwd_weight(du, h, pw1.weight, M, bias=pw1.bias)
         dh = linear_bwd_input(du, pw1.weight, M, out_f32=False)
         if res_conv is None:

@@ -132,11 +132,13 @@ int avec_avgpool_fwd(int dtype, const void* x, void* y, long long N, int HW, int
 int avec_avgpool_bwd(int dtype, const void* dy, void* dx, long long N, int HW, int C, hipStream_t stream);
 
 /* ---- conformer convolution module middle (avec_amd/csrc/convmod.hip) ----------------------- */
-/* nn.GLU(dim=-1) + depthwise layers.Conv1d(k, groups=C, stride, "same") (nnet/modules.py:375-376); w is tap-major [K][C]. */
+/* nn.GLU(dim=-1) + depthwise layers.Conv1d(k, groups=C, stride, padding) (nnet/modules.py:375-376); w is tap-major [K][C].
+ * pad_left = zero frames in front of the sequence (nnet/layers.py:137-156): K / 2 for "same", K - 1 for "causal" (streaming), 0 for "valid"-like use;
+ * the output always has (T - 1) / stride + 1 frames, i.e. the right padding is whatever completes K - 1. */
 int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
-                        int B, int T, int C, int K, int stride, hipStream_t stream);
+                        int B, int T, int C, int K, int stride, int pad_left, hipStream_t stream);
 int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
-                        int B, int T, int C, int K, int stride, hipStream_t stream);
+                        int B, int T, int C, int K, int stride, int pad_left, hipStream_t stream);
 
 /* ---- attention (avec_amd/csrc/attention.hip) ------------------------------------------------ */
 typedef struct avec_attn {

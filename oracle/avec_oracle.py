@@ -45,6 +45,20 @@ def key_padding_mask(T, lengths):
     return keep[:, None, None, :].expand(-1, 1, T, T).contiguous()
 
 
+def context_mask(T, lengths, left_context=None, right_context=None, mask_start=0):
+    """nnet/attentions.py:694-731: band j - i <= right_context, i - j <= left_context (None = unlimited), the leading mask_start x mask_start block forced
+    open, then intersected with the key padding; (B or 1, 1, T, T) float, 1 = keep."""
+    m = torch.ones(T, T)
+    if right_context is not None:
+        m = m.tril(diagonal=right_context)
+    if left_context is not None:
+        m = torch.minimum(m, torch.ones(T, T).triu(diagonal=-left_context))
+    m[:mask_start, :mask_start] = 1
+    if lengths is None:
+        return m[None, None]
+    return torch.minimum(m[None, None], key_padding_mask(T, lengths)[:, :, :1])
+
+
 def patch_pool_mask(mask, P):
     """nnet/attentions.py:140-171,357-362: zero-pad to a multiple of P then min-pool PxP."""
     T = mask.shape[-1]
@@ -201,22 +215,22 @@ def feed_forward(sd, prefix, x):
     return linear(sd, prefix + ".layers.4", h)
 
 
-def conv_module(sd, prefix, x, stride, train, stats_out):
+def conv_module(sd, prefix, x, stride, train, stats_out, causal=False):
     """nnet/modules.py:341-385: LN -> pw conv (D->2D') -> GLU -> depthwise k=15 stride s, zero pad
-    (7,7) -> BatchNorm1d -> Swish -> pw conv."""
+    (k//2, (k-1)//2) for "same" or (k-1, 0) for "causal" (nnet/layers.py:137-156) -> BatchNorm1d -> Swish -> pw conv."""
     h = layer_norm(sd, prefix + ".layers.0", x)
     h = F.linear(h, sd[prefix + ".layers.1.weight"][:, :, 0], sd[prefix + ".layers.1.bias"])
     h = F.glu(h, dim=-1)
     w = sd[prefix + ".layers.3.weight"]
     k = w.shape[-1]
-    h = F.pad(h.transpose(1, 2), ((k - 1) // 2, k // 2))
+    h = F.pad(h.transpose(1, 2), (k - 1, 0) if causal else (k // 2, (k - 1) // 2))
     h = F.conv1d(h, w, sd[prefix + ".layers.3.bias"], stride=stride, groups=w.shape[0])
     h = batch_norm(sd, prefix + ".layers.4", h, train, stats_out)
     h = swish(h).transpose(1, 2)
     return F.linear(h, sd[prefix + ".layers.6.weight"][:, :, 0], sd[prefix + ".layers.6.bias"])
 
 
-def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out):
+def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out, causal_conv=False):
     """nnet/blocks.py:289-306."""
     x = x + 0.5 * feed_forward(sd, prefix + ".ff_module1", x)
     h = layer_norm(sd, prefix + ".self_att_module.norm", x)
@@ -231,22 +245,25 @@ def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out):
         res = F.linear(x[:, ::2], sd[prefix + ".conv_res.weight"][:, :, 0], sd[prefix + ".conv_res.bias"])
     else:
         res = x
-    x = res + conv_module(sd, prefix + ".conv_module", x, stride, train, stats_out)
+    x = res + conv_module(sd, prefix + ".conv_module", x, stride, train, stats_out, causal_conv)
     x = x + 0.5 * feed_forward(sd, prefix + ".ff_module2", x)
     return layer_norm(sd, prefix + ".norm", x), stride
 
 
 def conformer_interctc(sd, prefix, x, lengths, num_blocks, interctc_blocks, loss_prefix, patch_sizes,
-                       train, stats_out, H=4):
-    """nnet/networks.py:262-307."""
+                       train, stats_out, H=4, context=None, causal_conv=False):
+    """nnet/networks.py:262-307.  context = (left_context, right_context, mask_start) of a streaming Mask, or None for the key-padding mask."""
     T = x.shape[1]
-    mask = key_padding_mask(T, lengths) if lengths is not None else None
+    if context is not None:
+        mask = context_mask(T, lengths, *context)
+    else:
+        mask = key_padding_mask(T, lengths) if lengths is not None else None
     inter = {}
     i, j = 0, 0
     for stage, nb in enumerate(num_blocks):
         for _ in range(nb):
             x, stride = conformer_block(sd, f"{prefix}.conformer_blocks.{i}", x, mask, H,
-                                        patch_sizes[stage], train, stats_out)
+                                        patch_sizes[stage], train, stats_out, causal_conv)
             logits = None
             if i + 1 in interctc_blocks:
                 p = f"{prefix}.interctc_modules.{j}"

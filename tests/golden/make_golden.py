@@ -352,6 +352,17 @@ def streaming_case():
     for k, (lg, ln) in inter.items():
         flat[k + ".logits"] = lg
         flat[k + ".len"] = ln
+    # fully causal variant: causal relative positions (nnet/attentions.py:234-256, nnet/embeddings.py:136-145) + causal mask + causal conv
+    torch.manual_seed(33)
+    cnet = nodrop(nnet.ConformerInterCTC(dim_model=[32, 48], num_blocks=[2, 1], interctc_blocks=[2], vocab_size=16, loss_prefix="c_ctc",
+                                         att_params=[ATT("RelPosPatch1dMultiHeadAttention", patch_size=3), ATT("RelPos1dMultiHeadAttention", causal=True)],
+                                         conv_params={"class": "Conv1d", "params": {"padding": "causal", "kernel_size": 15}}, ff_ratio=4, drop_rate=0.1,
+                                         mask=nnet.Mask(left_context=6, right_context=0), conv_stride=2)).train()
+    csd = {k: v.clone() for k, v in cnet.state_dict().items()}
+    cx = torch.randn(2, 19, 32)
+    clen = torch.tensor([19, 12])
+    cy, cylen, cinter = cnet(cx, clen)
+    save("streaming_causal", x=cx, lengths=clen, y=cy, ylen=cylen, logits=cinter["c_ctc_1"][0], sd=csd)
     save("streaming_stack", masks=cases, mask_lens=lens, x=xs, lengths=lengths, y=y, ylen=ylen, inter=flat, sd=sd0, w=w, dx=xs.grad,
          grads=grads_of(net))
 
