@@ -1,0 +1,244 @@
+// 3x3, stride-1, 64 -> 64 channel convolution of the first ResNet-18 stage (nnet/networks.py ResNet stage 1, 22x22 images): slab kernel.
+//
+// Why not the implicit-GEMM kernel here: with N = 64 output channels there is one column tile, so every workgroup re-fetches the whole 72 KB
+// weight matrix, and every input pixel travels L2 -> LDS nine times (once per tap): 2.7 GB of LDS-DMA per launch for 0.4 GB of tensors, which is
+// what bounds that kernel at ~450 TFLOP/s on these four layers (and their backward-data twins).
+// Here a persistent workgroup (8 waves) keeps the WHOLE weight matrix in LDS (64 x 576 bf16, 80-chunk rows, XOR-swizzled) and loads one image slab
+// (a zero row above and below, one zero column shared by neighbouring rows: (H+2)*(W+1) + 1 pixels x 128 B, XOR-swizzled pixel pairs) per iteration by LDS-DMA: every input byte crosses L2 -> LDS once, the nine taps
+// are nine LDS offsets.  Per image: M = H*W pixels (padded to 512 = 8 waves x 64), N = 64, K = 576 -> 36 k-steps of v_mfma_f32_32x32x16_bf16.
+// The product is computed transposed (C^T = W . X^T): a lane then owns ONE pixel and groups of 4 consecutive channels, so the bf16 output leaves
+// the registers as 8-byte pieces of its NHWC row and the BatchNorm statistics are per-register sums reduced once at the end.
+// LDS: 81 920 (weights) + 73 728 (slab) = 155 648 B -> one workgroup per CU; the store of image n-1 overlaps the DMA latency of image n.
+// forward:   y[p][co]  = sum_{tap,ci} x[p + tap - 1][ci] * Wf[co][tap][ci]          (flip = 0, weight = forward shadow  [Cout][9][Cin])
+// backward:  dx[p][ci] = sum_{tap,co} dy[p - tap + 1][co] * Wb[ci][tap][co] (+ res)  (flip = 1, weight = backward shadow [Cin][9][Cout])
+#include "common.h"
+#include "vec.h"
+#include "avec_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float c3_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
+
+#define C3_WPITCH 1280                      // bytes per weight row in LDS: 72 data chunks in 80 slots (5 groups of 16)
+#define C3_WBYTES (64 * C3_WPITCH)          // 81 920
+#define C3_MAXPIX 576                       // slab pixels ((H+2)*(W+2), even)
+#define C3_SBYTES (C3_MAXPIX * 128)         // 73 728
+
+__device__ __attribute__((aligned(64))) unsigned char c3_zero16[64];     // source of the zero border (LDS-DMA has no immediate fill)
+
+struct C3Args { const bf16* x; const bf16* w; bf16* y; const bf16* res; float* stats; int N, H, W, flip; };
+
+__device__ __forceinline__ int c3_wslot(int n, int c) { return (c & ~15) | ((c & 15) ^ (n & 15)); }
+// slab: 256-byte rows of two pixels (16 chunks), chunk index XOR (pair index & 7): a ds_read_b128 lane group that reads 16 CONSECUTIVE pixels (any parity of the
+// first) touches 16 different 16-byte bank slots.  Output pixel (oy, ox) and tap (kh, kw) read slab pixel oy*(W+1) + ox + kh*(W+1) + kw: consecutive pixels stay
+// consecutive except for a +1 step at the end of an image row (one 2-way conflict in the lane groups that contain it): the slab keeps ONE zero column per row,
+// shared by the right edge of row y and the left edge of row y+1.
+__device__ __forceinline__ int c3_saddr(int pix, int c) { const int pr = pix >> 1; return pr * 256 + (((((pix & 1) << 3) | c) ^ (pr & 7)) << 4); }
+// lane -> pixel of a 32-pixel tile such that the two b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each own 16 consecutive pixels
+__device__ __forceinline__ int c3_lane_pixel(int l) { return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l; }
+
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ws = smem; char* Sl = smem + C3_WBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // ---- weights -> LDS once (plain loads + ds_write: 9 chunks per thread) ----
+  for (int q = tid; q < 64 * 72; q += 512) {
+    const int n = q / 72, c = q - n * 72;
+    *(chunk16*)(Ws + n * C3_WPITCH + c3_wslot(n, c) * 16) = ldg16(a.w + (long long)n * 576 + c * 8);
+  }
+  // ---- slab DMA plan: piece q = wave + 8*i (i < 9) covers slots [q*64, q*64+64); slot s of pair-row pr holds logical chunk s ^ (pr & 15) ----
+  int soff[9];                               // element offset inside the image, or -1 = zero (border / beyond the slab)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, pr = S >> 4, c2 = (S & 15) ^ (pr & 7);
+    const int pix = pr * 2 + (c2 >> 3), ch = c2 & 7;          // slab pixel = 1 + y' * (W+1) + x: rows 0 and H+1 are zero, column W is the zero column shared by two rows
+    const int py = (pix - 1) / PW, px = (pix - 1) - py * PW;
+    const bool in = pix >= 1 && pix < NPIX && py >= 1 && py <= H && px < W;
+    soff[i] = in ? ((py - 1) * W + px) * 64 + ch * 8 : -1;
+  }
+  // ---- fragment addressing ----
+  // pixel operand (MFMA B): lane -> pixel row (lane & 31) of m-tile i, k-half lane >> 5;  weight operand (MFMA A): lane -> channel (lane & 31) of n-tile j
+  const int kh2 = lane >> 5;
+  int p0[2]; bool pvalid[2]; int pm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = wave * 64 + i * 32 + c3_lane_pixel(lane & 31);
+    pvalid[i] = m < HW; if (m >= HW) m = HW - 1;
+    pm[i] = m;
+    const int oy = m / W;
+    p0[i] = oy * PW + (m - oy * W);          // slab pixel of tap offset (0, 0); offset (dh, dw) adds dh*PW + dw
+  }
+  const int wrow[2] = {(lane & 31) * C3_WPITCH, (32 + (lane & 31)) * C3_WPITCH};
+  const int wkey = lane & 15;                // (n & 15) for both n-tiles
+
+  float ssum[2][16], ssq[2][16];             // BatchNorm statistics of this lane's channels over its pixels, all images of the workgroup
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+
+  c3_f32x16 acc[2][2];                       // [n-tile j][m-tile i], C^T layout: column = pixel (lane & 31), rows = channels (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Results leave in two steps so that nobody waits for a store: right after the MFMAs of image n the accumulators are folded into the statistics, added to the
+  // residual and packed to bf16 (32 registers); those 8-byte pieces are stored at the START of image n+1's MFMA phase, after the wait for its slab, and
+  // complete under that phase.  The residual pieces of image n are requested at the start of its own MFMA phase and consumed after it.
+  // A lane owns channels {0-3, 8-11, 16-19, 24-27} (+4 for the upper half-wave) of its pixel: v_permlane32_swap trades the odd 4-channel group of the lower
+  // half-wave for the even group of the upper one, after which every lane holds 8 consecutive channels = one 16-byte piece per (n-tile, 16-channel block).
+  uint4 outp[2][2][2], resp[2][2][2];
+  long long prev = -1;                       // image whose packed results are still in outp
+  auto swap_pair = [&](uint2& x, uint2& y) {   // (X, Y) = (group 2k, group 2k+1) <-> (channels 0-7 | 8-15 of the 16-block): an involution
+    auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false); x.x = r0[0]; y.x = r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false); x.y = r1[0]; y.y = r1[1];
+  };
+  const int chq = kh2 * 8;                   // this lane's 8-channel piece inside a 16-channel block after the swap
+  auto issue_stores = [&]() {
+    if (prev < 0) return;
+    bf16* yo = a.y + prev * HW * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!pvalid[i]) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *(uint4*)(yo + (long long)pm[i] * 64 + j * 32 + k * 16 + chq) = outp[j][i][k];
+    }
+  };
+
+  for (long long n = blockIdx.x; n < a.N; n += gridDim.x) {
+    __syncthreads();                         // every wave is done reading the slab of the previous image (and the weights are in place)
+    const bf16* xi = a.x + n * HW * 64;
+    {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const void* src = soff[i] >= 0 ? (const void*)(xi + soff[i]) : (const void*)c3_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Sl + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
+    }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab; the stores of image n-2... n-1's MFMA phase are long done
+    __syncthreads();
+    issue_stores();
+    if (a.res) {
+      const bf16* ro = a.res + n * HW * 64;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) resp[j][i][k] = *(const uint4*)(ro + (long long)pm[i] * 64 + j * 32 + k * 16 + chq);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    // 36 k-steps (9 taps x 4 chunks of 16 channels); the fragments of step s+1 are requested before the MFMAs of step s
+    auto tap_addr = [&](int tap, int& ax0, int& ax1, int& aw0, int& aw1, bool& z0, bool& z1) {
+      const int th = tap / 3, tw = tap - th * 3;
+      const int dh = (a.flip & 1) ? 2 - th : th, dw = (a.flip & 1) ? 2 - tw : tw;
+      const int d = dh * PW + dw;
+      ax0 = c3_saddr(p0[0] + d, kh2); ax1 = c3_saddr(p0[1] + d, kh2);
+      const int wt = (((tap >> 1) << 4) | ((((tap & 1) << 3) | kh2) ^ wkey)) << 4;
+      aw0 = wrow[0] + wt; aw1 = wrow[1] + wt;
+      z0 = z1 = false;
+    };
+    auto load4 = [&](int ax0, int ax1, int aw0, int aw1, bool z0, bool z1, int q, chunk16& fx0, chunk16& fx1, chunk16& fw0, chunk16& fw1) {
+      fx0 = *(const chunk16*)(Sl + (ax0 ^ (q << 5)));
+      fx1 = *(const chunk16*)(Sl + (ax1 ^ (q << 5)));
+      fw0 = *(const chunk16*)(Ws + (aw0 ^ (q << 5)));
+      fw1 = *(const chunk16*)(Ws + (aw1 ^ (q << 5)));
+    };
+    const int ntap = 9;
+#pragma unroll 1
+    for (int tap = 0; tap < ntap; ++tap) {
+      int ax0, ax1, aw0, aw1; bool z0, z1;
+      tap_addr(tap, ax0, ax1, aw0, aw1, z0, z1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        chunk16 cx0, cx1, cw0, cw1;
+        load4(ax0, ax1, aw0, aw1, z0, z1, q, cx0, cx1, cw0, cw1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw0), __builtin_bit_cast(c3_bf16x8, cx0), acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw0), __builtin_bit_cast(c3_bf16x8, cx1), acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx0), acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx1), acc[1][1], 0, 0, 0);
+      }
+    }
+    // fold + pack
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          uint2 rx = make_uint2(0u, 0u), ry = make_uint2(0u, 0u);
+          if (a.res) { rx = make_uint2(resp[j][i][k].x, resp[j][i][k].y); ry = make_uint2(resp[j][i][k].z, resp[j][i][k].w); swap_pair(rx, ry); }   // back to (group 2k, group 2k+1)
+          uint2 o[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int g = 2 * k + e;
+            float v[4] = {acc[j][i][g * 4 + 0], acc[j][i][g * 4 + 1], acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]};
+            if (a.stats && pvalid[i]) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { ssum[j][g * 4 + t] += v[t]; ssq[j][g * 4 + t] += v[t] * v[t]; }
+            }
+            if (a.res) {
+              const uint2 r = e ? ry : rx;
+              v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u); v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+            }
+            o[e] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+          }
+          swap_pair(o[0], o[1]);
+          outp[j][i][k] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+        }
+    prev = n;
+  }
+  issue_stores();
+  if (a.stats) {
+    // lanes sharing lane >> 5 hold the same channels for different pixels: butterfly over the 32 pixel lanes, then over the 8 waves through LDS
+    __syncthreads();
+    float* red = (float*)Sl;                 // [8 waves][2 (sum, sq)][64 channels]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = ssum[j][r], q = ssq[j][r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if ((lane & 31) == 0) {
+          const int ch = j * 32 + (r >> 2) * 8 + kh2 * 4 + (r & 3);
+          red[(wave * 2 + 0) * 64 + ch] = s; red[(wave * 2 + 1) * 64 + ch] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+      for (int w = 0; w < 8; ++w) t += red[w * 128 + tid];
+      float* rep = a.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 128;
+      atomicAdd(rep + tid, t);               // [sum 64 | sumsq 64]
+    }
+  }
+}
+
+extern "C" int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
+  return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && H * W <= 512 && (H + 2) * (W + 1) + 1 <= C3_MAXPIX && H >= 1 && W >= 2;
+}
+
+extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, float* stats, long long images, int H, int W, int flip, hipStream_t st) {
+  AVEC_CHECK_ARG(x && w && y && images > 0, "conv3x3_c64: null buffer");
+  AVEC_CHECK_ARG(avec_conv3x3_c64_supported(H, W, 64, 64, 3, 3, 1), "conv3x3_c64: %dx%d images do not fit the slab", H, W);
+  static bool attr_set = false;
+  const size_t lds = C3_WBYTES + C3_SBYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { avec_set_error("conv3x3_c64: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  static const int wgs_env = getenv("AVEC_C3_WGS") ? atoi(getenv("AVEC_C3_WGS")) : 256;
+  C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
+  const int grid = (int)(images < wgs_env ? images : wgs_env);
+  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}

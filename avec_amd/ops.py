@@ -783,8 +783,19 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
     M = N * OH * OW
     sh = rt.shadow(weight)
     y = empty((M, Cout), rt.act_dtype(), x)
+    if _slab_conv(H, W, Cin, Cout, KH, KW, stride):
+        lib.conv3x3_c64(x.data_ptr(), sh.fwd.data_ptr(), y.data_ptr(), None, _p(stats), N, H, W, 0, rt.stream())
+        return y, OH, OW
     gemm_nt(x, sh.fwd, y, M, Cout, KH * KW * Cin, rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_FWD, stats=stats)
     return y, OH, OW
+
+
+SLAB_CONV = os.environ.get("AVEC_NO_SLAB_CONV") is None
+
+
+def _slab_conv(H, W, Cin, Cout, KH, KW, stride):
+    """ResNet stage 1 (3x3, stride 1, 64 -> 64 channels, 22x22 images), bf16: weights resident in LDS + one image slab per iteration (csrc/conv3x3.hip)"""
+    return SLAB_CONV and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_conv3x3_c64_supported")(H, W, Cin, Cout, KH, KW, stride))
 
 
 def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None):
@@ -796,6 +807,9 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     if not need_dx:
         return None
     dx = empty((N * H * W, Cin), rt.act_dtype(), dy)
+    if _slab_conv(H, W, Cin, Cout, KH, KW, stride):
+        lib.conv3x3_c64(dy.data_ptr(), sh.bwd.data_ptr(), dx.data_ptr(), _p(dx_res), None, N, H, W, 1, rt.stream())
+        return dx
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
             res=dx_res, res_act=True)
     return dx

@@ -185,6 +185,14 @@ int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, uns
 int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                        const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t stream);
 
+/* ---- 3x3 / stride 1 / 64->64 channel convolution of ResNet stage 1 (avec_amd/csrc/conv3x3.hip) ------ */
+/* Same contract as avec_gemm_nt with ROWS_CONV_FWD (flip = 0: x NHWC bf16, w = forward shadow [64][9][64], y NHWC bf16, stats = AVEC_STAT_REPLICAS x [sum | sumsq]
+ * of the fp32 results) or ROWS_CONV_BWD (flip = 1: x = dy, w = backward shadow [Cin][9][Cout], y = dx, res = optional bf16 tensor added to dx) for layers.Conv2d
+ * (nnet/layers.py:200-306) with kernel 3x3, stride 1, "same" padding, 64 input and output channels, images of at most 512 pixels whose zero-bordered slab fits
+ * 72 KB of LDS ((H+2)(W+2) <= 576, even): weights stay in LDS, every input byte crosses L2 -> LDS once.  bf16 only. */
+int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride);
+int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, float* stats, long long images, int H, int W, int flip, hipStream_t stream);
+
 /* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
 /* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,
  * NormalizeVideo (nnet/transforms.py:40-52), RandomCrop / CenterCrop + RandomHorizontalFlip (AV cfg:82-89), TimeMaskSecond (nnet/transforms.py:108-126),

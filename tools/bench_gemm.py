@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import avec_amd
 from avec_amd import ops, runtime as rt
-from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
+from avec_amd.lib import lib, ROWS_CONV_FWD, ROWS_CONV_BWD
 
 avec_amd.set_compute_dtype(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 d = torch.device("cuda")
@@ -48,6 +48,9 @@ def conv(Nimg, H, Cin, Cout, stride=1):
     dx = torch.empty(Nimg * H * H, Cin, device=d, dtype=adt)
     rb = ops.rows_conv(H, H, Cout, 3, 3, stride, 1, OH, OH)
     timeit(lambda: ops.gemm_nt(y, Wb, dx, Nimg * H * H, Cin, 9 * Cout, rows=rb, mode=ROWS_CONV_BWD), 2.0 * Nimg * H * H * Cin * 9 * Cout, "conv bwd-data")
+    if lib.raw("avec_conv3x3_c64_supported")(H, H, Cin, Cout, 3, 3, stride) and adt == torch.bfloat16:
+        timeit(lambda: lib.conv3x3_c64(x.data_ptr(), W.data_ptr(), y.data_ptr(), None, st.data_ptr(), Nimg, H, H, 0, rt.stream()), fl, "conv fwd  slab kernel (stats)")
+        timeit(lambda: lib.conv3x3_c64(y.data_ptr(), Wb.data_ptr(), dx.data_ptr(), x.data_ptr(), None, Nimg, H, H, 1, rt.stream()), fl, "conv bwd-data slab kernel (+res)")
     dW = torch.zeros(Cout, 9 * Cin, device=d)
     timeit(lambda: ops.gemm_tn(y, x, dW, M, Cout, 9 * Cin, q_rows=rows, q_mode=ROWS_CONV_FWD), fl, "conv wgrad")
 
