@@ -118,16 +118,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab; the stores of image n-2... n-1's MFMA phase are long done
     __syncthreads();
-    issue_stores();
-    if (a.res) {
-      const bf16* ro = a.res + n * HW * 64;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) resp[j][i][k] = *(const uint4*)(ro + (long long)pm[i] * 64 + j * 32 + k * 16 + chq);
-    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -150,9 +140,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
       fw0 = *(const chunk16*)(Ws + (aw0 ^ (q << 5)));
       fw1 = *(const chunk16*)(Ws + (aw1 ^ (q << 5)));
     };
-    const int ntap = 9;
-#pragma unroll 1
-    for (int tap = 0; tap < ntap; ++tap) {
+    // A CU moves only ~11 B/clk to or from HBM (its share of the chip's bandwidth): issued in one go, the 8 stores of the previous image block the wave
+    // for thousands of cycles.  They leave two per tap under the MFMAs of taps 1..4 instead; the residual pieces of this image are requested at tap 5
+    // (two separate loops, so that the registers of the packed results and of the residual pieces can be the same ones).
+    bf16* yprev = prev >= 0 ? a.y + prev * HW * 64 : nullptr;
+    auto one_tap = [&](int tap) {
       int ax0, ax1, aw0, aw1; bool z0, z1;
       tap_addr(tap, ax0, ax1, aw0, aw1, z0, z1);
 #pragma unroll
@@ -164,7 +156,33 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx0), acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx1), acc[1][1], 0, 0, 0);
       }
+    };
+#define C3_ST(I, J, K) if (pvalid[I]) *(uint4*)(yprev + (long long)pm[I] * 64 + J * 32 + K * 16 + chq) = outp[J][I][K]
+#pragma unroll 1
+    for (int tap = 0; tap < 5; ++tap) {
+      if (yprev) {
+        switch (tap) {
+          case 1: C3_ST(0, 0, 0); C3_ST(0, 0, 1); break;
+          case 2: C3_ST(0, 1, 0); C3_ST(0, 1, 1); break;
+          case 3: C3_ST(1, 0, 0); C3_ST(1, 0, 1); break;
+          case 4: C3_ST(1, 1, 0); C3_ST(1, 1, 1); break;
+          default: break;
+        }
+      }
+      one_tap(tap);
     }
+#undef C3_ST
+    if (a.res) {
+      const bf16* ro = a.res + n * HW * 64;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) resp[j][i][k] = *(const uint4*)(ro + (long long)pm[i] * 64 + j * 32 + k * 16 + chq);
+    }
+#pragma unroll 1
+    for (int tap = 5; tap < 9; ++tap) one_tap(tap);
     // fold + pack
 #pragma unroll
     for (int i = 0; i < 2; ++i)
