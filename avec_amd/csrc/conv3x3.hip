@@ -239,6 +239,113 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers: dW[co][tap][ci] = sum over images and pixels of dy[p][co] * x[p + tap - 1][ci].
+// The implicit-GEMM TN kernel is fabric-bound here (one 64-wide row tile: dy is re-read by every column tile, x once per tap: 1.95 GB fetched per
+// launch at 6 TB/s for 0.4 GB of tensors).  Slab version: a persistent 8-wave workgroup owns the WHOLE 64 x 576 fp32 result in registers (36 tiles of
+// 32 x 32 spread 5/4 over the waves) and streams images through LDS: the x slab (as in the forward kernel) and the dy image laid out with the same
+// row pitch W+1 (one zero column per image row), so that the reduction index k' = oy*(W+1) + ox is linear and tap (dh, dw) is the plain row offset
+// dh*(W+1) + dw into the slab.  Both MFMA operands are [k'][channel] arrays read with ds_read_b64_tr_b16 (the transposing read of gemm_tn_tr_kernel);
+// every input byte crosses L2 -> LDS once.  One atomic add per result element per workgroup at the end.
+// ------------------------------------------------------------------------------------------------
+typedef short c3_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ chunk16 c3_tr_read8(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) c3_v4s* lp_t;
+  const c3_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p1);
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  chunk16 f; f.w[0] = ua.x; f.w[1] = ua.y; f.w[2] = ub.x; f.w[3] = ub.y; return f;
+}
+#define C3W_KROWS 512                       // reduction rows per image: H*(W+1) <= 512
+#define C3W_DBYTES (C3W_KROWS * 128)        // 65 536: dy image with the slab's row pitch
+
+struct C3WArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W; };
+
+__global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem; char* Ds = smem + C3_SBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // 128-byte rows, 16-byte chunk index XOR 4*((row >> 1) & 1): the 4 rows of a transposing read fall on distinct banks (as in gemm_tn_tr_kernel)
+  int xoff[9], doff[8];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+    const int py = (row - 1) / PW, px = (row - 1) - py * PW;
+    const bool in = row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
+    xoff[i] = in ? ((py - 1) * W + px) * 64 + c * 8 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+    const int oy = row / PW, ox = row - oy * PW;
+    doff[i] = (oy < H && ox < W) ? (oy * W + ox) * 64 + c * 8 : -1;
+  }
+  // this wave's tiles: co half (wave >> 1) & 1, ci half wave & 1, taps (wave >> 2) + 2 j (j < 4) and, for waves 0..3, tap 8
+  const int cohalf = (wave >> 1) & 1, cihalf = wave & 1, tap0 = wave >> 2;
+  const bool five = wave < 4;
+  const int g4 = lane >> 4, t = lane & 15;
+  int offa[2], offb[5][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int krow = 8 * (g4 >> 1) + 4 * h + (t >> 2);
+    const int cbA = cohalf * 32 + 16 * (g4 & 1), cbB = cihalf * 32 + 16 * (g4 & 1);
+    offa[h] = krow * 128 + ((((cbA >> 3) + ((t & 3) >> 1)) ^ (4 * ((krow >> 1) & 1))) << 4) + (t & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tap = j < 4 ? tap0 + 2 * j : 8;
+      const int rowd = krow + (tap / 3) * PW + (tap % 3);
+      offb[j][h] = rowd * 128 + ((((cbB >> 3) + ((t & 3) >> 1)) ^ (4 * ((rowd >> 1) & 1))) << 4) + (t & 1) * 8;
+    }
+  }
+  c3_f32x16 acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (long long n = blockIdx.x; n < a.N; n += gridDim.x) {
+    __syncthreads();                         // every wave is done with the previous image
+    const bf16* xi = a.x + n * HW * 64; const bf16* di = a.dy + n * HW * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const void* src = xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const void* src = doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 2
+    for (int s = 0; s < C3W_KROWS / 16; ++s) {
+      const int so = s * 2048;
+      const chunk16 fa = c3_tr_read8(Ds + offa[0] + so, Ds + offa[1] + so);
+      chunk16 fb[5];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = c3_tr_read8(Xs + offb[j][0] + so, Xs + offb[j][1] + so);
+      if (five) fb[4] = c3_tr_read8(Xs + offb[4][0] + so, Xs + offb[4][1] + so);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[j], 0, 0, 0);
+      if (five) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[4]), acc[4], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j == 4 && !five) break;
+    const int tap = j < 4 ? tap0 + 2 * j : 8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cohalf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cihalf * 32 + (lane & 31);
+      atomicAdd(a.dw + (long long)co * 576 + tap * 64 + ci, acc[j][r]);
+    }
+  }
+}
+
 extern "C" int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
   return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && H * W <= 512 && (H + 2) * (W + 1) + 1 <= C3_MAXPIX && H >= 1 && W >= 2;
 }
@@ -257,6 +364,23 @@ extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const voi
   C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t st) {
+  AVEC_CHECK_ARG(x && dy && dw && images > 0, "wgrad3x3_c64: null buffer");
+  AVEC_CHECK_ARG(avec_conv3x3_c64_supported(H, W, 64, 64, 3, 3, 1) && H * (W + 1) <= C3W_KROWS, "wgrad3x3_c64: %dx%d images do not fit the slab", H, W);
+  static bool attr_set = false;
+  const size_t lds = C3_SBYTES + C3W_DBYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { avec_set_error("wgrad3x3_c64: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  C3WArgs a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W;
+  const int grid = (int)(images < 256 ? images : 256);
+  hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;
 }

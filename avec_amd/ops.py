@@ -19,7 +19,7 @@ class KernelTimer:
     launch while enabled; durations are read after the timed region."""
     NAMES = {(0, ROWS_CONV_FWD): "gemm_nt<conv_fwd>", (0, ROWS_CONV_BWD): "gemm_nt<conv_bwd_data>", (0, ROWS_STEM3D): "gemm_nt<stem3d>",
              (0, ROWS_PLAIN): "gemm_nt<plain>", (1, ROWS_CONV_FWD): "gemm_tn<conv_wgrad>", (1, ROWS_STEM3D): "gemm_tn<stem3d_wgrad>",
-             (1, ROWS_PLAIN): "gemm_tn<plain>"}
+             (1, ROWS_PLAIN): "gemm_tn<plain>", (2, 0): "conv3x3_slab<fwd>", (2, 1): "conv3x3_slab<bwd_data>", (2, 2): "conv3x3_slab<wgrad>"}
 
     def __init__(self):
         self.enabled = False
@@ -57,7 +57,7 @@ class KernelTimer:
         kid = max(tmpl, key=lambda k: tmpl[k][0])
         t, fl, n = tmpl[kid]
         achieved = fl / t / 1e12
-        return {"bound": "mfma", "kernel": "gemm_nt (plain + implicit-GEMM conv fwd / bwd-data)" if kid == 0 else "gemm_tn (weight gradients)",
+        return {"bound": "mfma", "kernel": {0: "gemm_nt (plain + implicit-GEMM conv fwd / bwd-data)", 1: "gemm_tn (weight gradients)", 2: "conv3x3_c64 slab kernel"}[kid],
                 "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
                 "alg_gflop_per_launch": round(fl / n / 1e9, 3),
@@ -784,7 +784,10 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
     sh = rt.shadow(weight)
     y = empty((M, Cout), rt.act_dtype(), x)
     if _slab_conv(H, W, Cin, Cout, KH, KW, stride):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
         lib.conv3x3_c64(x.data_ptr(), sh.fwd.data_ptr(), y.data_ptr(), None, _p(stats), N, H, W, 0, rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 0), 2.0 * M * Cout * KH * KW * Cin)
         return y, OH, OW
     gemm_nt(x, sh.fwd, y, M, Cout, KH * KW * Cin, rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_FWD, stats=stats)
     return y, OH, OW
@@ -803,12 +806,21 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     pad = (KH - 1) // 2
     M = N * OH * OW
     sh = rt.shadow(weight)
-    gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD, side=True)
+    if _slab_conv(H, W, Cin, Cout, KH, KW, stride) and H * (W + 1) <= 512:
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+        lib.wgrad3x3_c64(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
+    else:
+        gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD, side=True)
     if not need_dx:
         return None
     dx = empty((N * H * W, Cin), rt.act_dtype(), dy)
     if _slab_conv(H, W, Cin, Cout, KH, KW, stride):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
         lib.conv3x3_c64(dy.data_ptr(), sh.bwd.data_ptr(), dx.data_ptr(), _p(dx_res), None, N, H, W, 1, rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 1), 2.0 * N * H * W * Cin * KH * KW * Cout)
         return dx
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
             res=dx_res, res_act=True)

@@ -192,6 +192,9 @@ int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, c
  * 72 KB of LDS ((H+2)(W+2) <= 576, even): weights stay in LDS, every input byte crosses L2 -> LDS once.  bf16 only. */
 int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride);
 int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, float* stats, long long images, int H, int W, int flip, hipStream_t stream);
+/* weight gradient of the same layers (what avec_gemm_tn with ROWS_CONV_FWD computes): dw fp32 [64][9][64] (row stride 576) += sum over images / pixels of
+ * dy[p][co] * x[p + tap - 1][ci]; x, dy NHWC bf16.  Needs avec_conv3x3_c64_supported and H * (W + 1) <= 512. */
+int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t stream);
 
 /* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
 /* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,
