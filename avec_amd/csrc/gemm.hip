@@ -948,7 +948,9 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   // measured on MI355X: the implicit-GEMM weight gradients keep improving up to ~2048 workgroups (8 per CU; 183 -> 255 TFLOP/s on the
   // 64->64 3x3 layer), the plain small-K products are best around 512
   static const long long wg_env = getenv("AVEC_TN_WGS") ? atoll(getenv("AVEC_TN_WGS")) : 0;
-  const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? 2048 : 512);
+  // re-measured per ResNet stage (tools/bench_gemm.py, AVEC_TN_WGS sweep): few output tiles (stage 2: 9) are best at ~1024 workgroups (232 vs 255 us), 36 tiles
+  // (stage 3) at 2048, 144 tiles (stage 4) at 4096 (358 vs 378 us): the split has to cover the chip several times over, but every workgroup pays BI*BJ atomics
+  const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? (tiles <= 16 ? 1024 : tiles <= 64 ? 2048 : 4096) : 512);
   long long split = (wg_target + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1) split = 1;
   long long per = ((ksteps + split - 1) / split) * KE;
   split = (g.M + per - 1) / per;
