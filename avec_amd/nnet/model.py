@@ -54,6 +54,7 @@ class Model(Module):
             SyncBatchNorm.convert_sync_batchnorm(self)
         self.rank, self.is_distributed = rank, True
         self.world_size = dist.get_world_size()
+        rt.ensure_branch_group()          # second communicator for the collectives of the audio branch's stream (runtime.collective_group)
         if self.arena is not None:
             dist.broadcast(self.arena.master, 0)
             self.arena.mark_dirty()

@@ -171,7 +171,7 @@ def _f32c(t):
 
 def _sync_stats(stats):
     if rt.sync_batchnorm():
-        torch.distributed.all_reduce(stats)
+        torch.distributed.all_reduce(stats, group=rt.collective_group())
 
 
 # ============================================================================================

@@ -470,7 +470,7 @@ class ParamArena:
         if not getattr(self, "_early_armed", False) or hi <= lo:
             return
         import torch.distributed as dist
-        self._early.append((lo, hi, dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+        self._early.append((lo, hi, dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=collective_group())))
 
     def arm_early_all_reduce(self, flag):
         self._early_armed, self._early = bool(flag), []
@@ -500,6 +500,26 @@ def all_reduce_flat(flat, bucket_bytes=64 << 20):
     return flat
 
 
+def collective_group():
+    """Process group for a collective issued from the CURRENT stream.  Collectives of one communicator execute in issue order on its internal stream: the
+    audio encoder (side stream) issues all its SyncBatchNorm exchanges before the visual encoder issues its first one, so on the default group the visual
+    branch would wait for the whole audio branch and the two-stream overlap would be lost on every multi-GPU run.  The side stream therefore gets its own
+    communicator (created once, by every rank, at distribute time: ensure_branch_group)."""
+    g = _BRANCH.get("group")
+    if g is None or not torch.cuda.is_available():
+        return None
+    side = _BRANCH["streams"].get(torch.cuda.current_device())
+    return g if (side is not None and torch.cuda.current_stream() == side) else None
+
+
+def ensure_branch_group():
+    """collective on all ranks: create the side-stream communicator (no-op without torch.distributed or when the branch streams are off)"""
+    import torch.distributed as dist
+    if _BRANCH.get("group") is None and _BRANCH["enabled"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        _BRANCH["group"] = dist.new_group()
+    return _BRANCH.get("group")
+
+
 def sync_bn_stats(stats, nrep, C, count):
     """SyncBatchNorm statistic exchange: collapse the `nrep` replicated [sum | sumsq] partials, append the local element count and sum
     the (2C+1)-vector over ranks.  Returns the reduced vector (global sum, global sumsq, global count)."""
@@ -509,5 +529,5 @@ def sync_bn_stats(stats, nrep, C, count):
         lib.bn_collapse(stats.data_ptr(), nrep, float(count), red.data_ptr(), C, stream())
     else:       # (CPU tensors: the gloo unit tests of the exchange itself)
         red = torch.cat([stats.view(nrep, 2 * C).sum(0), torch.full((1,), float(count), dtype=stats.dtype, device=stats.device)])
-    dist.all_reduce(red, op=dist.ReduceOp.SUM)
+    dist.all_reduce(red, op=dist.ReduceOp.SUM, group=collective_group())
     return red
