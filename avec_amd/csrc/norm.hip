@@ -78,23 +78,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
   // D <= 1536: each lane owns up to 6 groups of 4 columns
   float pg[6][4], pb[6][4];
   for (int i = 0; i < 6; ++i) for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
+  // gamma is the same for every row: kept in registers; a row's dy / x / residual-gradient pieces are loaded once and used for both the two row sums and dx
+  float gg[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const int c = lane * 4 + i * 256; if (c < D) ld4<float>(g + c, gg[i]); else { gg[i][0] = gg[i][1] = gg[i][2] = gg[i][3] = 0.f; } }
   for (long long row = wave_id; row < M; row += nwaves) {
     const float mu = mean[row], rs = rstd[row];
+    float d[6][4], xh[6][4], o[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int c = lane * 4 + i * 256; if (c >= D) break;
+      ld4<TG>(dy + row * D + c, d[i]); ld4<float>(x + row * D + c, xh[i]);
+      if (dres) ld4<float>(dres + row * D + c, o[i]); else { o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f; }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      int c = lane * 4 + i * 256; if (c >= D) break;
-      float d[4], v[4], gg[4]; ld4<TG>(dy + row * D + c, d); ld4<float>(x + row * D + c, v); ld4<float>(g + c, gg);
-      for (int e = 0; e < 4; ++e) { float xh = (v[e] - mu) * rs; float t = d[e] * gg[e]; s1 += t; s2 += t * xh; pg[i][e] += d[e] * xh; pb[i][e] += d[e]; }
+      const int c = lane * 4 + i * 256; if (c >= D) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xh[i][e] = (xh[i][e] - mu) * rs; const float t = d[i][e] * gg[i][e]; s1 += t; s2 += t * xh[i][e]; pg[i][e] += d[i][e] * xh[i][e]; pb[i][e] += d[i][e]; }
     }
     s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      int c = lane * 4 + i * 256; if (c >= D) break;
-      float d[4], v[4], gg[4], o[4]; ld4<TG>(dy + row * D + c, d); ld4<float>(x + row * D + c, v); ld4<float>(g + c, gg);
-      if (dres) ld4<float>(dres + row * D + c, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
-      for (int e = 0; e < 4; ++e) { float xh = (v[e] - mu) * rs; o[e] += rs * (d[e] * gg[e] - s1 - xh * s2); }
-      st4<float>(dx + row * D + c, o);
+      const int c = lane * 4 + i * 256; if (c >= D) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[i][e] += rs * (d[i][e] * gg[i][e] - s1 - xh[i][e] * s2);
+      st4<float>(dx + row * D + c, o[i]);
     }
   }
   // block-level reduction of the 4 waves' partials through LDS, then one atomic per column per block
