@@ -165,6 +165,86 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
   }
 }
 
+// Long-utterance variant (used when the three [T][S] arrays above do not fit: 15 s clips have T = 376 frames at the inter-CTC heads): only alpha lives in LDS.
+//   phase 1  frame log-normalisers; the gradient rows are pre-set to 0
+//   phase 2  alpha recursion over the frames (one barrier per frame; the emission of the next frame is fetched from the L2-resident logits one frame ahead)
+//   phase 3  beta recursion with two rolling rows; each state adds its occupancy exp(alpha + beta - emission - ll) to its label's gradient entry with a
+//            fire-and-forget global atomic
+//   phase 4  gradient rows in parallel: softmax - occupancy
+__global__ __launch_bounds__(256) void ctc_alpha_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+                                                            const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
+                                                            int B, int T, int V, int Lmax, int blank, int zero_inf) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Smax = 2 * Lmax + 1;
+  float* alpha = sm; float* lnorm = alpha + (size_t)T * Smax; float* brow = lnorm + T; int* ext = (int*)(brow + 2 * Smax);
+  const int Tb = min((int)in_lens[b], T), L = min((int)tgt_lens[b], Lmax), S = 2 * L + 1;
+  const float* lg = logits + (long long)b * T * V;
+  float* gr = grad ? grad + (long long)b * T * V : nullptr;
+  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
+  for (int t = wv; t < Tb; t += 4) {
+    float mx = -INFINITY; for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[t * V + v]);
+    mx = wave_max(mx);
+    float se = 0.f; for (int v = lane; v < V; v += 64) se += __expf(lg[t * V + v] - mx);
+    se = wave_sum(se);
+    if (lane == 0) lnorm[t] = mx + __logf(se);
+  }
+  if (gr) for (int i = tid; i < T * V; i += 256) gr[i] = 0.f;
+  __syncthreads();
+  float ll = -INFINITY;
+  if (Tb > 0) {
+    // forward
+    const int NS = (S + 255) / 256;
+    for (int t = 0; t < Tb; ++t) {
+      float* an = alpha + (size_t)t * Smax; const float* ap = an - Smax;
+      for (int q = 0; q < NS; ++q) {
+        const int s = tid + q * 256; if (s >= S) break;
+        float a;
+        if (t == 0) a = (s < 2) ? 0.f : -INFINITY;
+        else {
+          a = ap[s];
+          if (s >= 1) a = logaddexpf_(a, ap[s - 1]);
+          if (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) a = logaddexpf_(a, ap[s - 2]);
+        }
+        an[s] = a + (lg[t * V + ext[s]] - lnorm[t]);
+      }
+      __syncthreads();
+    }
+    const float* al = alpha + (size_t)(Tb - 1) * Smax;
+    ll = al[S - 1]; if (S > 1) ll = logaddexpf_(ll, al[S - 2]);
+  } else if (L == 0) ll = 0.f;
+  float loss = -ll;
+  const bool inf = !(loss < INFINITY);
+  if (inf && zero_inf) loss = 0.f;
+  if (tid == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); }
+  if (!gr || inf || Tb == 0) return;          // gradient rows already zero
+  {
+    const int NS = (S + 255) / 256;
+    for (int k = 0; k < Tb; ++k) {
+      const int t = Tb - 1 - k; float* bc = brow + (k & 1) * Smax; const float* bn = brow + ((k & 1) ^ 1) * Smax;
+      for (int q = 0; q < NS; ++q) {
+        const int s = tid + q * 256; if (s >= S) break;
+        float bv;
+        if (k == 0) bv = (s >= S - 2) ? 0.f : -INFINITY;
+        else {
+          bv = bn[s];
+          if (s + 1 < S) bv = logaddexpf_(bv, bn[s + 1]);
+          if (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != ext[s]) bv = logaddexpf_(bv, bn[s + 2]);
+        }
+        const float e = lg[t * V + ext[s]] - lnorm[t];
+        bv += e;
+        bc[s] = bv;
+        const float w = __expf(alpha[(size_t)t * Smax + s] + bv - e - ll);
+        if (w > 0.f) atomicAdd(gr + t * V + ext[s], w);
+      }
+      __syncthreads();
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < Tb * V; i += 256) { const int t = i / V; gr[i] = __expf(lg[i] - lnorm[t]) - gr[i]; }
+}
+
 extern "C" long long avec_ctc_workspace_floats(int B, int T, int Lmax) { return (long long)B * ((long long)T * (2 * Lmax + 1) + T); }
 
 extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
@@ -175,6 +255,18 @@ extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, cons
   const size_t lds_fast = (3 * (size_t)T * Smax + T + 4 * (size_t)V + Smax) * 4;
   if (lds_fast <= 64 * 1024) {
     hipLaunchKernelGGL(ctc_lds_kernel, dim3(B), dim3(256), lds_fast, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_infinity);
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
+  const size_t lds_alpha = ((size_t)T * Smax + T + 3 * Smax) * 4;
+  static const bool no_alpha = getenv("AVEC_CTC_NO_ALPHA_LDS") != nullptr;
+  if (lds_alpha <= 150 * 1024 && !no_alpha) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)ctc_alpha_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e != hipSuccess) { avec_set_error("ctc_loss: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(ctc_alpha_lds_kernel, dim3(B), dim3(256), lds_alpha, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_infinity);
     AVEC_LAUNCH_CHECK(); return 0;
   }
   size_t lds = (size_t)(2 * (2 * Lmax + 1) + V) * 4 + (size_t)(2 * Lmax + 1) * 4;
