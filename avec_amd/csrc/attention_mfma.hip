@@ -17,7 +17,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
-static constexpr int NTMAX = 7;      // key tiles of 32 held in registers (T <= 224)
+static constexpr int NTMAX = 12;     // key tiles of 32 held in registers: kernels are instantiated for NTM = 7 (T <= 224, two workgroups per CU) and 12 (T <= 384)
 static constexpr int CTMAX = 3;      // channel tiles of 32 (d <= 96)
 
 template <int PITCH> __device__ __forceinline__ int aswz(int row) {
@@ -57,23 +57,28 @@ __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, long long
   }
 }
 
-struct MfmaGeom { int Tp, NT, NE, dpad, DKS, CT; size_t offK, offV, offE, offQ, offS, total; };
+struct MfmaGeom { int Tp, NT, NE, dpad, DKS, CT, alias; size_t offK, offV, offE, offQ, offS, total; };
 static MfmaGeom mfma_geom(int T, int d, int pitch, bool bwd) {
   MfmaGeom g; g.Tp = (T + 31) / 32 * 32; g.NT = g.Tp / 32; g.NE = g.Tp + 64; g.dpad = (d + 15) / 16 * 16; g.DKS = g.dpad / 16; g.CT = (d + 31) / 32;
-  g.offK = 0; g.offV = g.offK + (size_t)g.Tp * pitch; g.offE = g.offV + (size_t)g.Tp * pitch; g.offQ = g.offE + (size_t)g.NE * pitch;
-  g.offS = g.offQ + (size_t)64 * pitch * (bwd ? 2 : 1);            // bwd: Q and dO tiles
-  g.total = g.offS + (size_t)2 * 8192;                             // per wave: 2 x [32][32] fp32 skew ring (also the output staging)
+  // long sequences: K and V take turns in ONE image (K for the scores, V for P.V / dP, K again for dQ) -- costs two barriers per turn, fits T = 384 in 160 KB
+  for (g.alias = 0; g.alias < 2; ++g.alias) {
+    g.offK = 0; g.offV = g.alias ? g.offK : g.offK + (size_t)g.Tp * pitch; g.offE = g.offV + (size_t)g.Tp * pitch; g.offQ = g.offE + (size_t)g.NE * pitch;
+    g.offS = g.offQ + (size_t)64 * pitch * (bwd ? 2 : 1);            // bwd: Q and dO tiles
+    g.total = g.offS + (size_t)2 * 8192;                             // per wave: 2 x [32][32] fp32 skew ring (also the output staging)
+    if (g.total <= 160 * 1024) break;
+  }
+  if (g.alias > 1) g.alias = 1;
   return g;
 }
 
 // S^T tiles of one wave: S[jt][r] = scale * (K_j.Q_i + E_{T-1-i+j}.Q_i) (+ -1e9 on masked keys, -inf beyond T) for key
 // j = 32 jt + (r&3) + 8 (r>>2) + 4 hf and query il = lane & 31; returns this lane-half's running maximum.
-template <int PITCH>
-__device__ __forceinline__ float scores(f32x16 (&S)[NTMAX], const char* Ks, const char* Es, const char* qrow, float* ring, const MfmaGeom& G, float scale,
+template <int PITCH, int NTM>
+__device__ __forceinline__ float scores(f32x16 (&S)[NTM], const char* Ks, const char* Es, const char* qrow, float* ring, const MfmaGeom& G, float scale,
                                         int w, int il, int hf, int Tn, int klen, bool row_masked) {
   const int swr = aswz<PITCH>(il);                       // swizzle of operand row (tile bases are multiples of 32: same bits)
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt)
+  for (int jt = 0; jt < NTM; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[jt][r] = 0.f;
   // R^T tile et -> ring slot et & 1 (rows e_local = 32 et + ..., this wave's window starts 32 (1 - w) rows into the staged E window)
@@ -93,7 +98,7 @@ __device__ __forceinline__ float scores(f32x16 (&S)[NTMAX], const char* Ks, cons
   };
   rel_tile(0);
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
       const char* krow = Ks + (32 * jt + il) * PITCH;
       for (int kk = 0; kk < G.DKS; ++kk) {
@@ -114,7 +119,7 @@ __device__ __forceinline__ float scores(f32x16 (&S)[NTMAX], const char* Ks, cons
   }
   float mx = -INFINITY;
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -173,7 +178,7 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&O)[CTMAX], float mul
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int PITCH>
+template <int PITCH, int NTM>
 __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
   const bf16* ep = (const bf16*)a.e + h * d;
   stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  if (!G.alias) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
   stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
   __syncthreads();
@@ -196,12 +201,12 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   const int klen = a.lens ? (int)(a.lens[b] / a.len_div) : Tn;
   const bool row_masked = i >= a.q_full;
 
-  f32x16 S[NTMAX];
-  float mx = scores<PITCH>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  f32x16 S[NTM];
+  float mx = scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float lsum = 0.f;
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float p = __expf(S[jt][r] - mx); S[jt][r] = p; lsum += p; }
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   lsum += __shfl_xor(lsum, 32, 64);
   if (hf == 0 && i < Tn) { a.lse[((long long)bh * Tn + i) * 2] = mx; a.lse[((long long)bh * Tn + i) * 2 + 1] = lsum; }
 
+  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place
   // O^T = V^T P^T
   f32x16 O[CTMAX];
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
     for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
   int offv[CTMAX][2]; tr_offsets<PITCH>(offv, lane);
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
 // backward, row pass: P and dS (stored for the batched dK / dV / dE GEMMs) and dQ
 //     dP^T[j][i] = V_j . dO_i ;  dS^T = P^T o (dP^T - delta_i) * scale ;  dQ^T = K^T dS^T + E_win^T unskew(dS^T)
 // ------------------------------------------------------------------------------------------------
-template <int PITCH>
+template <int PITCH, int NTM>
 __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom G) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ; char* Gs = Qs + 64 * PITCH;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
   const bf16* ep = (const bf16*)a.e + h * d;
   const bf16* gp = (const bf16*)a.dout + (long long)b * Tn * a.ldo + h * d;
   stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  if (!G.alias) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
   stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad);
@@ -277,14 +283,15 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
   }
   delta += __shfl_xor(delta, 32, 64);
 
-  f32x16 S[NTMAX];
-  scores<PITCH>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  f32x16 S[NTM];
+  scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place for dP
   bf16* prow = (bf16*)a.pbuf + ((long long)bh * Tn + i) * a.ldt;
   bf16* srow = (bf16*)a.dsbuf + ((long long)bh * Tn + i) * a.ldt;
   bf16* rrow = a.dsrel ? (bf16*)a.dsrel + ((long long)h * a.B * Tn + (long long)b * Tn + i) * a.ldr + (Tn - 1 - i) : nullptr;
   const bool st8 = (a.ldt & 3) == 0 && ((((size_t)a.pbuf) | ((size_t)a.dsbuf)) & 7) == 0;
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
       f32x16 dP;
 #pragma unroll
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
       }
     }
   }
+  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // and K comes back for dQ
   // dQ^T = K^T dS^T   (A = K^T via transposed reads, B = dS^T registers)
   f32x16 DQ[CTMAX];
 #pragma unroll
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
     for (int r = 0; r < 16; ++r) DQ[ct][r] = 0.f;
   int offt[CTMAX][2]; tr_offsets<PITCH>(offt, lane);
 #pragma unroll
-  for (int jt = 0; jt < NTMAX; ++jt) {
+  for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -348,13 +356,13 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
 #pragma unroll
   for (int r = 0; r < 16; ++r) ring[1024 + ((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + il] = 0.f;     // slot 1 = tile -1
 #pragma unroll
-  for (int et = 0; et <= NTMAX; ++et) {
+  for (int et = 0; et <= NTM; ++et) {
     if (et <= G.NT) {
       float* slot = ring + (et & 1) * 1024;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = 0.f;
-        if (et < NTMAX) v = (et < G.NT) ? S[et < NTMAX ? et : 0][r] : 0.f;
+        if (et < NTM) v = (et < G.NT) ? S[et < NTM ? et : 0][r] : 0.f;
         slot[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + il] = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -397,8 +405,9 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, false);
   if (G.total > 160 * 1024) return 1;
   dim3 grid((a.T + 63) / 64, a.B * a.H);
-  if (pitch == 128) { if (int r = mfma_set_lds(attn_mfma_fwd_kernel<128>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_fwd_kernel<128>, grid, dim3(128), G.total, st, a, G); }
-  else { if (int r = mfma_set_lds(attn_mfma_fwd_kernel<256>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_fwd_kernel<256>, grid, dim3(128), G.total, st, a, G); }
+#define AVEC_LAUNCH_ATTN(KERNEL) do { if (int r = mfma_set_lds(KERNEL, G.total)) return r; hipLaunchKernelGGL(KERNEL, grid, dim3(128), G.total, st, a, G); } while (0)
+  if (a.T <= 224) { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<128, 7>)); else AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<256, 7>)); }
+  else { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<128, 12>)); else AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<256, 12>)); }
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -408,7 +417,8 @@ int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) {
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, true);
   if (G.total > 160 * 1024) return 1;
   dim3 grid((a.T + 63) / 64, a.B * a.H);
-  if (pitch == 128) { if (int r = mfma_set_lds(attn_mfma_bwd_kernel<128>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_bwd_kernel<128>, grid, dim3(128), G.total, st, a, G); }
-  else { if (int r = mfma_set_lds(attn_mfma_bwd_kernel<256>, G.total)) return r; hipLaunchKernelGGL(attn_mfma_bwd_kernel<256>, grid, dim3(128), G.total, st, a, G); }
+  if (a.T <= 224) { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<128, 7>)); else AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<256, 7>)); }
+  else { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<128, 12>)); else AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<256, 12>)); }
+#undef AVEC_LAUNCH_ATTN
   AVEC_LAUNCH_CHECK(); return 0;
 }
