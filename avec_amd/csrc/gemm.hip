@@ -866,18 +866,6 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   static const int stg_env = getenv("AVEC_NT_STG") ? atoi(getenv("AVEC_NT_STG")) : 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
 #define G3(MODE, S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
     if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
-  static const int small_env = getenv("AVEC_NT_SMALL") ? atoi(getenv("AVEC_NT_SMALL")) : 0;     // experiment: 64x64 plain tiles, 64-byte rows, ring of 6 / 8
-#define G4(S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
-  if (a16 && !f32src && sizeof(T) == 2 && mode == MODE_PLAIN && (BM + BN) <= 128 && g.K % 32 == 0) { if (small_env == 6) G4(6); if (small_env == 8) G4(8); }
-#undef G4
-  // few-tile plain products (the conformer layers at M = B*T <= 6400: at most ~2 workgroups per CU, so occupancy is not the issue): 256-byte rows
-  // = 128 K-elements per ring step halve the number of barrier / wait / issue rounds
-#define G5(S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 256; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 256>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE_PLAIN, S_, false, 256>), grid, dim3(256), l2, st, g); return 0; } while (0)
-  if (a16 && !f32src && sizeof(T) == 2 && mode == MODE_PLAIN && (BM + BN) <= 128 && (long long)grid.x * grid.y <= 640 && g.K >= 256) {
-    if (small_env == 2) G5(2); if (small_env == 3) G5(3); if (small_env == 4) G5(4); }
-#undef G5
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
