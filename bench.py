@@ -63,6 +63,10 @@ def pmc_traffic(family):
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not family or not os.path.exists(path):
         return None
+    if family.startswith("conv3x3"):
+        ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith("conv3x3_c64_kernel") or k.startswith("wgrad3x3_c64_kernel")]
+        n = sum(v["launches"] for v in ks)
+        return round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0)) for v in ks) / n) if n else None
     want_tn = family.startswith("gemm_tn")
     want_mode = {"plain": 0, "conv_fwd": 1, "conv_bwd_data": 2, "conv_wgrad": 1}.get(family[family.find("<") + 1:-1]) if "<" in family else "all"
     if want_mode is None:
