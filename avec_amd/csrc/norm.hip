@@ -69,50 +69,67 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// dx (+)= LN backward; dgamma/dbeta accumulated with atomics (one partial per wave).
-template <typename TG>
+// dx (+)= LN backward; dgamma/dbeta: per-lane partial sums over the wave's rows, reduced per block in LDS, then the two-pass column reduction.
+// NG = column groups of 256 per lane-quad (D <= 256 NG): the conformer widths (180..360) need 2, so the row pieces of the NEXT row are requested before the
+// two wave reductions of the current one (a wave walks 4..8 rows; un-pipelined, every row costs a full load latency).
+template <typename TG, int NG>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ g, float* dx, const float* dres,
                                                      float* __restrict__ dg, float* __restrict__ db, long long M, int D, ColWs ws) {
   const int lane = threadIdx.x & 63; const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6); const int nwaves = gridDim.x * 4;
-  // D <= 1536: each lane owns up to 6 groups of 4 columns
-  float pg[6][4], pb[6][4];
-  for (int i = 0; i < 6; ++i) for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
-  // gamma is the same for every row: kept in registers; a row's dy / x / residual-gradient pieces are loaded once and used for both the two row sums and dx
-  float gg[6][4];
+  float pg[NG][4], pb[NG][4], gg[NG][4];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { const int c = lane * 4 + i * 256; if (c < D) ld4<float>(g + c, gg[i]); else { gg[i][0] = gg[i][1] = gg[i][2] = gg[i][3] = 0.f; } }
-  for (long long row = wave_id; row < M; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    float d[6][4], xh[6][4], o[6][4];
+  for (int i = 0; i < NG; ++i) {
+    const int c = lane * 4 + i * 256;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int c = lane * 4 + i * 256; if (c >= D) break;
-      ld4<TG>(dy + row * D + c, d[i]); ld4<float>(x + row * D + c, xh[i]);
-      if (dres) ld4<float>(dres + row * D + c, o[i]); else { o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f; }
+    for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; gg[i][e] = 0.f; }
+    if (c < D) ld4<float>(g + c, gg[i]);
+  }
+  struct RowData { float d[NG][4], v[NG][4], o[NG][4], mu, rs; };
+  auto fetch = [&](long long row, RowData& r) {
+    r.mu = mean[row]; r.rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < D) {
+        ld4<TG>(dy + row * D + c, r.d[i]); ld4<float>(x + row * D + c, r.v[i]);
+        if (dres) ld4<float>(dres + row * D + c, r.o[i]); else { r.o[i][0] = r.o[i][1] = r.o[i][2] = r.o[i][3] = 0.f; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r.d[i][e] = 0.f; r.v[i][e] = r.mu; r.o[i][e] = 0.f; }
+      }
     }
+  };
+  RowData cur, nxt;
+  long long row = wave_id;
+  if (row < M) fetch(row, cur);
+  for (; row < M; row += nwaves) {
+    const bool more = row + nwaves < M;
+    if (more) fetch(row + nwaves, nxt);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int c = lane * 4 + i * 256; if (c >= D) break;
+    for (int i = 0; i < NG; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { xh[i][e] = (xh[i][e] - mu) * rs; const float t = d[i][e] * gg[i][e]; s1 += t; s2 += t * xh[i][e]; pg[i][e] += d[i][e] * xh[i][e]; pb[i][e] += d[i][e]; }
-    }
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (cur.v[i][e] - cur.mu) * cur.rs, t = cur.d[i][e] * gg[i][e];
+        cur.v[i][e] = xh; s1 += t; s2 += t * xh; pg[i][e] += cur.d[i][e] * xh; pb[i][e] += cur.d[i][e];
+      }
     s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int c = lane * 4 + i * 256; if (c >= D) break;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[i][e] += rs * (d[i][e] * gg[i][e] - s1 - xh[i][e] * s2);
-      st4<float>(dx + row * D + c, o[i]);
+      for (int e = 0; e < 4; ++e) cur.o[i][e] += cur.rs * (cur.d[i][e] * gg[i][e] - s1 - cur.v[i][e] * s2);
+      st4<float>(dx + row * D + c, cur.o[i]);
     }
+    if (more) cur = nxt;
   }
   // block-level reduction of the 4 waves' partials through LDS, then one atomic per column per block
   extern __shared__ float lnred[];           // [2][D]
   for (int c = threadIdx.x; c < 2 * D; c += 256) lnred[c] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < NG; ++i) {
     int c = lane * 4 + i * 256; if (c >= D) break;
     for (int e = 0; e < 4; ++e) { atomicAdd(lnred + c + e, pg[i][e]); atomicAdd(lnred + D + c + e, pb[i][e]); }
   }
@@ -140,8 +157,11 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
   ColWs ws = avec_reduce_ws((size_t)nb * 2 * D, st);
   if (!ws.partial && nb > 128) nb = 128;
   const size_t lds = (size_t)2 * D * sizeof(float);
-  if (dy_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, (const float*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws);
-  else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3((unsigned)nb), dim3(256), lds, st, (const bf16*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws);
+#define AVEC_LN_BWD(TG, NG) hipLaunchKernelGGL((ln_bwd_kernel<TG, NG>), dim3((unsigned)nb), dim3(256), lds, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, ws)
+  const bool f32in = dy_f32 || dtype == AVEC_F32;
+  if (D <= 512) { if (f32in) AVEC_LN_BWD(float, 2); else AVEC_LN_BWD(bf16, 2); }
+  else { if (f32in) AVEC_LN_BWD(float, 6); else AVEC_LN_BWD(bf16, 6); }
+#undef AVEC_LN_BWD
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {dgamma, dbeta}; return col_finalize(ws, 1, (unsigned)nb, 2, D, dst, D, st); }
   return 0;
