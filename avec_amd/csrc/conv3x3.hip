@@ -346,6 +346,129 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / 128 -> 128 channel layers of ResNet stage 2 (11 x 11 images): same slab idea, the 128 x 1152 fp32 result split over two
+// kinds of workgroup (blockIdx & 1 = half of the output channels: 64 x 1152 = 72 tiles of 32 x 32, nine per wave: one (co tile, ci quarter) pair and all
+// nine taps).  Two images per iteration: x slabs of 176 rows x 256 B and dy images of 144 rows x 128 B (this workgroup's 64 output channels), all with
+// the row pitch W+1.  The implicit-GEMM TN kernel fetches 0.65 GB per launch for 0.2 GB of tensors here; this one reads x twice (once per channel half)
+// and dy once.
+// ------------------------------------------------------------------------------------------------
+#define C3X_ROWS 176                        // x slab rows per image: (H+2)*(W+1) + 1 <= 176, and reads reach 16*9 - 1 + 2*(W+1) + 2
+#define C3X_KROWS 144                       // reduction rows per image: H*(W+1) <= 144
+struct C3W128Args { const bf16* x; const bf16* dy; float* dw; int N, H, W; };
+
+__global__ __launch_bounds__(512) void wgrad3x3_c128_kernel(C3W128Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem; char* Ds = smem + 2 * C3X_ROWS * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  const int cohalf = blockIdx.x & 1;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // DMA plans (element offsets inside an image, -1 = zero): x: 2 x 44 pieces, 11 per wave; dy: 2 x 18 pieces, 5 per wave (the last 4 of 40 unused)
+  int xoff[11], doff[5];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    const int P = wave + 8 * i, S = (P % 44) * 64 + lane, row = S >> 4, c = (S & 15) ^ (4 * (row & 3));
+    const int py = (row - 1) / PW, px = (row - 1) - py * PW;
+    const bool in = row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
+    xoff[i] = in ? ((py - 1) * W + px) * 128 + c * 8 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int P = wave + 8 * i, S = (P % 18) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+    const int oy = row / PW, ox = row - oy * PW;
+    doff[i] = (P < 36 && oy < H && ox < W) ? (oy * W + ox) * 128 + cohalf * 64 + c * 8 : -1;
+  }
+  const int cot = wave & 1, ciq = wave >> 1;
+  const int g4 = lane >> 4, t = lane & 15;
+  int offa[2], offb[9][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int krow = 8 * (g4 >> 1) + 4 * h + (t >> 2);
+    const int cbA = cot * 32 + 16 * (g4 & 1), cbB = ciq * 32 + 16 * (g4 & 1);
+    offa[h] = krow * 128 + ((((cbA >> 3) + ((t & 3) >> 1)) ^ (4 * ((krow >> 1) & 1))) << 4) + (t & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int rowd = krow + (j / 3) * PW + (j % 3);
+      offb[j][h] = rowd * 256 + ((((cbB >> 3) + ((t & 3) >> 1)) ^ (4 * (rowd & 3))) << 4) + (t & 1) * 8;
+    }
+  }
+  c3_f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const long long npairs = ((long long)a.N + 1) / 2;
+  for (long long p = blockIdx.x >> 1; p < npairs; p += gridDim.x >> 1) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int P = wave + 8 * i; const long long img = 2 * p + P / 44;
+      const void* src = (xoff[i] >= 0 && img < a.N) ? (const void*)(a.x + img * HW * 128 + xoff[i]) : (const void*)c3_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + P * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int P = wave + 8 * i; const long long img = 2 * p + P / 18;
+      if (P < 36) {
+        const void* src = (doff[i] >= 0 && img < a.N) ? (const void*)(a.dy + img * HW * 128 + doff[i]) : (const void*)c3_zero16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + P * 1024), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int im = 0; im < 2; ++im) {
+      const char* xb = Xs + im * (C3X_ROWS * 256); const char* db = Ds + im * (C3X_KROWS * 128);
+#pragma unroll 1
+      for (int s = 0; s < C3X_KROWS / 16; ++s) {
+        const chunk16 fa = c3_tr_read8(db + offa[0] + s * 2048, db + offa[1] + s * 2048);
+#pragma unroll
+        for (int jb = 0; jb < 9; jb += 3) {          // three taps at a time: 12 fragment registers in flight instead of 36
+          chunk16 fb[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) fb[j] = c3_tr_read8(xb + offb[jb + j][0] + s * 4096, xb + offb[jb + j][1] + s * 4096);
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            acc[jb + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[jb + j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cohalf * 64 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = ciq * 32 + (lane & 31);
+      atomicAdd(a.dw + (long long)co * 1152 + j * 128 + ci, acc[j][r]);
+    }
+}
+
+extern "C" int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
+  return Cin == 128 && Cout == 128 && KH == 3 && KW == 3 && stride == 1 && H >= 1 && W >= 2 && H * (W + 1) <= C3X_KROWS && (H + 2) * (W + 1) + 1 <= C3X_ROWS &&
+         C3X_KROWS - 1 + 2 * (W + 1) + 2 < C3X_ROWS;
+}
+
+extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t st) {
+  AVEC_CHECK_ARG(x && dy && dw && images > 0, "wgrad3x3_c128: null buffer");
+  AVEC_CHECK_ARG(avec_wgrad3x3_c128_supported(H, W, 128, 128, 3, 3, 1), "wgrad3x3_c128: %dx%d images do not fit the slab", H, W);
+  static bool attr_set = false;
+  const size_t lds = 2 * C3X_ROWS * 256 + 2 * C3X_KROWS * 128;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { avec_set_error("wgrad3x3_c128: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  C3W128Args a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W;
+  const long long pairs = (images + 1) / 2;
+  const int grid = (int)(2 * (pairs < 128 ? pairs : 128));
+  hipLaunchKernelGGL(wgrad3x3_c128_kernel, dim3(grid), dim3(512), lds, st, a);
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
   return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && H * W <= 512 && (H + 2) * (W + 1) + 1 <= C3_MAXPIX && H >= 1 && W >= 2;
 }

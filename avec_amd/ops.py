@@ -794,6 +794,7 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
 
 
 SLAB_CONV = os.environ.get("AVEC_NO_SLAB_CONV") is None
+SLAB_WGRAD128 = os.environ.get("AVEC_NO_SLAB_WGRAD128") is None
 
 
 def _slab_conv(H, W, Cin, Cout, KH, KW, stride):
@@ -809,6 +810,11 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     if _slab_conv(H, W, Cin, Cout, KH, KW, stride) and H * (W + 1) <= 512:
         ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
         lib.wgrad3x3_c64(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
+    elif SLAB_CONV and SLAB_WGRAD128 and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_wgrad3x3_c128_supported")(H, W, Cin, Cout, KH, KW, stride)):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+        lib.wgrad3x3_c128(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     else:

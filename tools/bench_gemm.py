@@ -55,6 +55,8 @@ def conv(Nimg, H, Cin, Cout, stride=1):
     timeit(lambda: ops.gemm_tn(y, x, dW, M, Cout, 9 * Cin, q_rows=rows, q_mode=ROWS_CONV_FWD), fl, "conv wgrad")
     if lib.raw("avec_conv3x3_c64_supported")(H, H, Cin, Cout, 3, 3, stride) and adt == torch.bfloat16:
         timeit(lambda: lib.wgrad3x3_c64(x.data_ptr(), y.data_ptr(), dW.data_ptr(), Nimg, H, H, rt.stream()), fl, "conv wgrad slab kernel")
+    if lib.raw("avec_wgrad3x3_c128_supported")(H, H, Cin, Cout, 3, 3, stride) and adt == torch.bfloat16:
+        timeit(lambda: lib.wgrad3x3_c128(x.data_ptr(), y.data_ptr(), dW.data_ptr(), Nimg, H, H, rt.stream()), fl, "conv wgrad slab kernel (128 ch)")
 
 
 plain(4096, 4096, 4096)
