@@ -347,38 +347,37 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradient of the 3x3 / 128 -> 128 channel layers of ResNet stage 2 (11 x 11 images): same slab idea, the 128 x 1152 fp32 result split over two
-// kinds of workgroup (blockIdx & 1 = half of the output channels: 64 x 1152 = 72 tiles of 32 x 32, nine per wave: one (co tile, ci quarter) pair and all
-// nine taps).  Two images per iteration: x slabs of 176 rows x 256 B and dy images of 144 rows x 128 B (this workgroup's 64 output channels), all with
-// the row pitch W+1.  The implicit-GEMM TN kernel fetches 0.65 GB per launch for 0.2 GB of tensors here; this one reads x twice (once per channel half)
-// and dy once.
+// Weight gradient of the wider 3x3 layers (ResNet stages 2..4: C = 128 / 256 / 512 channels, 11x11 / 6x6 / 3x3 images): same slab idea, the C x 9C fp32
+// result split over (C/64) x (C/128) kinds of workgroup -- 64 output channels x 128 input channels x 9 taps = 72 tiles of 32 x 32, nine per wave (one
+// (co tile, ci quarter) pair and all nine taps).  Several images per iteration: x slabs of RS rows x 256 B (this kind's 128 input channels) and dy images
+// of KP rows x 128 B (its 64 output channels), all with the row pitch W+1; 352 x-rows and 288 dy-rows of LDS hold 2..10 images.  The DMA plan (which
+// image / element each 16-byte LDS slot receives) lives in LDS.  x is read C/64 times and dy C/128 times in total -- against once per column tile and
+// once per tap for the implicit-GEMM TN kernel (0.65 GB fetched per launch for 0.2 GB of tensors at C = 128).
 // ------------------------------------------------------------------------------------------------
-#define C3X_ROWS 176                        // x slab rows per image: (H+2)*(W+1) + 1 <= 176, and reads reach 16*9 - 1 + 2*(W+1) + 2
-#define C3X_KROWS 144                       // reduction rows per image: H*(W+1) <= 144
-struct C3W128Args { const bf16* x; const bf16* dy; float* dw; int N, H, W; };
+#define C3X_ROWS 352                        // x rows in LDS
+#define C3X_KROWS 288                       // dy rows in LDS
+struct C3WWArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W, C, KP, RS, IT; };   // KP: reduction rows per image (16-multiple), RS: x rows per image, IT: images per iteration
 
-__global__ __launch_bounds__(512) void wgrad3x3_c128_kernel(C3W128Args a) {
+__global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Xs = smem; char* Ds = smem + 2 * C3X_ROWS * 256;
+  char* Xs = smem; char* Ds = smem + C3X_ROWS * 256;
+  int* xplan = (int*)(Ds + C3X_KROWS * 128); int* dplan = xplan + C3X_ROWS * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
-  const int cohalf = blockIdx.x & 1;
+  const int H = a.H, W = a.W, C = a.C, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  const int nci = C >> 7, kinds = (C >> 6) * nci, kind = blockIdx.x % kinds, cog = kind / nci, cig = kind - cog * nci;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // DMA plans (element offsets inside an image, -1 = zero): x: 2 x 44 pieces, 11 per wave; dy: 2 x 18 pieces, 5 per wave (the last 4 of 40 unused)
-  int xoff[11], doff[5];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) {
-    const int P = wave + 8 * i, S = (P % 44) * 64 + lane, row = S >> 4, c = (S & 15) ^ (4 * (row & 3));
+  // plan entry: (image inside the iteration) << 24 | element offset inside the image, or -1 = zero
+  for (int S = tid; S < C3X_ROWS * 16; S += 512) {
+    const int R = S >> 4, c = (S & 15) ^ (4 * (R & 3)), im = R / a.RS, row = R - im * a.RS;
     const int py = (row - 1) / PW, px = (row - 1) - py * PW;
-    const bool in = row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
-    xoff[i] = in ? ((py - 1) * W + px) * 128 + c * 8 : -1;
+    const bool in = im < a.IT && row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
+    xplan[S] = in ? (im << 24) | (((py - 1) * W + px) * C + cig * 128 + c * 8) : -1;
   }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int P = wave + 8 * i, S = (P % 18) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+  for (int S = tid; S < C3X_KROWS * 8; S += 512) {
+    const int R = S >> 3, c = (S & 7) ^ (4 * ((R >> 1) & 1)), im = R / a.KP, row = R - im * a.KP;
     const int oy = row / PW, ox = row - oy * PW;
-    doff[i] = (P < 36 && oy < H && ox < W) ? (oy * W + ox) * 128 + cohalf * 64 + c * 8 : -1;
+    dplan[S] = (im < a.IT && oy < H && ox < W) ? (im << 24) | ((oy * W + ox) * C + cog * 64 + c * 8) : -1;
   }
   const int cot = wave & 1, ciq = wave >> 1;
   const int g4 = lane >> 4, t = lane & 15;
@@ -400,30 +399,33 @@ __global__ __launch_bounds__(512) void wgrad3x3_c128_kernel(C3W128Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const long long npairs = ((long long)a.N + 1) / 2;
-  for (long long p = blockIdx.x >> 1; p < npairs; p += gridDim.x >> 1) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-      const int P = wave + 8 * i; const long long img = 2 * p + P / 44;
-      const void* src = (xoff[i] >= 0 && img < a.N) ? (const void*)(a.x + img * HW * 128 + xoff[i]) : (const void*)c3_zero16;
+  const long long ngroups = ((long long)a.N + a.IT - 1) / a.IT;
+  const int wgs = gridDim.x / kinds;           // workgroups per kind (the launch rounds the grid to a multiple of `kinds`)
+  const int nsteps = a.KP >> 4;
+  for (long long p = blockIdx.x / kinds; p < ngroups; p += wgs) {
+    __syncthreads();                         // the plan is complete / every wave is done with the previous images
+    const long long img0 = p * a.IT;
+#pragma unroll 1
+    for (int P = wave; P < C3X_ROWS * 16 / 64; P += 8) {
+      const int e = xplan[P * 64 + lane];
+      const long long img = img0 + (e >> 24);
+      const void* src = (e >= 0 && img < a.N) ? (const void*)(a.x + img * HW * C + (e & 0xffffff)) : (const void*)c3_zero16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + P * 1024), 16, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int P = wave + 8 * i; const long long img = 2 * p + P / 18;
-      if (P < 36) {
-        const void* src = (doff[i] >= 0 && img < a.N) ? (const void*)(a.dy + img * HW * 128 + doff[i]) : (const void*)c3_zero16;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + P * 1024), 16, 0, 0);
-      }
+#pragma unroll 1
+    for (int P = wave; P < C3X_KROWS * 8 / 64; P += 8) {
+      const int e = dplan[P * 64 + lane];
+      const long long img = img0 + (e >> 24);
+      const void* src = (e >= 0 && img < a.N) ? (const void*)(a.dy + img * HW * C + (e & 0xffffff)) : (const void*)c3_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + P * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll 1
-    for (int im = 0; im < 2; ++im) {
-      const char* xb = Xs + im * (C3X_ROWS * 256); const char* db = Ds + im * (C3X_KROWS * 128);
+    for (int im = 0; im < a.IT; ++im) {
+      const char* xb = Xs + im * a.RS * 256; const char* db = Ds + im * a.KP * 128;
 #pragma unroll 1
-      for (int s = 0; s < C3X_KROWS / 16; ++s) {
+      for (int s = 0; s < nsteps; ++s) {
         const chunk16 fa = c3_tr_read8(db + offa[0] + s * 2048, db + offa[1] + s * 2048);
 #pragma unroll
         for (int jb = 0; jb < 9; jb += 3) {          // three taps at a time: 12 fragment registers in flight instead of 36
@@ -441,30 +443,40 @@ __global__ __launch_bounds__(512) void wgrad3x3_c128_kernel(C3W128Args a) {
   for (int j = 0; j < 9; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = cohalf * 64 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = ciq * 32 + (lane & 31);
-      atomicAdd(a.dw + (long long)co * 1152 + j * 128 + ci, acc[j][r]);
+      const int co = cog * 64 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cig * 128 + ciq * 32 + (lane & 31);
+      atomicAdd(a.dw + (long long)co * 9 * C + j * C + ci, acc[j][r]);
     }
 }
 
-extern "C" int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
-  return Cin == 128 && Cout == 128 && KH == 3 && KW == 3 && stride == 1 && H >= 1 && W >= 2 && H * (W + 1) <= C3X_KROWS && (H + 2) * (W + 1) + 1 <= C3X_ROWS &&
-         C3X_KROWS - 1 + 2 * (W + 1) + 2 < C3X_ROWS;
+static bool c3_wide_geometry(int H, int W, int C, int& KP, int& RS, int& IT) {
+  const int PW = W + 1;
+  KP = (H * PW + 15) / 16 * 16; RS = (KP + 2 * PW + 2 + 15) / 16 * 16;
+  if (C < 128 || C % 128 || C > 1024 || H < 1 || W < 2 || KP > C3X_KROWS || RS > C3X_ROWS || (H + 2) * PW + 1 > RS || H * W * C >= (1 << 24)) return false;
+  IT = C3X_ROWS / RS; if (C3X_KROWS / KP < IT) IT = C3X_KROWS / KP;
+  if (IT > 64) IT = 64;
+  return IT >= 1;
 }
 
-extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t st) {
+extern "C" int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride) {
+  int KP, RS, IT;
+  return Cin == Cout && KH == 3 && KW == 3 && stride == 1 && c3_wide_geometry(H, W, Cin, KP, RS, IT);
+}
+
+extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int C, int H, int W, hipStream_t st) {
   AVEC_CHECK_ARG(x && dy && dw && images > 0, "wgrad3x3_c128: null buffer");
-  AVEC_CHECK_ARG(avec_wgrad3x3_c128_supported(H, W, 128, 128, 3, 3, 1), "wgrad3x3_c128: %dx%d images do not fit the slab", H, W);
+  C3WWArgs a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W; a.C = C;
+  AVEC_CHECK_ARG(c3_wide_geometry(H, W, C, a.KP, a.RS, a.IT), "wgrad3x3_c128: %d channels, %dx%d images do not fit the slabs", C, H, W);
   static bool attr_set = false;
-  const size_t lds = 2 * C3X_ROWS * 256 + 2 * C3X_KROWS * 128;
+  const size_t lds = (size_t)C3X_ROWS * 256 + C3X_KROWS * 128 + (C3X_ROWS * 16 + C3X_KROWS * 8) * 4;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { avec_set_error("wgrad3x3_c128: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  C3W128Args a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W;
-  const long long pairs = (images + 1) / 2;
-  const int grid = (int)(2 * (pairs < 128 ? pairs : 128));
-  hipLaunchKernelGGL(wgrad3x3_c128_kernel, dim3(grid), dim3(512), lds, st, a);
+  const int kinds = (C / 64) * (C / 128);
+  const long long groups = (images + a.IT - 1) / a.IT;
+  long long per_kind = 256 / kinds; if (per_kind < 1) per_kind = 1; if (per_kind > groups) per_kind = groups;
+  hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3((unsigned)(per_kind * kinds)), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;
 }

@@ -814,7 +814,7 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
             KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     elif SLAB_CONV and SLAB_WGRAD128 and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_wgrad3x3_c128_supported")(H, W, Cin, Cout, KH, KW, stride)):
         ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-        lib.wgrad3x3_c128(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
+        lib.wgrad3x3_c128(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, Cin, H, W, rt.stream())
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     else:

@@ -195,9 +195,10 @@ int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, flo
 /* weight gradient of the same layers (what avec_gemm_tn with ROWS_CONV_FWD computes): dw fp32 [64][9][64] (row stride 576) += sum over images / pixels of
  * dy[p][co] * x[p + tap - 1][ci]; x, dy NHWC bf16.  Needs avec_conv3x3_c64_supported and H * (W + 1) <= 512. */
 int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t stream);
-/* the same for the 128 -> 128 channel layers of ResNet stage 2 (11 x 11 images): dw fp32 [128][9][128] (row stride 1152) */
+/* the same for the wider 3x3 / stride-1 layers with Cin == Cout == C, C a multiple of 128 (ResNet stages 2..4: 128 / 256 / 512 channels, 11x11 / 6x6 / 3x3 images):
+ * dw fp32 [C][9][C] (row stride 9C) += ...; supported when the per-image slabs fit (H (W+1) <= 288 rows of reduction, see csrc/conv3x3.hip) */
 int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride);
-int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t stream);
+int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int C, int H, int W, hipStream_t stream);
 
 /* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
 /* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,

@@ -56,7 +56,7 @@ def conv(Nimg, H, Cin, Cout, stride=1):
     if lib.raw("avec_conv3x3_c64_supported")(H, H, Cin, Cout, 3, 3, stride) and adt == torch.bfloat16:
         timeit(lambda: lib.wgrad3x3_c64(x.data_ptr(), y.data_ptr(), dW.data_ptr(), Nimg, H, H, rt.stream()), fl, "conv wgrad slab kernel")
     if lib.raw("avec_wgrad3x3_c128_supported")(H, H, Cin, Cout, 3, 3, stride) and adt == torch.bfloat16:
-        timeit(lambda: lib.wgrad3x3_c128(x.data_ptr(), y.data_ptr(), dW.data_ptr(), Nimg, H, H, rt.stream()), fl, "conv wgrad slab kernel (128 ch)")
+        timeit(lambda: lib.wgrad3x3_c128(x.data_ptr(), y.data_ptr(), dW.data_ptr(), Nimg, Cin, H, H, rt.stream()), fl, "conv wgrad slab kernel (wide)")
 
 
 plain(4096, 4096, 4096)
