@@ -20,10 +20,23 @@ static constexpr int DW_TT = 32;
 template <typename T>
 __device__ __forceinline__ void stage_glu(float* gs, const T* u, long long b, int Tn, int C, int col, int t_base, int nrows) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < nrows; r += 8) {
-    const int t = t_base + r; float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (col < C && t >= 0 && t < Tn) glu4<T>(u, b * Tn + t, C, col, g);
-    *(float4*)(gs + r * 128 + tx * 4) = make_float4(g[0], g[1], g[2], g[3]);
+  // six rows per pass: all twelve loads are in flight before the first sigmoid (one load latency per pass instead of one per row)
+  for (int r0 = ty; r0 < nrows; r0 += 48) {
+    float a[6][4], bq[6][4];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int r = r0 + 8 * q, t = t_base + r;
+      const bool ok = r < nrows && col < C && t >= 0 && t < Tn;
+      const long long row = ok ? b * Tn + t : b * Tn;          // clamped: the loads stay unconditional
+      const int cc = col < C ? col : 0;
+      ld4<T>(u + row * 2 * C + cc, a[q]); ld4<T>(u + row * 2 * C + C + cc, bq[q]);
+      if (!ok) { a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int r = r0 + 8 * q;
+      if (r < nrows) *(float4*)(gs + r * 128 + tx * 4) = make_float4(a[q][0] * sigmoidf_(bq[q][0]), a[q][1] * sigmoidf_(bq[q][1]), a[q][2] * sigmoidf_(bq[q][2]), a[q][3] * sigmoidf_(bq[q][3]));
+    }
   }
 }
 template <typename T>
@@ -84,23 +97,52 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) for (int e = 0; e < 4; ++e) part[k][e] = 0.f;
   if (col < C) {
-    for (int r = ty; r < nto; r += 8) {
-      float d[4]; ld4<T>(dc + ((long long)b * To + to0 + r) * C + col, d);
-      for (int e = 0; e < 4; ++e) part[KMAX][e] += d[e];
+    float dq[DW_TT / 8][4];                      // this thread's rows of dc, all requested before the first one is used
+#pragma unroll
+    for (int q = 0; q < DW_TT / 8; ++q) {
+      const int r = ty + 8 * q;
+      ld4<T>(dc + ((long long)b * To + to0 + (r < nto ? r : 0)) * C + col, dq[q]);
+      if (r >= nto) { dq[q][0] = dq[q][1] = dq[q][2] = dq[q][3] = 0.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < DW_TT / 8; ++q) {
+      const int r = ty + 8 * q;
+      if (r >= nto) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[KMAX][e] += dq[q][e];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
-        if (k >= K) break;
-        const float4 g = *(const float4*)(gs + (r * stride + k) * 128 + tx * 4);
-        part[k][0] += d[0] * g.x; part[k][1] += d[1] * g.y; part[k][2] += d[2] * g.z; part[k][3] += d[3] * g.w;
+        if (k < K) {
+          const float4 g = *(const float4*)(gs + (r * stride + k) * 128 + tx * 4);
+          part[k][0] += dq[q][0] * g.x; part[k][1] += dq[q][1] * g.y; part[k][2] += dq[q][2] * g.z; part[k][3] += dq[q][3] * g.w;
+        }
       }
     }
   }
-  float* dst[KMAX + 1];
+  // reduce the 17 partial vectors over the 8 row groups of the workgroup in ONE pass (the generic colreduce_atomic walks them one at a time: 34 barriers):
+  // the two row groups of a wave meet by a shuffle, the four waves through the (now dead) GLU image
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) dst[k] = (k < K) ? dw + (long long)k * C : nullptr;
-  dst[KMAX] = dbias;
-  float* const (&cdst)[KMAX + 1] = dst;
-  colreduce_atomic<KMAX + 1>(part, cdst, col, C, ws);
+  for (int k = 0; k <= KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[k][e] += __shfl_xor(part[k][e], 32, 64);
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) *(float4*)(gs + ((wv * (KMAX + 1) + k) * 32 + tx) * 4) = make_float4(part[k][0], part[k][1], part[k][2], part[k][3]);
+  }
+  __syncthreads();
+  float* mine = ws.partial ? ws_slot(ws, blockIdx.x, blockIdx.y, gridDim.y, (KMAX + 1) * 128) : nullptr;
+  for (int i = threadIdx.x; i < (KMAX + 1) * 128; i += 256) {
+    const int k = i >> 7, c = i & 127;
+    const float v = gs[(0 * (KMAX + 1) + k) * 128 + c] + gs[(1 * (KMAX + 1) + k) * 128 + c] + gs[(2 * (KMAX + 1) + k) * 128 + c] + gs[(3 * (KMAX + 1) + k) * 128 + c];
+    if (mine) mine[i] = v;
+    else {
+      const int cc = blockIdx.x * 128 + c;
+      float* d = k == KMAX ? dbias : (k < K ? dw + (long long)k * C : nullptr);
+      if (d && cc < C) atomicAdd(d + cc, v);
+    }
+  }
 }
 
 extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
@@ -123,7 +165,8 @@ extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, con
   long long n4 = (long long)B * T_ * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
   const int nchunks = (To + DW_TT - 1) / DW_TT;
   dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C, st);
-  const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
+  size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
+  if (lds < (size_t)4 * (KMAX + 1) * 128 * sizeof(float)) lds = (size_t)4 * (KMAX + 1) * 128 * sizeof(float);      // the reduction image of the weight-gradient kernel
   AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
   DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To, pad_left);
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), lds, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, pad_left, nchunks, ws));
