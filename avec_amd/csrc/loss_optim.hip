@@ -103,12 +103,21 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
   const float* lg = logits + (long long)b * T * V;
   float* gr = grad ? grad + (long long)b * T * V : nullptr;
   for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
-  for (int t = wv; t < Tb; t += 4) {
-    float mx = -INFINITY; for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[t * V + v]);
-    mx = wave_max(mx);
-    float se = 0.f; for (int v = lane; v < V; v += 64) se += __expf(lg[t * V + v] - mx);
-    se = wave_sum(se);
-    if (lane == 0) lnorm[t] = mx + __logf(se);
+  // frame log-normalisers: four frames per wave in flight (each is a load -> max -> exp -> sum chain of its own)
+  for (int t0 = wv * 4; t0 < Tb; t0 += 16) {
+    float mx[4], se[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int t = min(t0 + q, Tb - 1); mx[q] = -INFINITY; for (int v = lane; v < V; v += 64) mx[q] = fmaxf(mx[q], lg[t * V + v]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mx[q] = wave_max(mx[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int t = min(t0 + q, Tb - 1); se[q] = 0.f; for (int v = lane; v < V; v += 64) se[q] += __expf(lg[t * V + v] - mx[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) se[q] = wave_sum(se[q]);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (t0 + q < Tb) lnorm[t0 + q] = mx[q] + __logf(se[q]);
+    }
   }
   __syncthreads();
   for (int i = tid; i < Tb * S; i += 256) { const int t = i / S, s = i - t * S; lpe[t * Smax + s] = lg[t * V + ext[s]] - lnorm[t]; }
@@ -154,14 +163,13 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
   if (!gr) return;
   for (int i = tid; i < (T - Tb) * V; i += 256) gr[(long long)Tb * V + i] = 0.f;
   if (inf || Tb == 0) { for (int i = tid; i < Tb * V; i += 256) gr[i] = 0.f; return; }
+  // gradient rows: one frame per wave per pass; the occupancy histogram is private to the wave and LDS operations of one wave complete in order,
+  // so the passes need no workgroup barrier
   float* oc = occ + wv * V;
-  for (int t0 = 0; t0 < Tb; t0 += 4) {
-    const int t = t0 + wv;
+  for (int t = wv; t < Tb; t += 4) {
     for (int v = lane; v < V; v += 64) oc[v] = 0.f;
-    __syncthreads();
-    if (t < Tb) for (int s = lane; s < S; s += 64) atomicAdd(oc + ext[s], __expf(alpha[t * Smax + s] + beta[t * Smax + s] - lpe[t * Smax + s] - ll));
-    __syncthreads();
-    if (t < Tb) for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - oc[v];
+    for (int s = lane; s < S; s += 64) atomicAdd(oc + ext[s], __expf(alpha[t * Smax + s] + beta[t * Smax + s] - lpe[t * Smax + s] - ll));
+    for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - oc[v];
   }
 }
 
