@@ -178,7 +178,7 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&O)[CTMAX], float mul
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int PITCH, int NTM>
+template <int PITCH, int NTM, bool ALIAS>
 __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
   const bf16* ep = (const bf16*)a.e + h * d;
   stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  if (!G.alias) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  if (!ALIAS) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
   stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
   __syncthreads();
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   lsum += __shfl_xor(lsum, 32, 64);
   if (hf == 0 && i < Tn) { a.lse[((long long)bh * Tn + i) * 2] = mx; a.lse[((long long)bh * Tn + i) * 2 + 1] = lsum; }
 
-  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place
+  if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place
   // O^T = V^T P^T
   f32x16 O[CTMAX];
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
 // backward, row pass: P and dS (stored for the batched dK / dV / dE GEMMs) and dQ
 //     dP^T[j][i] = V_j . dO_i ;  dS^T = P^T o (dP^T - delta_i) * scale ;  dQ^T = K^T dS^T + E_win^T unskew(dS^T)
 // ------------------------------------------------------------------------------------------------
-template <int PITCH, int NTM>
+template <int PITCH, int NTM, bool ALIAS>
 __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom G) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ; char* Gs = Qs + 64 * PITCH;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
   const bf16* ep = (const bf16*)a.e + h * d;
   const bf16* gp = (const bf16*)a.dout + (long long)b * Tn * a.ldo + h * d;
   stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  if (!G.alias) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
+  if (!ALIAS) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
   stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
   stage_rows<PITCH, 128>(Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
 
   f32x16 S[NTM];
   scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
-  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place for dP
+  if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place for dP
   bf16* prow = (bf16*)a.pbuf + ((long long)bh * Tn + i) * a.ldt;
   bf16* srow = (bf16*)a.dsbuf + ((long long)bh * Tn + i) * a.ldt;
   bf16* rrow = a.dsrel ? (bf16*)a.dsrel + ((long long)h * a.B * Tn + (long long)b * Tn + i) * a.ldr + (Tn - 1 - i) : nullptr;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
       }
     }
   }
-  if (G.alias) { __syncthreads(); stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // and K comes back for dQ
+  if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // and K comes back for dQ
   // dQ^T = K^T dS^T   (A = K^T via transposed reads, B = dS^T registers)
   f32x16 DQ[CTMAX];
 #pragma unroll
@@ -406,8 +406,11 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   if (G.total > 160 * 1024) return 1;
   dim3 grid((a.T + 63) / 64, a.B * a.H);
 #define AVEC_LAUNCH_ATTN(KERNEL) do { if (int r = mfma_set_lds(KERNEL, G.total)) return r; hipLaunchKernelGGL(KERNEL, grid, dim3(128), G.total, st, a, G); } while (0)
-  if (a.T <= 224) { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<128, 7>)); else AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<256, 7>)); }
-  else { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<128, 12>)); else AVEC_LAUNCH_ATTN((attn_mfma_fwd_kernel<256, 12>)); }
+#define AVEC_PICK_ATTN(NAME) do { \
+    if (a.T <= 224 && !G.alias) { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 7, false>)); else AVEC_LAUNCH_ATTN((NAME<256, 7, false>)); } \
+    else if (!G.alias) { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 12, false>)); else AVEC_LAUNCH_ATTN((NAME<256, 12, false>)); } \
+    else { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 12, true>)); else AVEC_LAUNCH_ATTN((NAME<256, 12, true>)); } } while (0)
+  AVEC_PICK_ATTN(attn_mfma_fwd_kernel);
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
@@ -417,8 +420,8 @@ int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) {
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, true);
   if (G.total > 160 * 1024) return 1;
   dim3 grid((a.T + 63) / 64, a.B * a.H);
-  if (a.T <= 224) { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<128, 7>)); else AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<256, 7>)); }
-  else { if (pitch == 128) AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<128, 12>)); else AVEC_LAUNCH_ATTN((attn_mfma_bwd_kernel<256, 12>)); }
+  AVEC_PICK_ATTN(attn_mfma_bwd_kernel);
+#undef AVEC_PICK_ATTN
 #undef AVEC_LAUNCH_ATTN
   AVEC_LAUNCH_CHECK(); return 0;
 }
