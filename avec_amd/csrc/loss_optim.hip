@@ -91,11 +91,11 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
 //   phase 1  frame log-normalisers, one frame per wave, then log p(ext[s] | t) for every (t, s) in parallel
 //   phase 2  alpha (threads 0..127) and beta (threads 128..255) recursions run concurrently, one barrier per frame, LDS only
 //   phase 3  gradient rows, one frame per wave (occupancy scatter into a per-wave LDS histogram)
-__global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
-                                                      const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
-                                                      int B, int T, int V, int Lmax, int blank, int zero_inf) {
+__device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+                                             const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
+                                             int B, int T, int V, int Lmax, int blank, int zero_inf, int b) {
   extern __shared__ float sm[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int Smax = 2 * Lmax + 1;
   float* lpe = sm; float* alpha = lpe + T * Smax; float* beta = alpha + T * Smax; float* lnorm = beta + T * Smax;
   float* occ = lnorm + T; int* ext = (int*)(occ + 4 * V);
@@ -171,6 +171,23 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
     for (int s = lane; s < S; s += 64) atomicAdd(oc + ext[s], __expf(alpha[t * Smax + s] + beta[t * Smax + s] - lpe[t * Smax + s] - ll));
     for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - oc[v];
   }
+}
+
+__global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+                                                      const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
+                                                      int B, int T, int V, int Lmax, int blank, int zero_inf) {
+  ctc_lds_body(logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_inf, blockIdx.x);
+}
+
+// Several CTC heads over the same batch and labels in ONE launch (the InterCTC model evaluates six of them back to back, 32 workgroups each: together they fill
+// 192 CUs instead of 32 six times).  blockIdx.x = head * B + utterance.
+#define AVEC_CTC_MAX_HEADS 8
+struct CtcHeads { const float* logits[AVEC_CTC_MAX_HEADS]; const long long* in_lens[AVEC_CTC_MAX_HEADS]; float* nll[AVEC_CTC_MAX_HEADS]; float* mean_out[AVEC_CTC_MAX_HEADS];
+                  float* grad[AVEC_CTC_MAX_HEADS]; int T[AVEC_CTC_MAX_HEADS]; };
+__global__ __launch_bounds__(256) void ctc_lds_multi_kernel(CtcHeads h, const long long* __restrict__ targets, const long long* __restrict__ tgt_lens,
+                                                            int B, int V, int Lmax, int blank, int zero_inf) {
+  const int head = blockIdx.x / B, b = blockIdx.x - head * B;
+  ctc_lds_body(h.logits[head], h.in_lens[head], targets, tgt_lens, h.nll[head], h.mean_out[head], h.grad[head], B, h.T[head], V, Lmax, blank, zero_inf, b);
 }
 
 // Long-utterance variant (used when the three [T][S] arrays above do not fit: 15 s clips have T = 376 frames at the inter-CTC heads): only alpha lives in LDS.
@@ -282,6 +299,25 @@ extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, cons
   hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(64), lds, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, workspace, B, T, V, Lmax, blank, zero_infinity);
   AVEC_LAUNCH_CHECK(); return 0;
 }
+
+extern "C" int avec_ctc_loss_multi(int n_heads, const float* const* logits, const long long* const* in_lens, const int* T, float* const* nll, float* const* mean_out, float* const* grad,
+                                   const long long* targets, const long long* tgt_lens, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
+  AVEC_CHECK_ARG(n_heads >= 1 && n_heads <= AVEC_CTC_MAX_HEADS && logits && in_lens && T && nll && mean_out && grad && targets && tgt_lens, "ctc_loss_multi: bad arguments (%d heads)", n_heads);
+  AVEC_CHECK_ARG(B > 0 && V > 0 && Lmax >= 0 && blank >= 0 && blank < V, "ctc_loss_multi: bad dims");
+  CtcHeads h; size_t lds = 0;
+  const size_t Smax = 2 * (size_t)Lmax + 1;
+  for (int i = 0; i < AVEC_CTC_MAX_HEADS; ++i) {
+    const int k = i < n_heads ? i : 0;
+    AVEC_CHECK_ARG(logits[k] && in_lens[k] && nll[k] && T[k] > 0, "ctc_loss_multi: null buffer in head %d", k);
+    h.logits[i] = logits[k]; h.in_lens[i] = in_lens[k]; h.nll[i] = nll[k]; h.mean_out[i] = mean_out[k]; h.grad[i] = grad[k]; h.T[i] = T[k];
+    const size_t need = (3 * (size_t)T[k] * Smax + T[k] + 4 * (size_t)V + Smax) * 4;
+    if (need > lds) lds = need;
+  }
+  AVEC_CHECK_ARG(lds <= 64 * 1024, "ctc_loss_multi: a head does not fit the all-LDS kernel (use avec_ctc_loss per head)");
+  hipLaunchKernelGGL(ctc_lds_multi_kernel, dim3((unsigned)(n_heads * B)), dim3(256), lds, st, h, targets, tgt_lens, B, V, Lmax, blank, zero_infinity);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_ctc_loss_multi_fits(int T, int V, int Lmax) { const size_t S = 2 * (size_t)Lmax + 1; return (3 * (size_t)T * S + T + 4 * (size_t)V + S) * 4 <= 64 * 1024; }
 
 // nn.CrossEntropyLoss(ignore_index, reduction='none') as losses.SoftmaxCrossEntropy uses it (nnet/losses.py:258-290): one wave per row,
 //   loss[m] = logsumexp(x[m]) - x[m][y[m]]  (0 when y[m] == ignore_index);  mean_out += loss[m] / M  (Reduction('mean') = mean over ALL rows);

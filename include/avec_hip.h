@@ -217,6 +217,11 @@ int avec_video_input(const unsigned char* clips, const long long* clip_off, cons
 long long avec_ctc_workspace_floats(int B, int T, int Lmax);
 int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
                   float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
+/* the same for up to 8 heads that share the batch and the labels (ConformerInterCTC: nnet/networks.py:285-305 feeds six CTC losses), one launch; every head must
+ * fit the all-LDS kernel (avec_ctc_loss_multi_fits).  Arrays of n_heads host pointers / frame counts. */
+int avec_ctc_loss_multi_fits(int T, int V, int Lmax);
+int avec_ctc_loss_multi(int n_heads, const float* const* logits, const long long* const* in_lens, const int* T, float* const* nll, float* const* mean_out, float* const* grad,
+                        const long long* targets, const long long* tgt_lens, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
 int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t stream);
 /* losses.SoftmaxCrossEntropy (nnet/losses.py:258-290; the LRW word classifier): per-row cross entropy of fp32 logits [M][V] against int64 targets,
  * rows with target == ignore_index give 0; mean_out (optional) += loss/M; grad (optional) = softmax - onehot */
