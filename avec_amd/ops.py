@@ -412,7 +412,7 @@ class AttentionModuleFn(torch.autograd.Function):
         linear_bwd_weight(doo, o, wo, Mp, bias=bo)
         do = linear_bwd_input(doo, wo, Mp, out_f32=False)
         dqkv = empty((Mp, 3 * D), adt, dy)
-        de = torch.zeros((2 * Tp - 1, D), dtype=torch.float32, device=dy.device)
+        de = rt.zeros_scratch((2 * Tp - 1) * D, dy.device).view(2 * Tp - 1, D)      # pre-zeroed pool: no fill launch per layer (-0.15 ms per step)
         a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D, T // patch if (patch > 1 and mask is None) else 0)
         a.dout = do.data_ptr()
         esz = dqkv.element_size()
