@@ -115,12 +115,12 @@ class Model(Module):
 
     def _fused_ctc_losses(self, outputs, targets):
         """The CTC heads of an InterCTC model share the batch and the labels: when they all fit the LDS-resident kernel they are evaluated by ONE launch
-        (ops.CTCLossMultiFn) instead of one 32-workgroup launch per head.  Returns {key: loss} for the heads it covered (same values as losses.CTCLoss)."""
+        (ops.CTCLossMultiFn) instead of one 32-workgroup launch per head.  Returns ({key: loss} for the heads it covered (same values as losses.CTCLoss; for logging), their weighted sum (differentiable)) or ({}, None)."""
         from .losses import CTCLoss
         keys = [k for k in outputs if isinstance(self.losses.get(k), CTCLoss) and isinstance(outputs[k], (list, tuple)) and len(outputs[k]) == 2
                 and torch.is_tensor(outputs[k][0]) and outputs[k][0].is_cuda and outputs[k][0].dim() == 3]
         if len(keys) < 2 or len(keys) > 8:
-            return {}
+            return {}, None
         l0, t0 = self.losses[keys[0]], targets[keys[0]]
         same = all(self.losses[k].blank == l0.blank and self.losses[k].zero_infinity == l0.zero_infinity and self.losses[k].reduction == "mean" and not self.losses[k].assert_shorter
                    and targets[k][0] is t0[0] and targets[k][1] is t0[1] and outputs[k][0].shape[0] == outputs[keys[0]][0].shape[0]
@@ -128,11 +128,13 @@ class Model(Module):
         y, y_len = t0
         Lmax = y.shape[1] if y.dim() == 2 else y.numel() // outputs[keys[0]][0].shape[0]
         if not same or not all(ops.ctc_multi_fits(outputs[k][0].shape[1], outputs[k][0].shape[2], Lmax) for k in keys):
-            return {}
+            return {}, None
         flat = []
         for k in keys:
             flat += [outputs[k][0], outputs[k][1]]
-        return dict(zip(keys, ops.CTCLossMultiFn.apply(l0.blank, l0.zero_infinity, y, y_len, *flat)))
+        weights = tuple(self.loss_weights[k].get_val_step(self.model_step + 1) for k in keys)
+        res = ops.CTCLossMultiFn.apply(l0.blank, l0.zero_infinity, y, y_len, weights, *flat)
+        return dict(zip(keys, res[1:])), res[0]
 
     # -- one forward + losses (nnet/model.py:227-344) ---------------------------------------------
     def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
@@ -146,10 +148,15 @@ class Model(Module):
         targets = self.map_to_outputs(outputs, targets)
         if not self.built:
             self.build(outputs)
-        fused = self._fused_ctc_losses(outputs, targets)
+        fused, fused_total = self._fused_ctc_losses(outputs, targets)
+        if fused_total is not None:
+            total_loss = total_loss + fused_total
         for key in outputs:
             if self.losses[key] is not None:
-                l = fused[key] if key in fused else self.losses[key](targets[key], outputs[key])
+                if key in fused:                     # already inside fused_total with its weight
+                    batch_losses["loss_" + key] = fused[key]
+                    continue
+                l = self.losses[key](targets[key], outputs[key])
                 batch_losses["loss_" + key] = l
                 total_loss = total_loss + l * self.loss_weights[key].get_val_step(self.model_step + 1)
             if compute_metrics and self.metrics and self.metrics[key] is not None:

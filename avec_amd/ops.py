@@ -725,11 +725,12 @@ class CTCLossFn(torch.autograd.Function):
 
 
 class CTCLossMultiFn(torch.autograd.Function):
-    """n CTC heads over the same batch and labels in one launch (avec_ctc_loss_multi): apply(blank, zero_infinity, targets, target_len, logits_0, len_0, ...)
-    -> n batch-mean losses.  Same arithmetic per head as CTCLossFn (the kernel body is shared)."""
+    """n CTC heads over the same batch and labels in one launch (avec_ctc_loss_multi): apply(blank, zero_infinity, targets, target_len, weights, logits_0, len_0, ...)
+    -> (sum_i weights[i] * loss_i, loss_0, ..., loss_{n-1}); the individual batch-mean losses are returned for logging (not differentiable), the weighted sum
+    carries the gradient: backward is one scaling launch per head.  Same arithmetic per head as CTCLossFn (the kernel body is shared)."""
 
     @staticmethod
-    def forward(ctx, blank, zero_infinity, targets, target_len, *flat):
+    def forward(ctx, blank, zero_infinity, targets, target_len, weights, *flat):
         n = len(flat) // 2
         logits, lens = [_f32c(t) for t in flat[0::2]], flat[1::2]
         rt.require_gpu(logits[0])
@@ -742,29 +743,39 @@ class CTCLossMultiFn(torch.autograd.Function):
         tl = target_len.to(device=dev, dtype=torch.int64).contiguous()
         ils = [l.to(device=dev, dtype=torch.int64).contiguous() for l in lens]
         nll = torch.empty((n, B), dtype=torch.float32, device=dev)
-        means = torch.zeros((n,), dtype=torch.float32, device=dev)
-        grads = [empty(tuple(lg.shape), torch.float32, lg) if ctx.needs_input_grad[4 + 2 * i] else None for i, lg in enumerate(logits)]
+        means = rt.zeros_scratch(n, dev)
+        grads = [empty(tuple(lg.shape), torch.float32, lg) if ctx.needs_input_grad[5 + 2 * i] else None for i, lg in enumerate(logits)]
         arr_p = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
         Ts = (ctypes.c_int * n)(*[lg.shape[1] for lg in logits])
         lib.ctc_loss_multi(n, arr_p([lg.data_ptr() for lg in logits]), arr_p([l.data_ptr() for l in ils]), Ts, arr_p([nll[i].data_ptr() for i in range(n)]),
                            arr_p([means[i:].data_ptr() for i in range(n)]), arr_p([g.data_ptr() if g is not None else None for g in grads]),
                            tg.data_ptr(), tl.data_ptr(), B, V, Lmax, blank, int(zero_infinity), rt.stream())
-        ctx.saved = (grads, B, n)
+        wkey = (tuple(float(x) for x in weights), str(dev))
+        if wkey not in _WCACHE:                      # created in the eager warm-up steps, reused (a constant) by a captured graph
+            _WCACHE[wkey] = torch.tensor(wkey[0], dtype=torch.float32, device=dev)
+        total = torch.dot(means, _WCACHE[wkey])
+        ctx.saved = (grads, B, n, [float(x) for x in weights])
         ctx.keep = (logits, ils, tg, tl, nll)
-        return tuple(means[i] for i in range(n))
+        outs = tuple(means[i] for i in range(n))
+        ctx.mark_non_differentiable(*outs)
+        return (total,) + outs
 
     @staticmethod
-    def backward(ctx, *dlosses):
-        grads, B, n = ctx.saved
-        out = [None, None, None, None]
+    def backward(ctx, dtotal, *_unused):
+        grads, B, n, weights = ctx.saved
+        out = [None, None, None, None, None]
+        dt = dtotal.float().contiguous()
         for i in range(n):
-            if grads[i] is None or dlosses[i] is None:
+            if grads[i] is None:
                 out += [None, None]
                 continue
             o = torch.empty_like(grads[i])
-            lib.scale_by_scalar(grads[i].data_ptr(), dlosses[i].float().contiguous().data_ptr(), 1.0 / B, o.data_ptr(), grads[i].numel(), rt.stream())
+            lib.scale_by_scalar(grads[i].data_ptr(), dt.data_ptr(), weights[i] / B, o.data_ptr(), grads[i].numel(), rt.stream())
             out += [o, None]
         return tuple(out)
+
+
+_WCACHE = {}
 
 
 def ctc_multi_fits(T, V, Lmax):
