@@ -155,10 +155,10 @@ class Model(Module):
             if self.losses[key] is not None:
                 if key in fused:                     # already inside fused_total with its weight
                     batch_losses["loss_" + key] = fused[key]
-                    continue
-                l = self.losses[key](targets[key], outputs[key])
-                batch_losses["loss_" + key] = l
-                total_loss = total_loss + l * self.loss_weights[key].get_val_step(self.model_step + 1)
+                else:
+                    l = self.losses[key](targets[key], outputs[key])
+                    batch_losses["loss_" + key] = l
+                    total_loss = total_loss + l * self.loss_weights[key].get_val_step(self.model_step + 1)
             if compute_metrics and self.metrics and self.metrics[key] is not None:
                 metric, decoder = self.metrics[key], (self.decoders[key] if self.decoders else None)
                 name = metric.name if metric.name not in batch_metrics else metric.name + "_" + key
