@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 // TN: O[i][j] += sum_m P[m][i] * Q[m][j];   P plain [M][I] (T), Q via row loader ([M][J], plain or im2col)
 // LDS images are [i][m] / [j][m] (reduction index contiguous) filled by transposing stores.
 // ------------------------------------------------------------------------------------------------
-struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block; float* pcs;   // pcs: optional column sums of P (bias gradient), transposed-read kernel only
+struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; void* Oact; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block; float* pcs;   // Oact: when set, the result is STORED in the activation dtype (one workgroup per tile, no split) instead of added to O;   // pcs: optional column sums of P (bias gradient), transposed-read kernel only
                   // Iq/Jq: load bounds (>= I/J when rows are padded)
                 int split, nb_inner; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
 
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   g.P = (const T*)g.P + bo * g.sPo + bi * g.sPi;
   g.q.ptr = (Q_F32 && sizeof(T) == 2) ? (const void*)((const float*)g.q.ptr + bo * g.sQo + bi * g.sQi) : (const void*)((const T*)g.q.ptr + bo * g.sQo + bi * g.sQi);
   g.O += bo * g.sOo + bi * g.sOi;
+  T* Oact = g.Oact ? (T*)g.Oact + bo * g.sOo + bi * g.sOi : nullptr;
   const long long mb = (long long)zs * g.m_per_block;
   long long me = mb + g.m_per_block; if (me > g.M) me = g.M;
 
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i0 + wm * (BI / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.I) atomicAdd(g.O + (long long)row * g.ldo + col, acc[i][j][r]);
+        if (row < g.I) { if (Oact) stf(Oact + (long long)row * g.ldo + col, acc[i][j][r]); else atomicAdd(g.O + (long long)row * g.ldo + col, acc[i][j][r]); }
       }
   }
 }
@@ -939,7 +940,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   // re-measured per ResNet stage (tools/bench_gemm.py, AVEC_TN_WGS sweep): few output tiles (stage 2: 9) are best at ~1024 workgroups (232 vs 255 us), 36 tiles
   // (stage 3) at 2048, 144 tiles (stage 4) at 4096 (358 vs 378 us): the split has to cover the chip several times over, but every workgroup pays BI*BJ atomics
   const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? (tiles <= 16 ? 1024 : tiles <= 64 ? 2048 : 4096) : 512);
-  long long split = (wg_target + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1) split = 1;
+  long long split = (wg_target + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1 || g.Oact) split = 1;
   long long per = ((ksteps + split - 1) / split) * KE;
   split = (g.M + per - 1) / per;
   g.m_per_block = (int)per; g.split = (int)split;
@@ -949,7 +950,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   const bool f32src = q_f32 && sizeof(T) == 2;
   const bool a16 = nbatch == 1 && aligned16(g.P) && aligned16(g.q.ptr) && g.Iq % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
-  if (sizeof(T) == 2 && a16 && !f32src) {                   // bf16: LDS-DMA + transposed-read kernel
+  if (sizeof(T) == 2 && a16 && !f32src && !g.Oact) {        // bf16: LDS-DMA + transposed-read kernel
     static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
     if (use_tr) {
       // reduction rows per LDS tile: 32 (two 16 KB stages for 128x128) keeps 4 workgroups resident per CU; measured on the ResNet weight
@@ -979,9 +980,9 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
 }
 
 static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
-                        float* O, long long ldo, long long M, int I, int J, int nb_outer, int nb_inner, const long long* strides, float* p_colsum, hipStream_t stream) {
+                        float* O, void* Oact, long long ldo, long long M, int I, int J, int nb_outer, int nb_inner, const long long* strides, float* p_colsum, hipStream_t stream) {
   AVEC_CHECK_ARG(dtype == AVEC_F32 || dtype == AVEC_BF16, "gemm_tn: bad dtype %d", dtype);
-  AVEC_CHECK_ARG(P && Q && O && q_rows, "gemm_tn: null pointer");
+  AVEC_CHECK_ARG(P && Q && (O || Oact) && q_rows, "gemm_tn: null pointer");
   AVEC_CHECK_ARG(M > 0 && I > 0 && J > 0 && nb_outer > 0 && nb_inner > 0, "gemm_tn: bad dims");
   AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_mode == MODE_CONV_FWD, "gemm_tn: bad q_mode %d", q_mode);
   const int vec = dtype == AVEC_BF16 ? 8 : 4;
@@ -992,7 +993,7 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   AVEC_CHECK_ARG(q_mode != MODE_PLAIN || dtype == AVEC_F32 || q_rows->ld % 2 == 0, "gemm_tn: ldq must be even");
   AVEC_CHECK_ARG(q_mode == MODE_PLAIN || q_rows->C % vec == 0, "gemm_tn: conv C=%d must be a multiple of %d", q_rows->C, vec);
   AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
-  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0; g.pcs = p_colsum;
+  TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.Oact = Oact; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0; g.pcs = p_colsum;
   g.split = 1; g.nb_inner = nb_inner;
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
@@ -1015,17 +1016,23 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
 
 extern "C" int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
                             float* O, long long ldo, long long M, int I, int J, hipStream_t stream) {
-  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, nullptr, stream);
+  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, nullptr, ldo, M, I, J, 1, 1, nullptr, nullptr, stream);
 }
 extern "C" int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
                                  float* O, long long ldo, float* p_colsum, long long M, int I, int J, hipStream_t stream) {
   AVEC_CHECK_ARG(!p_colsum || (I % 4 == 0 && ldp % 4 == 0), "gemm_tn_bias: column sums need I %% 4 == 0 and ldp %% 4 == 0");
-  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, ldo, M, I, J, 1, 1, nullptr, p_colsum, stream);
+  return gemm_tn_impl(dtype, P, ldp, Q, q_rows, q_mode, q_f32, O, nullptr, ldo, M, I, J, 1, 1, nullptr, p_colsum, stream);
 }
 
 extern "C" int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                                     int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream) {
   avec_rows_t rows = {}; rows.ld = ldq;
   AVEC_CHECK_ARG(strides6, "gemm_tn_batched: null strides");
-  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, O, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
+  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, O, nullptr, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
+}
+extern "C" int avec_gemm_tn_batched_store(int dtype, const void* P, long long ldp, const void* Q, long long ldq, void* O_act, long long ldo, long long M, int I, int J,
+                                          int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream) {
+  avec_rows_t rows = {}; rows.ld = ldq;
+  AVEC_CHECK_ARG(strides6 && O_act, "gemm_tn_batched_store: null pointer");
+  return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, nullptr, O_act, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
 }

@@ -429,15 +429,15 @@ class AttentionModuleFn(torch.autograd.Function):
         lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())
         if use_mfma:
             # dK = dS^T Q and dV = P^T dO per (batch, head); dE_h = sum_b skew(dS)^T Q : batched TN MFMA GEMMs, fp32 accumulation
-            dkv32 = torch.zeros((Mp, 2 * D), dtype=torch.float32, device=dy.device)
+            # dK and dV: one workgroup per (batch, head, tile) reduces over all Tp rows and stores straight into the K / V thirds of dqkv (no zero-filled
+            # fp32 staging, no atomics, no cast pass); dE sums over the batch, so it keeps the accumulate form
             L6 = ctypes.c_longlong * 6
-            lib.gemm_tn_batched(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dkv32.data_ptr(), 2 * D, Tp, Tp, d, B, H,
-                                L6(H * Tp * Tld, Tp * Tld, Tp * 3 * D, d, Tp * 2 * D, d), rt.stream())
-            lib.gemm_tn_batched(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dkv32.data_ptr() + D * 4, 2 * D, Tp, Tp, d, B, H,
-                                L6(H * Tp * Tld, Tp * Tld, Tp * D, d, Tp * 2 * D, d), rt.stream())
+            lib.gemm_tn_batched_store(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D, Tp, Tp, d, B, H,
+                                      L6(H * Tp * Tld, Tp * Tld, Tp * 3 * D, d, Tp * 3 * D, d), rt.stream())
+            lib.gemm_tn_batched_store(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D, Tp, Tp, d, B, H,
+                                      L6(H * Tp * Tld, Tp * Tld, Tp * D, d, Tp * 3 * D, d), rt.stream())
             lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * Tp, 2 * Tp - 1, d, 1, H,
                                 L6(0, B * Tp * Rld, 0, d, 0, d), rt.stream())
-            lib.cast_rows(rt.dt(), dkv32.data_ptr(), 2 * D, dqkv.data_ptr() + D * esz, 3 * D, Mp, 2 * D, rt.stream())
         dhp = None
         grp = rt.fused_group(wq)
         if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:

@@ -88,6 +88,10 @@ int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, co
                       float* O, long long ldo, float* p_colsum, long long M, int I, int J, hipStream_t stream);
 int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                          int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
+/* the same products STORED in the activation dtype (one workgroup per tile reduces over all M rows: no split, no atomics, no zero-filled fp32 staging):
+ * dK and dV of the attention backward go straight into the Q|K|V gradient matrix */
+int avec_gemm_tn_batched_store(int dtype, const void* P, long long ldp, const void* Q, long long ldq, void* O_act, long long ldo, long long M, int I, int J,
+                               int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 
 /* ---- normalisation / elementwise (avec_amd/csrc/norm.hip) ---------------------------------- */
 /* nn.LayerNorm(eps=1e-6) forward/backward: aten::native_layer_norm(_backward) emitted by nnet/modules.py:278,302,373
