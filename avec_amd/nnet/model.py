@@ -140,6 +140,8 @@ class Model(Module):
     def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
         batch_losses, batch_metrics, batch_truths, batch_preds = {}, {}, {}, {}
         total_loss = torch.zeros((), device=self.device)
+        if self.arena is not None:
+            self.arena.check_versions()           # weights edited in place since the last pass -> refresh their compute-dtype shadows
         outputs = self.forward(inputs)
         if isinstance(outputs, list):
             outputs = {"output_" + str(k): v for k, v in enumerate(outputs)}
@@ -194,14 +196,18 @@ class Model(Module):
             self.arena.all_reduce_grads()
             self.optimizer.grad_scale = 1.0 / self.world_size
         if self.grad_max_norm is not None:
-            norm = self.arena.grad.norm() * getattr(self.optimizer, "grad_scale", 1.0)
-            self.arena.grad.mul_((self.grad_max_norm / (norm + 1e-6)).clamp(max=1.0))
-            self.add_info("grad_norm", norm)
+            self.add_info("grad_norm", self.clip_gradients(self.grad_max_norm))
         self.optimizer.step()
         self.optimizer.zero_grad()
         self.add_info("lr", float(self.optimizer.param_groups[0]["lr"]))
         self.add_info("step", int(self.model_step))
         return batch_losses, batch_metrics, 0
+
+    def clip_gradients(self, max_norm):
+        """global-norm clipping of the flat gradient arena (torch.nn.utils.clip_grad_norm_ semantics, nnet/model.py:381-383); returns the norm before clipping"""
+        norm = self.arena.grad.norm() * getattr(self.optimizer, "grad_scale", 1.0)
+        self.arena.grad.mul_((max_norm / (norm + 1e-6)).clamp(max=1.0))
+        return norm
 
     def make_graphed_train_step(self, inputs, targets, precision=torch.bfloat16, warmup=2):
         """Capture ONE optimisation step (shadow refresh, forward, 6 losses, backward, Adam) into a hipGraph: ~2500 launches replay from a
@@ -262,9 +268,11 @@ class Model(Module):
         if ckpt.get("is_distributed", False):
             sd = {k.replace(".module.", ".").replace("module.", "", 1) if k.startswith("module.") else k.replace(".module.", "."): v for k, v in sd.items()}
         self.load_state_dict({k: v for k, v in sd.items()}, strict=strict)
-        self.model_step.fill_(ckpt["model_step"])
         if load_optimizer and ckpt.get("optimizer_state_dict") is not None:
+            # the step counter (Noam schedule, loss-weight schedules, Adam bias correction) travels with the optimizer state (nnet/model.py:527-536):
+            # fine-tuning from a checkpoint without its optimizer restarts the schedule at step 0 on zero moments
             self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+            self.model_step.fill_(ckpt["model_step"])
 
     # -- loops (compact counterparts of nnet/model.py:668-942, 1047-1077) ----------------------------
     def fit(self, dataset_train, epochs, dataset_eval=None, eval_steps=None, verbose_eval=0, initial_epoch=0, callback_path=None, steps_per_epoch=None,
@@ -275,6 +283,9 @@ class Model(Module):
             os.makedirs(callback_path, exist_ok=True)
         for epoch in range(initial_epoch, epochs):
             self.train()
+            sampler = getattr(dataset_train, "sampler", None)
+            if self.is_distributed and hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)          # reshuffle + re-shard per epoch (nnet/model.py:709-710)
             acc_step, t0, n = 0, time.time(), 0
             for step, batch in enumerate(dataset_train):
                 inputs = self.transfer_to_device(batch["inputs"])
@@ -291,6 +302,8 @@ class Model(Module):
                     self.save(os.path.join(callback_path, "checkpoints_epoch_{}_step_{}.ckpt".format(epoch + 1, int(self.model_step))))
             if dataset_eval is not None and (epoch + 1) % eval_period_epoch == 0:
                 self.evaluate(dataset_eval, eval_steps)
+            if self.is_distributed:
+                torch.distributed.barrier()       # ranks leave the epoch together (rank 0 wrote the checkpoint)
 
     def evaluate(self, dataset_eval, eval_steps=None, verbose=0, eval_loss=True, recompute_metrics=False):
         if isinstance(dataset_eval, (list, tuple)):          # several evaluation sets (the reference configs list LRS2 and LRS3 test sets)

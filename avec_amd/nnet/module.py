@@ -56,4 +56,4 @@ class Module(nn.Module):
             return struct.to(dev)
         if struct is None:
             return None
-        raise Exception("Incorrect struct type: {}. Must be dict, list module, tensor or None.".format(type(struct)))
+        raise TypeError("cannot move a %s to a device (expected None, a tensor, a module, or a dict / list / tuple of those)" % type(struct).__name__)

@@ -42,11 +42,19 @@ class Adam(optim.Adam):
         if self.arena is None:
             raise RuntimeError("nnet.Adam steps a model's flat parameter arena on the GPU: move the model with Model.to('cuda') first "
                                "(there is no per-tensor / CPU optimizer path)")
-        if "host_state" not in self._flat:
-            self._flat["host_state"] = torch.zeros(2, dtype=torch.float32).pin_memory()
-        self._flat["host_state"][0] = float(self.scheduler.model_step)
-        self._flat["host_state"][1] = float(lr)
-        self._flat["state"].copy_(self._flat["host_state"], non_blocking=True)
+        # ring of pinned {step, lr} slots: the H2D copy of step N is asynchronous, so the host may already be preparing step N+1 (graph replays,
+        # eager steps never sync) -- it then writes a DIFFERENT slot; a slot is reused only after its copy's event completed
+        if "host_ring" not in self._flat:
+            self._flat["host_ring"] = [(torch.zeros(2, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._flat["host_pos"] = 0
+        slot, ev = self._flat["host_ring"][self._flat["host_pos"] % 8]
+        if self._flat["host_pos"] >= 8:
+            ev.synchronize()
+        self._flat["host_pos"] += 1
+        slot[0] = float(self.scheduler.model_step)
+        slot[1] = float(lr)
+        self._flat["state"].copy_(slot, non_blocking=True)
+        ev.record()
 
     def launch_step(self):
         """device half: ONE kernel over the flat arenas (graph-capturable)"""

@@ -371,6 +371,12 @@ class ParamArena:
         self.device = dev
         self._shadow_dtype = None
         self.dirty = True
+        self._vstamp = None
+        # any load_state_dict on the model OR on one of its sub-modules (the reference configs transplant the LRW front-end this way,
+        # configs/LRS23/AV/EffConfInterCTC.py:70-75) rewrites master weights: the compute-dtype shadows must follow
+        for m in module.modules():
+            if any(True for _ in m.parameters(recurse=False)):
+                m.register_load_state_dict_post_hook(lambda _m, _keys, arena=self: arena.mark_dirty())
         self._build_shadows()
 
     def _build_shadows(self):
@@ -449,7 +455,20 @@ class ParamArena:
             self.dirty = False
 
     def mark_dirty(self):
+        """The master weights changed outside the Adam kernel: refresh the shadows before the next GEMM.  Called automatically by load_state_dict
+        (model or sub-module) and by check_versions(); call it by hand after editing weights through `.data` (which leaves no trace)."""
         self.dirty = True
+
+    def check_versions(self):
+        """In-place edits of parameters (p.copy_, init functions, EMA copies under no_grad) bump the tensors' version counters: compare their sum
+        with the last one seen (once per forward pass, ~0.1 ms of host time) and mark the shadows stale when it moved."""
+        stamp = 0
+        for p in self.params:
+            stamp += p._version
+        if stamp != self._vstamp:
+            if self._vstamp is not None:
+                self.dirty = True
+            self._vstamp = stamp
 
     def zero_grad(self):
         self.grad.zero_()

@@ -51,13 +51,33 @@ def main(B=2):
     ls2 = O.total_loss({k: [v[0].detach(), v[1]] for k, v in out.items()}, labels, llen, O.AV_LOSS_WEIGHTS, use_aten=False)
     print("own-CTC loss", float(ls2["loss"]), "aten", float(ls["loss"]))
     ok &= abs(float(ls2["loss"]) - float(ls["loss"])) < 1e-4 * abs(float(ls["loss"]))
-    worst = 0.0
+    # Gradients: the fp64 oracle is the truth.  Per tensor, the oracle's relative-L2 distance to it must not exceed the reference's own distance
+    # (both are fp32 evaluations of the same graph in different summation orders) by more than 4x + 1e-5 -- the criterion of
+    # tests/test_gpu_parity.py::test_full_model_grads_match_oracle.  Structurally-zero gradients (biases in front of a softmax-invariant
+    # shift / a training-mode BatchNorm: pure rounding noise in both) are only bounded in magnitude.
+    STRUCT_ZERO = ("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias", "layers.0.0.bias")
+    sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    for k, v in sd64.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    out64 = O.av_forward(sd64, video.double(), vlen, audio.double(), alen, train=True, stats_out={})
+    O.total_loss(out64, labels, llen, O.AV_LOSS_WEIGHTS)["loss"].backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    worst, worst_k, n_zero, n_checked = 0.0, None, 0, 0
     for k, g in ref_grads.items():
-        go = sd[k].grad
-        err = (g - go).abs().max().item() / (g.abs().max().item() + 1e-12)
-        worst = max(worst, err)
-    print("worst relative grad error (max-norm) over %d tensors: %.2e" % (len(ref_grads), worst))
-    ok &= worst < 1e-3
+        g64 = sd64[k].grad
+        if k.endswith(STRUCT_ZERO):
+            n_zero += 1
+            ok &= sd[k].grad.abs().max().item() < 1e-3 * max(1.0, g64.abs().max().item()) + 1e-3
+            continue
+        e_ref, e_orc = l2(g, g64), l2(sd[k].grad, g64)
+        ratio = e_orc / (4.0 * e_ref + 1e-5)
+        if ratio > worst:
+            worst, worst_k = ratio, (k, e_orc, e_ref)
+        n_checked += 1
+    print("gradients: %d tensors vs the fp64 truth (+ %d structurally-zero ones bounded in magnitude); worst oracle/(4*reference+1e-5) error ratio %.3f at %s"
+          % (n_checked, n_zero, worst, worst_k))
+    ok &= worst < 1.0 and n_checked > 800
     new_sd = model.state_dict()
     w = 0.0
     for k, v in stats.items():

@@ -1,0 +1,317 @@
+"""GPU (-m gpu), round-2 parity cases: the arithmetic and the kernel variants the benchmark actually runs.
+
+* bf16 (the benchmarked dtype) full-model GRADIENTS against the fp64 oracle, per tensor, also with the kernel variants that only the B=32 shape
+  selects (64-byte-row NT ring, deep TN splits) forced through the library's environment switches in a subprocess;
+* SpecAugment (inside the timed region) as a property test on the device output (nnet/preprocessing.py:115-130);
+* BASELINE config 5's shape (15 s clips: 240 000 samples / 376 frames) through the full AV model against the oracle;
+* bench.py's own launcher (python bench.py --gpus 2 spawns its ranks) on one GPU over gloo.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests import bf16_grad_probe as probe
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STRUCT_ZERO = ("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias", "layers.0.0.bias")
+
+# bf16 storage + bf16 MFMA inputs (8 mantissa bits, eps = 3.9e-3) through 24 conformer blocks / 17 convolutions with training-mode BatchNorm:
+# measured on MI355X (B = 2, this seed) the per-tensor relative L2 error of the gradients against the fp64 oracle has median ~1e-2 and
+# maximum ~4e-2 (BatchNorm-heavy ResNet tensors).  The bound is a small multiple of that; a wrong kernel (dropped term, wrong scale, transposed
+# tile) gives O(1) errors.
+BF16_GRAD_TOL = 0.10
+BF16_GRAD_MEDIAN_TOL = 0.03
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def av_oracle(tmp_path_factory):
+    """fp64 oracle gradients of the full AV model at B = 2 (seed-0 init, the inputs of tests/test_gpu_parity.py), saved for the subprocess runs"""
+    from oracle import avec_oracle as O
+    model, sd0 = probe.build_model()
+    video, vlen, audio, alen, labels, llen = probe.av_inputs(2)
+    sd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    out = O.av_forward(sd, video.double(), vlen, audio.double(), alen, train=True, stats_out={})
+    ls = O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)
+    ls["loss"].backward()
+    g64 = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad}
+    path = str(tmp_path_factory.mktemp("oracle") / "g64.pt")
+    torch.save(g64, path)
+    return model, g64, {k: float(v) for k, v in ls.items()}, path
+
+
+def _check_bf16(errs, losses, finite, ref_losses, tag):
+    assert finite, tag
+    for k, v in ref_losses.items():
+        assert abs(losses[k] - v) < 5e-2 * abs(v), (tag, k, losses[k], v)
+    checked = sorted((e, k) for k, e in errs.items() if not k.endswith(STRUCT_ZERO))
+    assert len(checked) > 800
+    worst_e, worst_k = checked[-1]
+    median = checked[len(checked) // 2][0]
+    assert worst_e < BF16_GRAD_TOL, (tag, worst_k, worst_e)
+    assert median < BF16_GRAD_MEDIAN_TOL, (tag, median)
+
+
+def test_full_model_bf16_grads_match_fp64_oracle(av_oracle):
+    """every non-structurally-zero gradient tensor of the benchmarked arithmetic (bf16) against the fp64 truth"""
+    model, g64, ref_losses, _ = av_oracle
+    errs, losses, finite = probe.grad_errors(model, g64, "bf16")
+    _check_bf16(errs, losses, finite, ref_losses, "default kernels")
+
+
+@pytest.mark.parametrize("env", [{"AVEC_NT_RB": "64", "AVEC_TN_WGS": "4096"}, {"AVEC_NT_RB": "128", "AVEC_TN_WGS": "64", "AVEC_TN_KT": "64"}],
+                         ids=["rb64+deep_split", "rb128+shallow_split"])
+def test_full_model_bf16_grads_bench_kernel_variants(av_oracle, tmp_path, env):
+    """the same check with the NT ring variant (64-byte rows, chosen by tile count at B = 32) and the TN split depth forced"""
+    _, _, ref_losses, g64_path = av_oracle
+    out = str(tmp_path / "errs.json")
+    e = dict(os.environ, **env)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-m", "tests.bf16_grad_probe", g64_path, out], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    _check_bf16(res["errs"], res["losses"], res["finite"], ref_losses, str(env))
+
+
+# ----------------------------------------------------------------------------------------------
+# SpecAugment
+# ----------------------------------------------------------------------------------------------
+def _runs(mask_1d):
+    """[(start, length)] of the True runs of a 1-D bool tensor"""
+    idx = mask_1d.nonzero().flatten().tolist()
+    runs = []
+    for i in idx:
+        if runs and runs[-1][0] + runs[-1][1] == i:
+            runs[-1][1] += 1
+        else:
+            runs.append([i, 1])
+    return runs
+
+
+def _coverable(runs, n_bands, max_width):
+    """can the runs be the union of at most n_bands intervals of width <= max_width?"""
+    if max_width <= 0:
+        return not runs
+    return sum(-(-ln // max_width) for _, ln in runs) <= n_bands
+
+
+def test_specaugment_properties():
+    """SpecAugment(mF=2, F=27, mT=5, pS=0.05) (nnet/preprocessing.py:115-130, torchaudio mask_along_axis semantics): on an all-ones input the zeros
+    are exactly 2 batch-shared frequency bands of width < 27 (whole rows, every frame) plus, per sample, at most 5 time bands of width < int(0.05 len)
+    inside [0, len); nothing else changes; time bands differ between samples; the draw is a function of (seed, step)."""
+    import avec_amd
+    from avec_amd import ops, runtime as rt
+    mF, Fp, mT, pS = 2, 27, 5, 0.05
+    B, NM, F = 8, 80, 400
+    lens = torch.tensor([400, 400, 363, 250, 120, 57, 19, 400], device=dev())
+    seen_freq, seen_time = set(), 0
+    for trial in range(6):
+        avec_amd.manual_seed(777 + trial)
+        mel = torch.ones(B, NM, F, device=dev())
+        out = ops.spec_augment_(mel.clone(), lens, mF, Fp, mT, pS, 5)
+        again = ops.spec_augment_(mel.clone(), lens, mF, Fp, mT, pS, 5)
+        assert torch.equal(out, again)                                   # same (seed, step, site) -> same masks
+        assert ((out == 0) | (out == 1)).all()                           # masking only writes zeros
+        z = (out == 0).cpu()
+        # frequency bands: rows zeroed over ALL frames (also beyond the valid length), identical for every sample
+        row_masked = z.all(dim=2)
+        assert (row_masked == row_masked[0:1]).all()
+        fr = _runs(row_masked[0])
+        assert _coverable(fr, mF, Fp - 1), fr
+        seen_freq.add(tuple(map(tuple, fr)))
+        for b in range(B):
+            ln = int(lens[b])
+            free_rows = (~row_masked[b]).nonzero().flatten()
+            if free_rows.numel() == 0:
+                continue
+            sub = z[b, free_rows]                                        # rows without a frequency mask: zeros are time masks only
+            assert (sub == sub[0:1]).all()                               # a time mask covers every mel bin of its frames
+            tr = _runs(sub[0])
+            Tp = int(pS * ln)
+            assert all(s + l <= ln for s, l in tr), (b, tr, ln)          # inside the valid length
+            assert _coverable(tr, mT, Tp - 1), (b, tr, Tp)               # width = int(U * Tp) <= Tp - 1
+            seen_time += len(tr)
+        # different samples draw different time masks
+        t0 = z[0, (~row_masked[0]).nonzero().flatten()[0]]
+        t1 = z[1, (~row_masked[1]).nonzero().flatten()[0]]
+        t7 = z[7, (~row_masked[7]).nonzero().flatten()[0]]
+        assert not (torch.equal(t0, t1) and torch.equal(t0, t7))
+        # the step counter changes the draw
+        rt.advance_rng(dev())
+        nxt = ops.spec_augment_(mel.clone(), lens, mF, Fp, mT, pS, 5)
+        assert not torch.equal(out, nxt)
+    assert len(seen_freq) > 1 and seen_time > 20                         # masks do occur and vary with the seed
+    # lengths too short for a time mask (int(0.05 * 19) = 0): sample 6 has no time mask at all (checked by _coverable with width 0 above)
+
+
+def test_specaugment_module_is_train_only():
+    import nnet
+    sa = nnet.SpecAugment(mF=2, F=27, mT=5, pS=0.05)
+    x = torch.ones(2, 80, 100, device=dev())
+    lens = torch.tensor([100, 60], device=dev())
+    sa.eval()
+    assert torch.equal(sa(x.clone(), lens), x)
+    sa.train()
+    y = sa(x.clone(), lens)
+    assert (y == 0).any() or True          # (a draw of two zero-width bands is legal)
+    assert ((y == 0) | (y == 1)).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE config 5 shape: 15 s clips (240 000 samples -> 1501 mel frames, 376 video frames)
+# ----------------------------------------------------------------------------------------------
+def test_full_model_config5_shape_matches_oracle():
+    """AV model at the long-utterance shape (Ta = 240 000, Tv = 376, ragged second clip, 36 labels): the kernels that only long inputs select
+    (alpha-in-LDS CTC, 12-tile / K-V time-sharing MFMA attention, 250-patch audio stage) -- 7 losses against the oracle, fp32 mode 1e-3, bf16 5e-2;
+    output lengths bit-exact."""
+    import avec_amd
+    from oracle import avec_oracle as O
+    model, sd0 = probe.build_model()
+    torch.manual_seed(5)
+    B = 2
+    video = torch.randn(B, 376, 88, 88, 1)
+    audio = 0.1 * torch.randn(B, 240000)
+    vlen, alen = torch.tensor([376, 251]), torch.tensor([240000, 160000])
+    labels, llen = torch.randint(1, 256, (B, 36)), torch.tensor([36, 22])
+    with torch.no_grad():
+        ref = O.av_forward(sd0, video, vlen, audio, alen, train=True, stats_out={})
+        ref_losses = {k: float(v) for k, v in O.total_loss(ref, labels, llen, O.AV_LOSS_WEIGHTS).items()}
+    d = dev()
+    try:
+        for dtype, tol in (("f32", 1e-3), ("bf16", 5e-2)):
+            model.load_state_dict(sd0)
+            avec_amd.set_compute_dtype(dtype)
+            model.arena.zero_grad()
+            losses, _, _, _ = model.forward_model([video.to(d), vlen.to(d), audio.to(d), alen.to(d)], (labels.to(d), llen.to(d)), compute_metrics=False)
+            for k, v in ref_losses.items():
+                assert abs(float(losses[k]) - v) < tol * abs(v), (dtype, k, float(losses[k]), v)
+            losses["loss"].backward()
+            assert torch.isfinite(model.arena.grad).all(), dtype
+            if dtype == "f32":
+                out = model([video.to(d), vlen.to(d), audio.to(d), alen.to(d)])
+                for k in ref:
+                    assert out[k][1].tolist() == [int(x) for x in ref[k][1]], k
+                    assert list(out[k][0].shape) == list(ref[k][0].shape), k
+    finally:
+        avec_amd.set_compute_dtype("f32")
+
+
+# ----------------------------------------------------------------------------------------------
+# bench.py launches its own ranks
+# ----------------------------------------------------------------------------------------------
+def test_bench_self_spawns_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` (no torchrun) must start two ranks itself and print ONE JSON line from rank 0 (here: both ranks on cuda:0, gloo)."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--backend", "gloo", "--share-gpu",
+                        "--no-cpu-baseline", "--no-kernel-timing"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0 and out["scaling"] == "weak"
+
+
+# ----------------------------------------------------------------------------------------------
+# harness paths the advisor flagged as untested: stale shadows, checkpoint round trip, gradient accumulation, clipping
+# ----------------------------------------------------------------------------------------------
+def _ao_model(seed=0):
+    import nnet
+    torch.manual_seed(seed)
+    model = nnet.AudioEfficientConformerInterCTC(vocab_size=256, att_type="patch", interctc_blocks=[])
+    for x in model.modules():
+        if isinstance(x, torch.nn.Dropout):
+            x.p = 0.0
+        if hasattr(x, "drop_rate"):
+            x.drop_rate = 0.0
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
+    model = model.to(dev()).train()
+    model.encoder.spec_augment.eval()
+    return model
+
+
+def _ao_batch():
+    torch.manual_seed(3)
+    audio, alen = 0.1 * torch.randn(2, 16000), torch.tensor([16000, 12000])
+    labels, llen = torch.randint(1, 256, (2, 5)), torch.tensor([5, 3])
+    return [audio.to(dev()), alen.to(dev())], (labels.to(dev()), llen.to(dev()))
+
+
+def test_arena_shadows_follow_weight_edits():
+    """Weights changed after Model.to('cuda') by a SUB-MODULE load_state_dict (how the reference configs transplant the LRW front-end) or by an in-place
+    edit must reach the compute-dtype GEMM shadows (advisor finding: the arena only refreshed after Model.load_state_dict / Adam)."""
+    import avec_amd
+    model = _ao_model().eval()
+    inputs, _ = _ao_batch()
+    for dtype in ("f32", "bf16"):
+        avec_amd.set_compute_dtype(dtype)
+        tol = 1e-5 if dtype == "f32" else 2e-2
+        with torch.no_grad():
+            y0 = model(inputs)["outputs"][0].float().clone()
+            head = model.encoder.head
+            head.load_state_dict({k: 2.0 * v for k, v in head.state_dict().items()})           # sub-module load: logits double
+            y1 = model(inputs)["outputs"][0].float().clone()
+            assert (y1 - 2.0 * y0).abs().max() <= tol * y0.abs().max() * 2, dtype
+            head.weight.mul_(0.5)
+            head.bias.mul_(0.5)                                                               # in-place edit (version counters): back to y0
+            y2 = model(inputs)["outputs"][0].float().clone()
+            assert (y2 - y0).abs().max() <= tol * y0.abs().max(), dtype
+    avec_amd.set_compute_dtype("f32")
+
+
+def test_grad_accumulation_clipping_and_checkpoint_roundtrip(tmp_path):
+    import avec_amd
+    avec_amd.set_compute_dtype("f32")
+    inputs, targets = _ao_batch()
+    # (1) two micro-steps of the same batch with accumulated_steps=2 == one plain step (loss / 2 summed twice; dropout off)
+    a, b = _ao_model(), _ao_model()
+    a.train_step(inputs, targets, precision=torch.float32)
+    _, _, acc = b.train_step(inputs, targets, precision=torch.float32, accumulated_steps=2, acc_step=0)
+    assert acc == 1 and int(b.model_step) == 0 and b.arena.grad.abs().max() > 0          # no optimizer step yet, gradients kept
+    _, _, acc = b.train_step(inputs, targets, precision=torch.float32, accumulated_steps=2, acc_step=acc)
+    assert acc == 0 and int(b.model_step) == 1
+    d = (a.arena.master - b.arena.master).abs().max().item()
+    step = (a.arena.master - _ao_model().arena.master).abs().max().item()
+    assert d <= 2e-3 * step, (d, step)
+    # (2) global-norm clipping of the flat arena
+    g = torch.randn_like(a.arena.grad)
+    a.arena.grad.copy_(g)
+    n = a.clip_gradients(0.5)
+    assert abs(float(n) - float(g.norm())) < 1e-3 * float(g.norm())
+    assert abs(float(a.arena.grad.norm()) - 0.5) < 1e-3
+    a.arena.grad.copy_(1e-3 * g / g.norm())
+    a.clip_gradients(0.5)
+    assert torch.allclose(a.arena.grad, 1e-3 * g / g.norm())                              # below the threshold: untouched
+    a.arena.zero_grad()
+    # (3) checkpoint round trip: parameters, Adam moments and the step counter; the next step continues identically
+    path = str(tmp_path / "ckpt.ckpt")
+    b.save(path)
+    c = _ao_model(seed=9)
+    c.load(path)
+    assert int(c.model_step) == 1 and torch.equal(c.arena.master, b.arena.master)
+    assert torch.equal(c.optimizer._flat["exp_avg"], b.optimizer._flat["exp_avg"]) and torch.equal(c.optimizer._flat["exp_avg_sq"], b.optimizer._flat["exp_avg_sq"])
+    b.train_step(inputs, targets, precision=torch.float32)
+    c.train_step(inputs, targets, precision=torch.float32)
+    assert int(c.model_step) == 2 and (c.arena.master - b.arena.master).abs().max().item() <= 1e-6
+    # without the optimizer state the schedule restarts (nnet/model.py:527-536)
+    e = _ao_model(seed=9)
+    e.load(path, load_optimizer=False)
+    assert int(e.model_step) == 0 and e.optimizer._flat["exp_avg"].abs().max() == 0
+    sd_b = torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"]
+    for k, v in e.state_dict().items():
+        if v.is_floating_point():
+            assert torch.equal(v.cpu(), sd_b[k].cpu()), k

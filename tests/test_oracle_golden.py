@@ -221,3 +221,15 @@ def test_vo_interctc_oracle_matches_reference_golden():
         assert abs(l - g["losses"]["loss_" + k]) < 1e-4 * g["losses"]["loss_" + k]
         total += w * l
     assert abs(total - g["losses"]["loss"]) < 1e-4 * g["losses"]["loss"]
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/nnet"), reason="needs the reference tree (build container only)")
+def test_oracle_fullsize_vs_reference_itself():
+    """The pin of the oracle at FULL size (61.7 M parameters): tests/golden/check_oracle_fullsize.py imports the reference, runs both on the same
+    inputs and compares 7 losses (1e-5), all 965 gradient tensors (fp64-calibrated, structurally-zero ones bounded) and the BatchNorm running statistics."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "check_oracle_fullsize.py")], cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "ORACLE FULL-SIZE CHECK: PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
