@@ -674,7 +674,7 @@ __device__ __forceinline__ chunk16 tr_read8(const char* p0, const char* p1) {
 template <int BC> __device__ __forceinline__ int tr_swz(int row) { return BC == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
 template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false, int KT = 64>      // Q32: the im2col source has < 2^31 elements: 32-bit offsets; KT: reduction rows per tile
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
+__device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const int by, const int bz) {
   typedef bf16 T;
   constexpr int CPI = BI / 8, CPJ = BJ / 8;                    // 16-byte chunks per LDS row
   constexpr int RI = 256 / CPI, RJ = 256 / CPJ;                // rows covered by one DMA pass of the workgroup
@@ -685,8 +685,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
-  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-  const int zb = blockIdx.z / g.split, zs = blockIdx.z - zb * g.split;
+  const int i0 = bx * BI, j0 = by * BJ;
+  const int zb = bz / g.split, zs = bz - zb * g.split;
   const long long bo = zb / g.nb_inner, bi = zb - bo * g.nb_inner;
   const T* Pp = (const T*)g.P + bo * g.sPo + bi * g.sPi;
   const T* Qp = (const T*)g.q.ptr + bo * g.sQo + bi * g.sQi;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
   // optional column sums of P (= bias gradient of the layer whose weight gradient this is), by the workgroups of the first J tile: lane =
   // (physical chunk pc, row class r4 = m & 3, row subgroup rs); rows of one class share the swizzle, so a lane always sees the same 8 columns
   constexpr int CS_RF = 64 / (CPI * 4), CS_N = (KT / 4) / (4 * CS_RF);
-  const bool do_cs = g.pcs != nullptr && blockIdx.y == 0;
+  const bool do_cs = g.pcs != nullptr && by == 0;
   const int cs_pc = lane % CPI, cs_r4 = (lane / CPI) & 3, cs_rs = lane / (CPI * 4);
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int LPT = NLI + NLJ;
@@ -821,6 +821,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
         if (row < g.I) atomicAdd(Op + (long long)row * g.ldo + col, acc[i][j][r]);
       }
   }
+}
+
+template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false, int KT = 64>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) { tn_tr_body<BI, BJ, MODE, STAGES, Q32, KT>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// ---- grouped launch: up to AVEC_TN_GROUP_MAX independent plain bf16 products (the weight gradients of one or more conformer blocks) as ONE grid.
+// The items travel BY VALUE in the kernel argument block (captured by a hipGraph node like any other argument; no device-side table to keep alive);
+// workgroup w belongs to the item whose [first, first + count) range contains it.
+struct TnItem { const void* P; const void* Q; float* O; float* pcs; int ldp, ldq, ldo, M, I, J, Iq, Jq, m_per_block, split, gx, gy, rows_out, rows_in, step, first; };
+struct TnGroup { TnItem it[AVEC_TN_GROUP_MAX]; int n, total; };
+template <int BT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(TnGroup grp) {
+  const int w = blockIdx.x;
+  int lo = 0, hi = grp.n - 1;                   // last item with first <= w
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (grp.it[mid].first <= w) lo = mid; else hi = mid - 1; }
+  const TnItem& t = grp.it[lo];
+  TnArgs g; g.P = t.P; g.ldp = t.ldp; g.q.ptr = t.Q; g.q.ld = t.ldq; g.q.rows_out = t.rows_out; g.q.rows_in = t.rows_in; g.q.step = t.step;
+  g.q.H = g.q.W = g.q.C = g.q.KH = g.q.KW = g.q.stride = g.q.pad = g.q.OH = g.q.OW = 0;
+  g.O = t.O; g.Oact = nullptr; g.ldo = t.ldo; g.M = t.M; g.I = t.I; g.J = t.J; g.Iq = t.Iq; g.Jq = t.Jq; g.m_per_block = t.m_per_block; g.pcs = t.pcs;
+  g.split = t.split; g.nb_inner = 1; g.sPo = g.sPi = g.sQo = g.sQi = g.sOo = g.sOi = 0;
+  int l = w - t.first; const int bx = l % t.gx; l /= t.gx; const int by = l % t.gy; const int bz = l / t.gy;
+  tn_tr_body<BT, BT, MODE_PLAIN, 2, false, 32>(g, bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1035,4 +1057,57 @@ extern "C" int avec_gemm_tn_batched_store(int dtype, const void* P, long long ld
   avec_rows_t rows = {}; rows.ld = ldq;
   AVEC_CHECK_ARG(strides6 && O_act, "gemm_tn_batched_store: null pointer");
   return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, nullptr, O_act, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
+}
+
+// ---- grouped weight gradients -------------------------------------------------------------------------------------------------------------
+static bool tn_item_ok(int dtype, const avec_tn_item_t& t) {
+  if (dtype != AVEC_BF16 || !t.P || !t.Q || !t.O || t.M <= 0 || t.I <= 0 || t.J <= 0) return false;
+  const int Iq = (t.ldp >= (t.I + 7) / 8 * 8) ? (t.I + 7) / 8 * 8 : t.I, Jq = (t.ldq >= (t.J + 7) / 8 * 8) ? (t.J + 7) / 8 * 8 : t.J;
+  if (!aligned16(t.P) || !aligned16(t.Q) || Iq % 8 || Jq % 8 || t.ldp % 8 || t.ldq % 8) return false;
+  if (t.p_colsum && (t.I % 4 || t.ldp % 4)) return false;
+  return t.M < (1ll << 31) && t.ldp < (1ll << 31) && t.ldq < (1ll << 31) && t.ldo < (1ll << 31);
+}
+extern "C" int avec_gemm_tn_grouped_ok(int dtype, const avec_tn_item_t* item) { return item && tn_item_ok(dtype, *item) ? 1 : 0; }
+
+extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int n, hipStream_t stream) {
+  AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_TN_GROUP_MAX, "gemm_tn_grouped: need 1..%d items (got %d)", AVEC_TN_GROUP_MAX, n);
+  for (int k = 0; k < n; ++k) AVEC_CHECK_ARG(tn_item_ok(dtype, items[k]), "gemm_tn_grouped: item %d is not eligible (bf16, 16-byte aligned operands, row strides %% 8 == 0)", k);
+  // tile size: 128x128 tiles read each operand byte half as often as 64x64 (these products are bound by L2 traffic), but a group must still cover the
+  // chip: take the big tile when the group has enough of them
+  static const int bt_env = getenv("AVEC_TNG_TILE") ? atoi(getenv("AVEC_TNG_TILE")) : 0;
+  long long t128 = 0;
+  for (int k = 0; k < n; ++k) t128 += (long long)((items[k].I + 127) / 128) * ((items[k].J + 127) / 128);
+  const int BT = bt_env == 64 || bt_env == 128 ? bt_env : (t128 >= 96 ? 128 : 64);
+  // common reduction-slice length: the largest multiple of 64 rows (>= 256) that still yields ~wg_target workgroups over the whole group
+  static const long long wg_env = getenv("AVEC_TNG_WGS") ? atoll(getenv("AVEC_TNG_WGS")) : 0;
+  const long long wg_target = wg_env > 0 ? wg_env : 1536;
+  long long per = 256;
+  for (long long cand = 8192; cand >= 256; cand -= 64) {
+    long long wgs = 0;
+    for (int k = 0; k < n; ++k) wgs += (long long)((items[k].I + BT - 1) / BT) * ((items[k].J + BT - 1) / BT) * ((items[k].M + cand - 1) / cand);
+    if (wgs >= wg_target) { per = cand; break; }
+  }
+  TnGroup grp; grp.n = n;
+  int first = 0;
+  for (int k = 0; k < n; ++k) {
+    const avec_tn_item_t& s = items[k]; TnItem& t = grp.it[k];
+    t.P = s.P; t.Q = s.Q; t.O = s.O; t.pcs = s.p_colsum; t.ldp = (int)s.ldp; t.ldq = (int)s.ldq; t.ldo = (int)s.ldo; t.M = (int)s.M; t.I = s.I; t.J = s.J;
+    t.Iq = (s.ldp >= (s.I + 7) / 8 * 8) ? (s.I + 7) / 8 * 8 : s.I; t.Jq = (s.ldq >= (s.J + 7) / 8 * 8) ? (s.J + 7) / 8 * 8 : s.J;
+    t.rows_out = s.q_rows_out > 0 ? s.q_rows_out : 1; t.rows_in = s.q_rows_in > 0 ? s.q_rows_in : 1; t.step = s.q_step;
+    long long mp = per; if (mp > s.M) mp = (s.M + 63) / 64 * 64;
+    t.m_per_block = (int)mp; t.split = (int)((s.M + mp - 1) / mp);
+    t.gx = (s.I + BT - 1) / BT; t.gy = (s.J + BT - 1) / BT; t.first = first;
+    first += t.gx * t.gy * t.split;
+  }
+  grp.total = first;
+  const size_t lds = (size_t)2 * 32 * (BT + BT) * 2;
+  if (BT == 128) {
+    if (int r = want_lds(gemm_tn_tr_grouped_kernel<128>, lds)) return r;
+    hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel<128>, dim3((unsigned)first), dim3(256), lds, stream, grp);
+  } else {
+    if (int r = want_lds(gemm_tn_tr_grouped_kernel<64>, lds)) return r;
+    hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel<64>, dim3((unsigned)first), dim3(256), lds, stream, grp);
+  }
+  AVEC_LAUNCH_CHECK();
+  return 0;
 }

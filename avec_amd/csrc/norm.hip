@@ -149,10 +149,105 @@ extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma,
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+// dx only (dgamma / dbeta are produced later by avec_layernorm_param_grads_grouped): one wave per row, every row in flight at once -- no serial walk over
+// rows, no column reduction on the dependent chain of the backward pass.
+template <typename TG, int NG>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
+                                                          const float* __restrict__ dres, long long M, int D) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float mu = mean[row], rs = rstd[row];
+  float d[NG][4], v[NG][4], o[NG][4], gg[NG][4];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < D) {
+      ld4<TG>(dy + row * D + c, d[i]); ld4<float>(x + row * D + c, v[i]); ld4<float>(g + c, gg[i]);
+      if (dres) ld4<float>(dres + row * D + c, o[i]); else { o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[i][e] = 0.f; v[i][e] = mu; o[i][e] = 0.f; gg[i][e] = 0.f; }
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float xh = (v[i][e] - mu) * rs, t = d[i][e] * gg[i][e]; v[i][e] = xh; s1 += t; s2 += t * xh; }
+  s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int c = lane * 4 + i * 256; if (c >= D) break;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[i][e] += rs * (d[i][e] * gg[i][e] - s1 - v[i][e] * s2);
+    st4<float>(dx + row * D + c, o[i]);
+  }
+}
+
+// ---- grouped LayerNorm parameter gradients: dgamma_k[c] += sum_m dy_k[m][c] * xhat_k[m][c], dbeta_k[c] += sum_m dy_k[m][c] for up to AVEC_LN_GROUP_MAX layers in ONE launch.
+// They only feed the optimizer, so the caller queues them (with the weight-gradient GEMMs) instead of paying a column reduction inside every LayerNorm backward.
+// Workgroup = 128 rows of one layer; thread = 4 consecutive columns of every R-th row; LDS reduction over the row lanes, then one atomic per column per workgroup.
+struct LnItem { const void* dy; const float* x; const float* mean; const float* rstd; float* dg; float* db; int M, D, dy_f32, first; };
+struct LnGroup { LnItem it[AVEC_LN_GROUP_MAX]; int n; };
+static constexpr int LNG_ROWS = 128;
+__global__ __launch_bounds__(256) void ln_param_grads_grouped_kernel(LnGroup grp) {
+  __shared__ float red[2][256][4];
+  const int w = blockIdx.x;
+  int lo = 0, hi = grp.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (grp.it[mid].first <= w) lo = mid; else hi = mid - 1; }
+  const LnItem& t = grp.it[lo];
+  const int D = t.D, L = D >> 2, R = 256 / L;                 // L lanes of 4 columns per row, R rows per pass (D <= 1024)
+  const int r = threadIdx.x / L, l = threadIdx.x - r * L;
+  const int m0 = (w - t.first) * LNG_ROWS; int m1 = m0 + LNG_ROWS; if (m1 > t.M) m1 = t.M;
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < R) {
+    for (int m = m0 + r; m < m1; m += R) {
+      float d[4], v[4];
+      if (t.dy_f32) ld4<float>((const float*)t.dy + (long long)m * D + l * 4, d); else ld4<bf16>((const bf16*)t.dy + (long long)m * D + l * 4, d);
+      ld4<float>(t.x + (long long)m * D + l * 4, v);
+      const float mu = t.mean[m], rs = t.rstd[m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pg[e] += d[e] * (v[e] - mu) * rs; pb[e] += d[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = pg[e]; red[1][threadIdx.x][e] = pb[e]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * D; o += 256) {
+    const int which = o >= D, c = o - which * D; float s = 0.f;
+    for (int rr = 0; rr < R; ++rr) s += red[which][rr * L + (c >> 2)][c & 3];
+    atomicAdd((which ? t.db : t.dg) + c, s);
+  }
+}
+extern "C" int avec_layernorm_param_grads_grouped(int dtype, const avec_ln_item_t* items, int n, hipStream_t st) {
+  AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_LN_GROUP_MAX, "layernorm_param_grads_grouped: need 1..%d items (got %d)", AVEC_LN_GROUP_MAX, n);
+  LnGroup grp; grp.n = n; int first = 0;
+  for (int k = 0; k < n; ++k) {
+    const avec_ln_item_t& s = items[k];
+    AVEC_CHECK_ARG(s.dy && s.x && s.mean && s.rstd && s.dgamma && s.dbeta && s.M > 0 && s.M < (1ll << 31) && s.D >= 4 && s.D % 4 == 0 && s.D <= 1024,
+                   "layernorm_param_grads_grouped: item %d: null pointer or D=%d not a multiple of 4 in [4, 1024]", k, s.D);
+    LnItem& t = grp.it[k];
+    t.dy = s.dy; t.x = s.x; t.mean = s.mean; t.rstd = s.rstd; t.dg = s.dgamma; t.db = s.dbeta; t.M = (int)s.M; t.D = s.D;
+    t.dy_f32 = (s.dy_f32 || dtype == AVEC_F32) ? 1 : 0; t.first = first;
+    first += (int)((s.M + LNG_ROWS - 1) / LNG_ROWS);
+  }
+  hipLaunchKernelGGL(ln_param_grads_grouped_kernel, dim3((unsigned)first), dim3(256), 0, st, grp);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
                                   float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
-  AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && (!dgamma == !dbeta), "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
+  if (!dgamma) {        // input gradient only (parameter gradients deferred to avec_layernorm_param_grads_grouped)
+    const dim3 grid((unsigned)((M + 3) / 4)); const bool f32in = dy_f32 || dtype == AVEC_F32;
+#define AVEC_LN_ROWS(TG, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<TG, NG>), grid, dim3(256), 0, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, M, D)
+    if (D <= 512) { if (f32in) AVEC_LN_ROWS(float, 2); else AVEC_LN_ROWS(bf16, 2); }
+    else { if (f32in) AVEC_LN_ROWS(float, 6); else AVEC_LN_ROWS(bf16, 6); }
+#undef AVEC_LN_ROWS
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   long long nb = (M + 15) / 16; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
   ColWs ws = avec_reduce_ws((size_t)nb * 2 * D, st);
   if (!ws.partial && nb > 128) nb = 128;

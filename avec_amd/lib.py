@@ -44,6 +44,23 @@ class Attn(ctypes.Structure):
                 ("B", ctypes.c_int), ("H", ctypes.c_int), ("T", ctypes.c_int), ("d", ctypes.c_int), ("scale", ctypes.c_float)]
 
 
+class TnItem(ctypes.Structure):
+    """avec_tn_item_t"""
+    _fields_ = [("P", ctypes.c_void_p), ("Q", ctypes.c_void_p), ("O", ctypes.c_void_p), ("p_colsum", ctypes.c_void_p),
+                ("ldp", ctypes.c_longlong), ("ldq", ctypes.c_longlong), ("ldo", ctypes.c_longlong), ("M", ctypes.c_longlong),
+                ("I", ctypes.c_int), ("J", ctypes.c_int), ("q_rows_out", ctypes.c_int), ("q_rows_in", ctypes.c_int), ("q_step", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+class LnItem(ctypes.Structure):
+    """avec_ln_item_t"""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("dgamma", ctypes.c_void_p),
+                ("dbeta", ctypes.c_void_p), ("M", ctypes.c_longlong), ("D", ctypes.c_int), ("dy_f32", ctypes.c_int)]
+
+
+TN_GROUP_MAX, LN_GROUP_MAX = 32, 40
+
+
 def _ctype(decl):
     decl = decl.strip()
     if "*" in decl or decl.startswith("hipStream_t"):

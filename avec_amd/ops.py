@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import runtime as rt
-from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, Attn, Epilogue, Rows, lib
+from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnItem, lib
 
 _byref = ctypes.byref
 
@@ -122,11 +122,97 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     return out
 
 
+# ---- deferred parameter gradients ------------------------------------------------------------------------------------------------------------
+# Weight gradients (dW = dY^T X), bias gradients and LayerNorm gamma/beta gradients only feed the optimizer: nothing in the backward chain waits for
+# them.  Launched one by one they are ~45 % of a conformer block's backward launches, each latency-bound (a few hundred workgroups, 12-21 us).  Inside a
+# backward pass they are therefore QUEUED per stream (the operand tensors stay referenced) and submitted as grouped launches (avec_gemm_tn_grouped,
+# avec_layernorm_param_grads_grouped: one grid over the tiles of up to 32 / 40 products) when a queue fills, at the explicit flush points (end of the audio
+# branch, before an early gradient all-reduce) and by a final autograd callback when the backward pass ends.  AVEC_DEFER_WGRAD=0 restores immediate launches.
+DEFER_WGRAD = os.environ.get("AVEC_DEFER_WGRAD", "1") != "0"
+_TN_FLUSH_AT = int(os.environ.get("AVEC_DEFER_TN_MAX", str(TN_GROUP_MAX)))
+_DEFER = {"queues": {}, "task": -1}
+
+
+class _PendingGrads:
+    __slots__ = ("stream", "tn", "ln", "keep", "flops")
+
+    def __init__(self, stream):
+        self.stream, self.tn, self.ln, self.keep, self.flops = stream, [], [], [], 0.0
+
+
+def _in_backward():
+    return DEFER_WGRAD and torch._C._current_graph_task_id() != -1
+
+
+def _pending():
+    st = torch.cuda.current_stream()
+    q = _DEFER["queues"].get(st.cuda_stream)
+    if q is None:
+        q = _DEFER["queues"][st.cuda_stream] = _PendingGrads(st)
+    task = torch._C._current_graph_task_id()
+    if _DEFER["task"] != task:                    # first queued item of this backward pass: flush whatever is left when the pass ends
+        _DEFER["task"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end)
+    return q
+
+
+def _launch_pending(q, part=None):
+    """submit queue `q` on the CURRENT stream (its own stream during the pass; the caller's stream, which has joined every branch, at the end of it)"""
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream != q.stream.cuda_stream:
+        for t in q.keep:
+            t.record_stream(cur)
+    if q.tn and part in (None, "tn"):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+        for i in range(0, len(q.tn), TN_GROUP_MAX):
+            chunk = q.tn[i:i + TN_GROUP_MAX]
+            lib.gemm_tn_grouped(BF16, (TnItem * len(chunk))(*chunk), len(chunk), rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (1, ROWS_PLAIN), q.flops)
+        q.tn, q.flops = [], 0.0
+    if q.ln and part in (None, "ln"):
+        for i in range(0, len(q.ln), LN_GROUP_MAX):
+            chunk = q.ln[i:i + LN_GROUP_MAX]
+            lib.layernorm_param_grads_grouped(rt.dt(), (LnItem * len(chunk))(*chunk), len(chunk), rt.stream())
+        q.ln = []
+    if not q.tn and not q.ln:
+        q.keep = []
+
+
+def flush_param_grads(all_streams=False):
+    """submit the queued parameter-gradient work of the current stream (all_streams: of every stream, on the current one)"""
+    if all_streams:
+        for q in list(_DEFER["queues"].values()):
+            _launch_pending(q)
+        return
+    q = _DEFER["queues"].get(torch.cuda.current_stream().cuda_stream)
+    if q is not None:
+        _launch_pending(q)
+
+
+def _flush_at_end():
+    _DEFER["task"] = -1
+    flush_param_grads(all_streams=True)
+
+
 def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32=False, ldo=None, dtype=None, p_colsum=None, side=False):
     """O[I][J] (fp32) += P[M][I]^T Q[M][J];  optionally p_colsum[I] += column sums of P (the bias gradient, fused into the same launch).
-    side=True (weight gradients): launched on the side stream (runtime.wgrad_fork), joined at the end of the backward pass."""
+    side=True (weight gradients): may be queued for a grouped launch (see above) / launched on the side stream (runtime.wgrad_fork)."""
     if q_rows is None:
         q_rows = rows_plain(J)
+    if side and q_mode == ROWS_PLAIN and not q_f32 and dtype is None and rt.compute_dtype() == "bf16" and _in_backward():
+        it = TnItem()
+        it.P, it.Q, it.O, it.p_colsum = P.data_ptr(), Q.data_ptr(), O.data_ptr(), _p(p_colsum)
+        it.ldp, it.ldq, it.ldo, it.M, it.I, it.J = (I if ldp is None else ldp), q_rows.ld, (J if ldo is None else ldo), M, I, J
+        it.q_rows_out, it.q_rows_in, it.q_step = q_rows.rows_out, q_rows.rows_in, q_rows.step
+        if lib.raw("avec_gemm_tn_grouped_ok")(BF16, _byref(it)):
+            q = _pending()
+            q.tn.append(it)
+            q.keep += [P, Q]
+            q.flops += 2.0 * M * I * J
+            if len(q.tn) >= _TN_FLUSH_AT:
+                _launch_pending(q, "tn")
+            return
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     st = rt.stream()
     if side and not KERNEL_TIMER.enabled:
@@ -149,8 +235,21 @@ def layernorm_fwd(x, w, b, M, D, out_f32, eps):
 
 def layernorm_bwd(dy, dy_f32, x, mean, rstd, w, b, M, D, dres=None):
     dx = empty((M, D), torch.float32, x)
+    gw, gb = grad_of(w), grad_of(b)
+    if D <= 1024 and _in_backward():          # dx now (one wave per row); d(gamma), d(beta) with the other queued parameter gradients
+        lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
+                          None, None, M, D, rt.stream())
+        it = LnItem()
+        it.dy, it.x, it.mean, it.rstd, it.dgamma, it.dbeta = dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        it.M, it.D, it.dy_f32 = M, D, int(dy_f32)
+        q = _pending()
+        q.ln.append(it)
+        q.keep += [dy, x, mean, rstd]
+        if len(q.ln) >= LN_GROUP_MAX:
+            _launch_pending(q, "ln")
+        return dx
     lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
-                      grad_of(w).data_ptr(), grad_of(b).data_ptr(), M, D, rt.stream())
+                      gw.data_ptr(), gb.data_ptr(), M, D, rt.stream())
     return dx
 
 
@@ -1057,6 +1156,7 @@ class AudioStemFn(torch.autograd.Function):
     def backward(ctx, da):
         mel, y, st, cp, count, conv, bn, B, NM, F, C, training = ctx.saved
         assert training, "AudioStem backward is implemented for training-mode BatchNorm"
+        flush_param_grads()                                   # last node of the audio branch: its queued parameter gradients go out on this (the branch's) stream
         da = da.to(rt.act_dtype()).contiguous()
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=mel.device)
         base = (da.data_ptr(), y.data_ptr(), mel.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(count))

@@ -489,6 +489,8 @@ class ParamArena:
         if not getattr(self, "_early_armed", False) or hi <= lo:
             return
         import torch.distributed as dist
+        from . import ops
+        ops.flush_param_grads()                   # queued weight / LayerNorm gradients of this stream belong to the range: they must be in the arena first
         self._early.append((lo, hi, dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=collective_group())))
 
     def arm_early_all_reduce(self, flag):

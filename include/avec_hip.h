@@ -86,6 +86,20 @@ int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const a
  * (nn.Linear backward: grad_bias = grad_output.sum(0)) */
 int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,
                       float* O, long long ldo, float* p_colsum, long long M, int I, int J, hipStream_t stream);
+/* Grouped weight gradients: up to AVEC_TN_GROUP_MAX independent products O_k[I_k][J_k] += P_k^T Q_k (+ optional column sums of P_k = bias gradients) as ONE launch --
+ * the ~10 weight-gradient products of a ConformerBlock backward (nnet/blocks.py:289-306: two FFN modules, attention projections, two pointwise convs) only feed the
+ * optimizer, so the caller may queue them and submit them together; one grid over all their tiles fills the chip where each product alone is latency-bound.
+ * bf16 only, operands 16-byte aligned with row strides that are multiples of 8 elements (avec_gemm_tn_grouped_ok tells; others go through avec_gemm_tn_bias). */
+#define AVEC_TN_GROUP_MAX 32
+typedef struct avec_tn_item {
+  const void* P; const void* Q; float* O; float* p_colsum;
+  long long ldp, ldq, ldo, M;
+  int I, J;
+  int q_rows_out, q_rows_in, q_step;   /* strided row remap of Q as in avec_rows_t (q_step <= 1: identity) */
+  int reserved;
+} avec_tn_item_t;
+int avec_gemm_tn_grouped_ok(int dtype, const avec_tn_item_t* item);
+int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int n, hipStream_t stream);
 int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                          int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 /* the same products STORED in the activation dtype (one workgroup per tile reduces over all M rows: no split, no atomics, no zero-filled fp32 staging):
@@ -100,6 +114,14 @@ int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const floa
                        float* mean, float* rstd, long long M, int D, float eps, hipStream_t stream);
 int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t stream);
+/* avec_layernorm_bwd with dgamma == dbeta == NULL computes dx only (one wave per row); the parameter gradients of up to AVEC_LN_GROUP_MAX such layers are
+ * then produced by ONE launch: dgamma_k[c] += sum_m dy_k[m][c] * xhat_k[m][c], dbeta_k[c] += sum_m dy_k[m][c]  (native_layer_norm_backward's weight / bias terms). */
+#define AVEC_LN_GROUP_MAX 40
+typedef struct avec_ln_item {
+  const void* dy; const float* x; const float* mean; const float* rstd; float* dgamma; float* dbeta;
+  long long M; int D; int dy_f32;      /* dy: fp32 when dy_f32 (or dtype == AVEC_F32), else act */
+} avec_ln_item_t;
+int avec_layernorm_param_grads_grouped(int dtype, const avec_ln_item_t* items, int n, hipStream_t stream);
 /* backward of out = res + alpha*Dropout(acc + bias): dacc (act) and dbias; nnet/modules.py:286-288 + nnet/blocks.py:292-301 */
 int avec_grad_prep(int dtype, const float* dout, long long ld, void* dacc, float alpha, float drop_p, const unsigned long long* rng,
                    unsigned rng_stream, float* dbias, long long M, int N, hipStream_t stream);

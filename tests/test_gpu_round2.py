@@ -47,7 +47,7 @@ def av_oracle(tmp_path_factory):
     out = O.av_forward(sd, video.double(), vlen, audio.double(), alen, train=True, stats_out={})
     ls = O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)
     ls["loss"].backward()
-    g64 = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad}
+    g64 = {k: v.grad.clone() for k, v in sd.items() if v.requires_grad and v.grad is not None}
     path = str(tmp_path_factory.mktemp("oracle") / "g64.pt")
     torch.save(g64, path)
     return model, g64, {k: float(v) for k, v in ls.items()}, path
@@ -315,3 +315,94 @@ def test_grad_accumulation_clipping_and_checkpoint_roundtrip(tmp_path):
     for k, v in e.state_dict().items():
         if v.is_floating_point():
             assert torch.equal(v.cpu(), sd_b[k].cpu()), k
+
+
+# ----------------------------------------------------------------------------------------------
+# grouped parameter-gradient launches
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", ["64", "128"])
+def test_gemm_tn_grouped_matches_torch(tile, monkeypatch):
+    """avec_gemm_tn_grouped: a mixed bag of weight-gradient products (FFN / QKV slice with ldp > I / strided-row residual conv / bias sums) in one launch
+    against fp64 torch; accumulates into O (O starts non-zero)."""
+    import ctypes
+    from avec_amd.lib import BF16, TnItem, lib
+    from avec_amd import runtime as rt
+    torch.manual_seed(0)
+    d = dev()
+    shapes = [(3200, 1024, 256, None, False), (3200, 256, 1024, None, True), (1600, 360, 360, 1080, True), (1600, 1440, 360, None, True),
+              (333, 64, 72, None, False), (800, 360, 256, None, True, 2), (70, 256, 256, None, True)]
+    items, refs, outs, keep = [], [], [], []
+    for sh in shapes:
+        M, I, J, ldp, bias = sh[:5]
+        step = sh[5] if len(sh) > 5 else 0
+        ldp_ = ldp or I
+        P = torch.randn(M, ldp_, device=d).to(torch.bfloat16)
+        Mq = M * step if step else M
+        Q = torch.randn(Mq, J, device=d).to(torch.bfloat16)
+        O = torch.randn(I, J, device=d)
+        bsum = torch.randn(I, device=d) if bias else None
+        Pv = P[:, ldp_ - I:] if ldp else P                        # a column slice (e.g. the V third of dQ|dK|dV)
+        Qv = Q[::step] if step else Q
+        ref = O.double() + Pv.double().t() @ Qv.double()
+        refb = (bsum.double() + Pv.double().sum(0)) if bias else None
+        it = TnItem()
+        it.P, it.Q, it.O, it.p_colsum = Pv.data_ptr(), Q.data_ptr(), O.data_ptr(), (bsum.data_ptr() if bias else None)
+        it.ldp, it.ldq, it.ldo, it.M, it.I, it.J = ldp_, J, J, M, I, J
+        it.q_rows_out, it.q_rows_in, it.q_step = (M, Mq, step) if step else (1, 1, 0)
+        assert lib.raw("avec_gemm_tn_grouped_ok")(BF16, ctypes.byref(it)) == 1
+        items.append(it); refs.append((ref, refb)); outs.append((O, bsum)); keep += [P, Q]
+    os.environ["AVEC_TNG_TILE"] = tile          # read once per process: the first parametrisation fixes it; both values are exercised across the two subprocess-free runs below
+    lib.gemm_tn_grouped(BF16, (TnItem * len(items))(*items), len(items), rt.stream())
+    torch.cuda.synchronize()
+    for (ref, refb), (O, bsum), sh in zip(refs, outs, shapes):
+        assert ((O.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3, sh
+        if refb is not None:
+            assert ((bsum.double() - refb).abs().max() / refb.abs().max()).item() < 2e-3, sh
+    # an unaligned operand (row stride 180 elements) is not eligible
+    bad = TnItem()
+    P = torch.randn(64, 180, device=d).to(torch.bfloat16)
+    bad.P, bad.Q, bad.O = P.data_ptr(), P.data_ptr(), outs[0][0].data_ptr()
+    bad.ldp, bad.ldq, bad.ldo, bad.M, bad.I, bad.J = 180, 180, 180, 64, 180, 180
+    assert lib.raw("avec_gemm_tn_grouped_ok")(BF16, ctypes.byref(bad)) == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_layernorm_rows_and_grouped_param_grads(dtype):
+    """dx-only LayerNorm backward (one wave per row) + avec_layernorm_param_grads_grouped against torch autograd for the conformer widths"""
+    import avec_amd
+    from avec_amd.lib import LnItem, lib
+    from avec_amd import runtime as rt
+    avec_amd.set_compute_dtype(dtype)
+    d = dev()
+    torch.manual_seed(1)
+    items, checks, keep = [], [], []
+    for M, D, with_res in [(3200, 256, True), (1600, 360, False), (6400, 180, True), (37, 1024, True), (130, 64, False)]:
+        x = torch.randn(M, D, device=d) * 2 + 0.3
+        g, b = torch.randn(D, device=d), torch.randn(D, device=d)
+        dy32 = torch.randn(M, D, device=d)
+        dy = dy32.to(rt.act_dtype())
+        dres = torch.randn(M, D, device=d) if with_res else None
+        xr = x.double().requires_grad_(True); gr = g.double().requires_grad_(True); br = b.double().requires_grad_(True)
+        y = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+        y.backward(dy.double())
+        mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+        mean_f, rstd_f = mean.float(), (var + 1e-6).rsqrt().float()
+        dx = torch.empty(M, D, device=d)
+        lib.layernorm_bwd(rt.dt(), dy.data_ptr(), 0, x.data_ptr(), mean_f.data_ptr(), rstd_f.data_ptr(), g.data_ptr(), dx.data_ptr(),
+                          dres.data_ptr() if with_res else None, None, None, M, D, rt.stream())
+        ref_dx = xr.grad + (dres.double() if with_res else 0)
+        tol = 1e-4 if dtype == "f32" else 1e-4          # dy is the same rounded tensor on both sides
+        assert ((dx.double() - ref_dx).abs().max() / ref_dx.abs().max()).item() < tol, (M, D)
+        dg, db = torch.randn(D, device=d), torch.randn(D, device=d)
+        it = LnItem()
+        it.dy, it.x, it.mean, it.rstd, it.dgamma, it.dbeta = dy.data_ptr(), x.data_ptr(), mean_f.data_ptr(), rstd_f.data_ptr(), dg.data_ptr(), db.data_ptr()
+        it.M, it.D, it.dy_f32 = M, D, 0
+        items.append(it)
+        checks.append((dg, db, dg.double() + gr.grad, db.double() + br.grad, (M, D)))
+        keep += [x, dy, mean_f, rstd_f]
+    lib.layernorm_param_grads_grouped(rt.dt(), (LnItem * len(items))(*items), len(items), rt.stream())
+    torch.cuda.synchronize()
+    for dg, db, rg, rb, tag in checks:
+        assert ((dg.double() - rg).abs().max() / rg.abs().max()).item() < 1e-4, tag
+        assert ((db.double() - rb).abs().max() / rb.abs().max()).item() < 1e-4, tag
+    avec_amd.set_compute_dtype("f32")
