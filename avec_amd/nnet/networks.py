@@ -1,4 +1,6 @@
 """Encoders (nnet/networks.py): ResNet-18 visual front-end, ConformerInterCTC stack, audio / visual / audio-visual encoders."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -158,19 +160,25 @@ class VisualEfficientConformerEncoder(nn.Module):
                                           loss_prefix=loss_prefix)
         self.head = layers.Linear(dim_model[-1], vocab_size) if include_head else nn.Identity()
 
-    def forward(self, x, lengths):
-        """x: (B, 1, T, H, W)"""
+    def forward_front(self, x):
+        """x: (B, 1, T, H, W) -> per-frame features (B, T, 256) fp32: Conv3d stem + max-pool + ResNet-18 (nnet/networks.py:497-504)"""
         B, C, T, H, W = x.shape
         assert C == 1
         stem = self.front_end[0].layers[0]
         bn = stem[1]
         frames = ops.VideoStemFn.apply(x.reshape(B, T, H, W), stem[0].weight, stem[0], bn, bn.training and not bn.frozen)     # (B*T, H/4, W/4, 64) act, channels-last
         feats = self.front_end[3].forward_nhwc(frames)                                                          # (B*T, 256) fp32
-        x = feats.view(B, T, -1)
+        return feats.view(B, T, -1)
+
+    def forward_back(self, x, lengths):
         x, lengths, inter = self.back_end(x, lengths)
         if not isinstance(self.head, nn.Identity):
             x = self.head(x)
         return x, lengths, inter
+
+    def forward(self, x, lengths):
+        """x: (B, 1, T, H, W)"""
+        return self.forward_back(self.forward_front(x), lengths)
 
 
 class AudioVisualEfficientConformerEncoder(nn.Module):
@@ -204,9 +212,20 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             for t in (audio, audio_len):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(side)
-            with torch.cuda.stream(side):
-                audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
-            video, video_len, v_inter = self.video_encoder(video, video_len)
+            # Host launch order = order in which a captured graph's kernels reach the GPU.  Forward: the visual front-end (few long kernels, the critical
+            # path) goes first, the ~400 short audio kernels are submitted while it runs, the visual conformer stack follows.  The autograd engine replays
+            # nodes newest-first, so the backward order is: visual conformer stack, audio encoder, ResNet / stem -- the audio submissions again hide
+            # behind running work instead of delaying the critical branch.  AVEC_AUDIO_FIRST=1 restores the old order (audio encoder first).
+            audio_first = os.environ.get("AVEC_AUDIO_FIRST", "0") == "1"
+            if audio_first:
+                with torch.cuda.stream(side):
+                    audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+                video, video_len, v_inter = self.video_encoder(video, video_len)
+            else:
+                feats = self.video_encoder.forward_front(video)
+                with torch.cuda.stream(side):
+                    audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+                video, video_len, v_inter = self.video_encoder.forward_back(feats, video_len)
             main.wait_stream(side)
             for t in [audio, audio_len] + [u for v in a_inter.values() for u in (v if isinstance(v, (list, tuple)) else [v])]:
                 if torch.is_tensor(t) and t.is_cuda:
