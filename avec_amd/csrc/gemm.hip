@@ -910,6 +910,12 @@ template <typename T>
 static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   // tile choice: big tiles only when they still fill the chip (256 CUs)
   long long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+  static const int tile_env = getenv("AVEC_NT_TILE") ? atoi(getenv("AVEC_NT_TILE")) : 0;      // experiments: 128 -> 128x128, 12864 -> 128x64, 64 -> 64x64 for every plain product
+  if (tile_env && mode == MODE_PLAIN) {
+    if (tile_env == 128 && g.N > 64) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
+    if (tile_env == 12864) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
+    if (tile_env == 64) return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
+  }
   if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
   if (((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
   return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);

@@ -19,7 +19,8 @@ class KernelTimer:
     launch while enabled; durations are read after the timed region."""
     NAMES = {(0, ROWS_CONV_FWD): "gemm_nt<conv_fwd>", (0, ROWS_CONV_BWD): "gemm_nt<conv_bwd_data>", (0, ROWS_STEM3D): "gemm_nt<stem3d>",
              (0, ROWS_PLAIN): "gemm_nt<plain>", (1, ROWS_CONV_FWD): "gemm_tn<conv_wgrad>", (1, ROWS_STEM3D): "gemm_tn<stem3d_wgrad>",
-             (1, ROWS_PLAIN): "gemm_tn<plain>", (2, 0): "conv3x3_slab<fwd>", (2, 1): "conv3x3_slab<bwd_data>", (2, 2): "conv3x3_slab<wgrad>"}
+             (1, ROWS_PLAIN): "gemm_tn<plain>", (2, 0): "conv3x3_slab<fwd>", (2, 1): "conv3x3_slab<bwd_data>", (2, 2): "conv3x3_slab<wgrad>",
+             (3, 0): "ffn_fused<fwd>", (3, 1): "ffn_fused<bwd>"}
 
     def __init__(self):
         self.enabled = False
@@ -57,7 +58,7 @@ class KernelTimer:
         kid = max(tmpl, key=lambda k: tmpl[k][0])
         t, fl, n = tmpl[kid]
         achieved = fl / t / 1e12
-        return {"bound": "mfma", "kernel": {0: "gemm_nt (plain + implicit-GEMM conv fwd / bwd-data)", 1: "gemm_tn (weight gradients)", 2: "conv3x3_c64 slab kernel"}[kid],
+        return {"bound": "mfma", "kernel": {0: "gemm_nt (plain + implicit-GEMM conv fwd / bwd-data)", 1: "gemm_tn (weight gradients)", 2: "conv3x3_c64 slab kernel", 3: "ffn_fused (macaron feed-forward)"}[kid],
                 "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
                 "alg_gflop_per_launch": round(fl / n / 1e9, 3),
@@ -381,6 +382,31 @@ class DropoutFn(torch.autograd.Function):
 # FeedForwardModule (nnet/modules.py:257-289) fused with its macaron residual (nnet/blocks.py:292,301)
 #   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
 # ============================================================================================
+# csrc/ffn.hip (one launch per direction) is correct (tests/test_gpu_round2.py) but, measured on MI355X, slower than the launch sequence it replaces
+# (M = 3200, D = 256: forward 73 us against 38 us): 50 workgroups x 64 rows cannot stream 1 MB of weights each fast enough.
+# Opt-in for experiments: AVEC_FFN_FUSED=1.
+FFN_FUSED = os.environ.get("AVEC_FFN_FUSED", "0") == "1"
+
+
+def _ffn_fused_ok(M, D, F):
+    return FFN_FUSED and rt.compute_dtype() == "bf16" and bool(lib.raw("avec_ffn_fused_supported")(BF16, M, D, F))
+
+
+def defer_ln_param_grads(dy, dy_f32, x, mean, rstd, w, b, M, D):
+    """queue d(gamma), d(beta) of a LayerNorm whose input gradient was computed elsewhere (inside a backward pass), or compute them now"""
+    it = LnItem()
+    it.dy, it.x, it.mean, it.rstd, it.dgamma, it.dbeta = dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), grad_of(w).data_ptr(), grad_of(b).data_ptr()
+    it.M, it.D, it.dy_f32 = M, D, int(dy_f32)
+    if _in_backward():
+        q = _pending()
+        q.ln.append(it)
+        q.keep += [dy, x, mean, rstd]
+        if len(q.ln) >= LN_GROUP_MAX:
+            _launch_pending(q, "ln")
+    else:
+        lib.layernorm_param_grads_grouped(rt.dt(), (LnItem * 1)(it), 1, rt.stream())
+
+
 class FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, alpha, drop_p, sid1, sid2):
@@ -390,17 +416,44 @@ class FeedForwardFn(torch.autograd.Function):
         M, D = x2.shape
         F = w1.shape[0]
         adt = rt.act_dtype()
-        h0, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
-        z = empty((M, F), adt, x2)
-        h1 = linear_fwd(h0, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z, drop_p=drop_p, sid=sid1)
-        y = linear_fwd(h1, w2, b2, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid2, res=x2, alpha=alpha)
-        ctx.saved = (x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp)
+        fused = _ffn_fused_ok(M, D, F)
+        if fused:        # csrc/ffn.hip: LN -> GEMM -> Swish/dropout -> GEMM -> residual in one launch, 64 rows per workgroup
+            sh1, sh2 = rt.shadow(w1), rt.shadow(w2)
+            y, mean, rstd = empty((M, D), torch.float32, x2), empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
+            h0, z, h1 = empty((M, D), adt, x2), empty((M, F), adt, x2), empty((M, F), adt, x2)
+            rng = rt.rng_state(x2.device).data_ptr() if drop_p > 0 else None
+            ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+            lib.ffn_fused_fwd(x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, sh1.fwd.data_ptr(), sh1.Cp, b1.data_ptr(), sh2.fwd.data_ptr(), sh2.Cp, b2.data_ptr(),
+                              alpha, drop_p, rng, sid1, sid2, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), h0.data_ptr(), z.data_ptr(), h1.data_ptr(), M, D, F, rt.stream())
+            if ev is not None:
+                KERNEL_TIMER.stop(ev, (3, 0), 4.0 * M * D * F)
+        else:
+            h0, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+            z = empty((M, F), adt, x2)
+            h1 = linear_fwd(h0, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z, drop_p=drop_p, sid=sid1)
+            y = linear_fwd(h1, w2, b2, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid2, res=x2, alpha=alpha)
+        ctx.saved = (x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp, fused)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp = ctx.saved
+        x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp, fused = ctx.saved
         dy = _f32c(dy.reshape(M, D))
+        if fused:
+            sh1, sh2 = rt.shadow(w1), rt.shadow(w2)
+            adt = rt.act_dtype()
+            dx = empty((M, D), torch.float32, dy)
+            dacc, dz, dh0 = empty((M, D), adt, dy), empty((M, F), adt, dy), empty((M, D), adt, dy)
+            rng = rt.rng_state(dy.device).data_ptr() if drop_p > 0 else None
+            ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+            lib.ffn_fused_bwd(dy.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln_w.data_ptr(), sh2.bwd.data_ptr(), sh2.ldb or D, sh1.bwd.data_ptr(), sh1.ldb or F,
+                              z.data_ptr(), alpha, drop_p, rng, sid1, sid2, dx.data_ptr(), dacc.data_ptr(), dz.data_ptr(), dh0.data_ptr(), M, D, F, rt.stream())
+            if ev is not None:
+                KERNEL_TIMER.stop(ev, (3, 1), 4.0 * M * D * F)
+            linear_bwd_weight(dacc, h1, w2, M, bias=b2)
+            linear_bwd_weight(dz, h0, w1, M, bias=b1)
+            defer_ln_param_grads(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D)
+            return (dx.view(shp),) + (None,) * 11
         dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2)
         linear_bwd_weight(dacc, h1, w2, M, bias=b2)
         dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1)

@@ -107,6 +107,24 @@ int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q,
 int avec_gemm_tn_batched_store(int dtype, const void* P, long long ldp, const void* Q, long long ldq, void* O_act, long long ldo, long long M, int I, int J,
                                int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 
+/* ---- fused macaron feed-forward module (avec_amd/csrc/ffn.hip) --------------------------------
+ * FeedForwardModule.forward (nnet/modules.py:257-289) with its residual (nnet/blocks.py:292,301) as ONE launch per direction (bf16 mode):
+ *   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
+ * A workgroup owns 64 rows and runs LN -> GEMM -> Swish/dropout -> GEMM -> residual on them; weights stream through LDS, the hidden activations of the
+ * tile stay on chip.  Saved for the backward pass: mean, rstd [M], h0 = LN(x) [M][D], z (pre-activation) and h1 (post dropout) [M][F], act dtype.
+ * w1 = [F][D], w2 = [D][F] (row-major, row strides ldw*), bf16; the backward takes their transposes w2t = [F][D], w1t = [D][F] (the "bwd shadows").
+ * backward: dx = dy + LN'(...) and the operands of the parameter gradients: dacc = alpha*mask2*dy [M][D], dz [M][F], dh0 [M][D]
+ *   (dW2 = dacc^T h1, db2 = colsum(dacc), dW1 = dz^T h0, db1 = colsum(dz) via avec_gemm_tn_grouped; dgamma/dbeta via avec_layernorm_param_grads_grouped with dy = dh0). */
+int avec_ffn_fused_supported(int dtype, long long M, int D, int F);
+int avec_ffn_debug_stamps(long long* out8);   /* s_memtime stamps {start, prologue done, slot loop done, end} of the last launch with AVEC_FFN_DBG & 32 (host copy) */
+int avec_ffn_fused_fwd(const float* x, const float* ln_g, const float* ln_b, float eps, const void* w1, long long ldw1, const float* b1,
+                       const void* w2, long long ldw2, const float* b2, float alpha, float drop_p, const unsigned long long* rng,
+                       unsigned sid1, unsigned sid2, float* y, float* mean, float* rstd, void* h0, void* z, void* h1,
+                       long long M, int D, int F, hipStream_t stream);
+int avec_ffn_fused_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* ln_g, const void* w2t, long long ldw2t,
+                       const void* w1t, long long ldw1t, const void* z, float alpha, float drop_p, const unsigned long long* rng,
+                       unsigned sid1, unsigned sid2, float* dx, void* dacc, void* dz, void* dh0, long long M, int D, int F, hipStream_t stream);
+
 /* ---- normalisation / elementwise (avec_amd/csrc/norm.hip) ---------------------------------- */
 /* nn.LayerNorm(eps=1e-6) forward/backward: aten::native_layer_norm(_backward) emitted by nnet/modules.py:278,302,373
  * and nnet/blocks.py:267.  x fp32 [M][D]; y act or fp32; dx optionally accumulated (residual merge). */
