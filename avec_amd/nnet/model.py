@@ -56,6 +56,9 @@ class Model(Module):
         self.rank, self.is_distributed = rank, True
         self.world_size = dist.get_world_size()
         rt.ensure_branch_group()          # second communicator for the collectives of the audio branch's stream (runtime.collective_group)
+        if sync_batch_norm and self.device.type == "cuda":
+            from .. import peer
+            peer.setup(self.device)       # SyncBatchNorm statistics by peer writes over xGMI (one small kernel per exchange, no host work); None -> torch.distributed collectives
         if self.arena is not None:
             dist.broadcast(self.arena.master, 0)
             self.arena.mark_dirty()
@@ -210,21 +213,36 @@ class Model(Module):
         return norm
 
     def make_graphed_train_step(self, inputs, targets, precision=torch.bfloat16, warmup=2):
-        """Capture ONE optimisation step (shadow refresh, forward, 6 losses, backward, Adam) into a hipGraph: ~2500 launches replay from a
-        single submission, removing the host-side launch overhead.  Static shapes: later batches are copied into the captured buffers.
-        Single-process only (collectives are kept out of captures); returns step(inputs, targets) -> losses dict (device scalars)."""
-        assert not self.is_distributed, "graph capture is used for single-GPU steps; multi-GPU steps run eagerly"
+        """Capture ONE optimisation step into a hipGraph: ~1600 launches replay from a single submission, removing the host-side launch overhead.
+        Static shapes: later batches are copied into the captured buffers.  Returns step(inputs, targets) -> losses dict (device scalars).
+        * single process: shadow refresh, forward, 6 losses, backward and Adam are all inside the graph;
+        * data parallel (one process per GPU): the graph holds shadow refresh + forward + losses + backward -- the SyncBatchNorm statistic exchanges are
+          peer-write kernels (avec_amd/peer.py), so no host-driven collective interrupts it; the gradient all-reduce (RCCL) and the Adam launch follow the
+          replay.  Requires the peer exchange (otherwise every BatchNorm layer needs a host-issued collective: use train_step)."""
+        from .. import peer
+        dist_mode = self.is_distributed
+        assert not dist_mode or peer.active() is not None, "graph capture of a data-parallel step needs the SyncBatchNorm peer exchange; use train_step"
         rt.set_compute_dtype(precision)
+        warmup = max(int(warmup), 1)                        # lazily created constants (DFT matrix, sinusoid tables, loss weights) must exist before the capture
         static_in = [t.clone() for t in inputs]
         static_tg = tuple(t.clone() for t in targets)
+        if dist_mode:
+            self.arena.arm_early_all_reduce(False)          # no collective inside the capture
 
         def body():
             rt.reset_zero_pool(self.device)
             losses, _, _, _ = self.forward_model(static_in, static_tg, compute_metrics=False)
             losses["loss"].backward()
             rt.advance_rng(self.device)
-            self.optimizer.launch_step()
+            if not dist_mode:
+                self.optimizer.launch_step()
             return losses
+
+        def finish():                                       # data parallel: average the gradients, then the optimizer launch
+            if dist_mode:
+                self.arena.all_reduce_grads()
+                self.optimizer.grad_scale = 1.0 / self.world_size
+                self.optimizer.launch_step()
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -232,11 +250,11 @@ class Model(Module):
             for _ in range(warmup):             # warm-up on a side stream: lazy kernel attributes, caches, allocator
                 self.optimizer.prepare_step()
                 body()
+                finish()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        self.optimizer.prepare_step()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph):                   # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
             static_losses = body()
 
         def step(new_inputs=None, new_targets=None):
@@ -247,6 +265,7 @@ class Model(Module):
                     d.copy_(s_, non_blocking=True)
             self.optimizer.prepare_step()
             graph.replay()
+            finish()
             return static_losses
 
         step.graph = graph

@@ -269,9 +269,6 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
-def _sync_stats(stats):
-    if rt.sync_batchnorm():
-        torch.distributed.all_reduce(stats, group=rt.collective_group())
 
 
 # ============================================================================================
@@ -648,7 +645,7 @@ def bn_finalize(bn, st, count, training):
     sptr, nrep = st.stats.data_ptr(), st.NREP
     if training and rt.sync_batchnorm():
         # SyncBatchNorm: collapse the replicas, append the local count, sum over ranks (one small RCCL all-reduce)
-        st.red = rt.sync_bn_stats(st.stats, st.NREP, C, count)
+        st.red = rt.sync_bn_stats(st.stats, st.NREP, C, count, key=(id(bn), "f"))
         sptr, nrep, cptr = st.red.data_ptr(), 1, st.red.data_ptr() + 2 * C * 4
     mom = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats and bn.running_mean is not None
@@ -664,7 +661,8 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
     dstats = rt.zeros_scratch(2 * C, dout.device)
     lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
     gw, gb = grad_of(bn.weight), grad_of(bn.bias)
-    if _add_local_affine_grads(dstats, gw, gb, C):
+    dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
+    if synced:
         gw = gb = None                    # (SyncBatchNorm) already added from the LOCAL sums; the kernel must not add the global ones
     dy = empty((M, C), adt, dout)
     dres = empty((M, C), adt, dout) if want_dres else None
@@ -673,14 +671,14 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
     return dy, dres
 
 
-def _add_local_affine_grads(dstats, gw, gb, C):
+def _add_local_affine_grads(dstats, gw, gb, C, key):
     """SyncBatchNorm: d(gamma), d(beta) are the LOCAL sums (the gradient all-reduce averages them like any other parameter, as torch's
-    SyncBatchNorm does); only the statistics entering dx are global.  Adds the local sums, then all-reduces `dstats`.  Returns True if it did."""
+    SyncBatchNorm does); only the statistics entering dx are global.  Adds the local sums, then all-reduces `dstats`.
+    Returns (dstats to use -- the global sums when synchronised --, whether it synchronised)."""
     if not rt.sync_batchnorm():
-        return False
+        return dstats, False
     lib.bn_affine_grads(dstats.data_ptr(), gw.data_ptr(), gb.data_ptr(), C, rt.stream())
-    _sync_stats(dstats)
-    return True
+    return rt.all_reduce_small(dstats, key), True
 
 
 
@@ -1148,8 +1146,10 @@ class VideoStemFn(torch.autograd.Function):
         args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
         lib.stem_pool_bwd(rt.dt(), *args, 0, None, None, None, B * T, OH, OW, C, rt.stream())
         gw, gb = grad_of(bn.weight), grad_of(bn.bias)
-        if _add_local_affine_grads(dstats, gw, gb, C):
+        dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
+        if synced:
             gw = gb = None
+            args = args[:5] + (dstats.data_ptr(),) + args[6:]
         dy = empty((M, C), rt.act_dtype(), v)
         lib.stem_pool_bwd(rt.dt(), *args, 1, dy.data_ptr(), _p(gw), _p(gb), B * T, OH, OW, C, rt.stream())
         if r is None:
@@ -1215,8 +1215,10 @@ class AudioStemFn(torch.autograd.Function):
         base = (da.data_ptr(), y.data_ptr(), mel.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(count))
         lib.audio_stem_bwd(rt.dt(), *base, 0, None, None, None, None, B, NM, F, C, rt.stream())
         gw, gb = grad_of(bn.weight), grad_of(bn.bias)
-        if _add_local_affine_grads(dstats, gw, gb, C):
+        dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
+        if synced:
             gw = gb = None
+            base = base[:5] + (dstats.data_ptr(),) + base[6:]
         lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
                            _p(gw), _p(gb), B, NM, F, C, rt.stream())
         arena = rt.arena_of(bn)

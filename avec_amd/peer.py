@@ -1,0 +1,133 @@
+"""SyncBatchNorm statistic exchange by direct peer writes over xGMI (csrc/peer.hip) instead of 90 latency-bound RCCL all-reduces per step.
+
+One uncached exchange buffer per rank, mapped by every rank of the node through HIP IPC; an exchange is ONE single-workgroup kernel on the calling
+stream (no host synchronisation, graph-capturable).  setup() verifies the mechanism against torch.distributed.all_reduce on this very node and the
+caller falls back to RCCL collectives when anything fails (IPC refused, more than 8 ranks, ranks on several nodes, a wrong sum)."""
+import ctypes
+import os
+
+import torch
+
+from .lib import lib
+
+MAX_WORLD = 8
+MAXN = 2056          # granules per slot: vectors of up to 2*1024 + 1 floats (BatchNorm widths <= 1024)
+SITES = 256          # distinct exchange sites (a BatchNorm layer uses two: forward statistics, backward sums)
+
+
+class PeerExchange:
+    def __init__(self, rank, world, device, group=None):
+        import torch.distributed as dist
+        assert 1 < world <= MAX_WORLD, "peer exchange serves 2..%d ranks of one node" % MAX_WORLD
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.site_granules = 2 * world * MAXN                     # two parity pages of world slots
+        nbytes = SITES * self.site_granules * 8
+        own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        with torch.cuda.device(device):
+            lib.peer_buffer_alloc(ctypes.byref(own), nbytes, handle)
+        self._own = own.value
+        handles = [None] * world
+        dist.all_gather_object(handles, (handle.raw, os.uname().nodename), group=group)
+        assert all(h[1] == handles[0][1] for h in handles), "ranks on different nodes: no peer mapping"
+        self.bases, self._opened = [], []
+        with torch.cuda.device(device):
+            for r, (h, _) in enumerate(handles):
+                if r == rank:
+                    self.bases.append(self._own)
+                    continue
+                p = ctypes.c_void_p()
+                lib.peer_buffer_open(h, ctypes.byref(p))
+                self.bases.append(p.value)
+                self._opened.append(p.value)
+        self.epochs = torch.zeros(SITES, dtype=torch.int32, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        self.sites = {}
+        dist.barrier(group=group)                                 # every buffer is mapped everywhere before the first write
+
+    def all_reduce_sum(self, vec, key):
+        """sum of `vec` (fp32, contiguous, <= MAXN elements) over the ranks, identical bits on every rank; `key` names the exchange site (every rank must
+        visit the sites in the same order)"""
+        site = self.sites.get(key)
+        if site is None:
+            site = self.sites[key] = len(self.sites)
+            assert site < SITES, "more than %d SyncBatchNorm exchange sites" % SITES
+        n = vec.numel()
+        assert vec.dtype == torch.float32 and vec.is_contiguous() and 0 < n <= MAXN
+        out = torch.empty_like(vec)
+        pages = (ctypes.c_void_p * self.world)(*[b + site * self.site_granules * 8 for b in self.bases])
+        lib.peer_exchange_sum(vec.data_ptr(), out.data_ptr(), n, pages, self.world * MAXN, self.rank, self.world,
+                              self.epochs.data_ptr() + 4 * site, self.err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def check(self):
+        """host-side: raise if a peer ever failed to arrive (synchronises)"""
+        if int(self.err.item()) != 0:
+            raise RuntimeError("avec_amd.peer: a SyncBatchNorm peer exchange timed out (a rank did not arrive within ~20 s)")
+
+    def close(self):
+        for p in self._opened:
+            lib.raw("avec_peer_buffer_close")(ctypes.c_void_p(p))
+        self._opened = []
+        if self._own:
+            lib.raw("avec_peer_buffer_free")(ctypes.c_void_p(self._own))
+            self._own = None
+
+
+_STATE = {"px": None, "tried": False}
+
+
+def setup(device, group=None):
+    """collective over all ranks: create the exchange, prove it against all_reduce, agree on the verdict.  Returns the PeerExchange or None."""
+    import torch.distributed as dist
+    if _STATE["tried"]:
+        return _STATE["px"]
+    _STATE["tried"] = True
+    if os.environ.get("AVEC_PEER_SYNCBN", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok, px = 1, None
+    if not (1 < world <= MAX_WORLD):
+        ok = 0
+    try:
+        if ok:
+            px = PeerExchange(rank, world, device, group)
+    except Exception as e:                                       # IPC / allocation refused on this node: fall back, loudly
+        ok = 0
+        print("[avec_amd.peer] rank %d: peer exchange unavailable (%s); SyncBatchNorm statistics go through torch.distributed" % (rank, e), flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if px is not None:
+            px.close()
+        return None
+    # self-test: three rounds over two sites against all_reduce (exercises both parity pages and the epoch counters)
+    good = 1
+    for it in range(3):
+        for site_key, n in (("selftest_a", 1025), ("selftest_b", 7)):
+            v = torch.arange(n, dtype=torch.float32, device=device) * (rank + 1) + it
+            got = px.all_reduce_sum(v, site_key)
+            ref = v.clone() if dist.get_backend(group) == "nccl" else v.cpu()
+            dist.all_reduce(ref, group=group)
+            torch.cuda.synchronize(device)
+            if not torch.equal(got.cpu(), ref.cpu()):
+                good = 0
+    if int(px.err.item()) != 0:
+        good = 0
+    flag = torch.tensor([good], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        print("[avec_amd.peer] rank %d: peer exchange self-test failed; SyncBatchNorm statistics go through torch.distributed" % rank, flush=True)
+        px.close()
+        return None
+    _STATE["px"] = px
+    return px
+
+
+def active():
+    return _STATE["px"]
+
+
+def reset():
+    if _STATE["px"] is not None:
+        _STATE["px"].close()
+    _STATE["px"], _STATE["tried"] = None, False

@@ -541,14 +541,24 @@ def ensure_branch_group():
     return _BRANCH.get("group")
 
 
-def sync_bn_stats(stats, nrep, C, count):
+def all_reduce_small(vec, key):
+    """all-reduce(sum) of a short fp32 statistics vector: ONE peer-write kernel over xGMI when the exchange is up (avec_amd/peer.py), else a torch.distributed
+    collective on the communicator of the current stream.  `key` identifies the exchange site (layer, direction)."""
+    import torch.distributed as dist
+    from . import peer
+    px = peer.active()
+    if px is not None and vec.is_cuda:
+        return px.all_reduce_sum(vec, key)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=collective_group())
+    return vec
+
+
+def sync_bn_stats(stats, nrep, C, count, key=None):
     """SyncBatchNorm statistic exchange: collapse the `nrep` replicated [sum | sumsq] partials, append the local element count and sum
     the (2C+1)-vector over ranks.  Returns the reduced vector (global sum, global sumsq, global count)."""
-    import torch.distributed as dist
     if stats.is_cuda:
         red = torch.empty(2 * C + 1, dtype=torch.float32, device=stats.device)
         lib.bn_collapse(stats.data_ptr(), nrep, float(count), red.data_ptr(), C, stream())
     else:       # (CPU tensors: the gloo unit tests of the exchange itself)
         red = torch.cat([stats.view(nrep, 2 * C).sum(0), torch.full((1,), float(count), dtype=stats.dtype, device=stats.device)])
-    dist.all_reduce(red, op=dist.ReduceOp.SUM, group=collective_group())
-    return red
+    return all_reduce_small(red, key)

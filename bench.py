@@ -171,8 +171,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # single GPU: the step is captured into a hipGraph (same launches, one submission); multi-GPU steps (RCCL collectives) run eagerly
-    use_graph = world == 1 and not args.eager
+    # The step is captured into a hipGraph (same launches, one submission).  Data parallel: forward + backward are captured when the SyncBatchNorm statistics
+    # travel by peer-write kernels (avec_amd/peer.py; verified at start-up on this node), the RCCL gradient all-reduce and the Adam launch follow each replay;
+    # without the peer exchange (refused IPC, gloo debugging on CPU tensors, ...) the step runs eagerly.
+    from avec_amd import peer
+    use_graph = not args.eager and (world == 1 or peer.active() is not None)
     if use_graph:
         graphed = model.make_graphed_train_step(inputs, targets, precision=precision, warmup=min(max(args.warmup, 1), 3))
         run_step = lambda: graphed()
@@ -220,7 +223,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "AV EffConfInterCTC (LRS23/AV) training step: fwd + 6 CTC losses + bwd + grad all-reduce + Adam; "
                                    "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "params": 61738836, "loss": round(loss, 4),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),
                        "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5)},
             "roofline": roof,
         }

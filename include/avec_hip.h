@@ -125,6 +125,23 @@ int avec_ffn_fused_bwd(const float* dy, const float* x, const float* mean, const
                        const void* w1t, long long ldw1t, const void* z, float alpha, float drop_p, const unsigned long long* rng,
                        unsigned sid1, unsigned sid2, float* dx, void* dacc, void* dz, void* dh0, long long M, int D, int F, hipStream_t stream);
 
+/* ---- SyncBatchNorm statistic exchange by peer writes over xGMI (avec_amd/csrc/peer.hip) ----------
+ * all-reduce(sum) of a short fp32 vector (the (2C+1)-float / 2C-float vectors of nnet/normalizations.py:172-249) between the GPUs of one node
+ * without RCCL and without the host: every rank writes {value, epoch} granules into its slot of an exchange page in EVERY rank's buffer
+ * (buffers mapped by all ranks through HIP IPC), polls its own page and adds the slots in rank order (bit-identical on all ranks).
+ * pages[r] = base of this exchange site's page pair in rank r's buffer: 2 pages of world * n granules (8 bytes each), `page_stride_granules` apart;
+ * epoch = this site's visit counter in the caller's device memory (zero-initialised, advanced by the kernel: graph-capturable);
+ * err_flag is set to 1 if a peer did not arrive within ~20 s (the call never hangs the GPU). */
+#define AVEC_PEER_MAX_WORLD 8
+int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
+                           unsigned* epoch, int* err_flag, hipStream_t stream);
+int avec_enable_peer_access(int peer_device);
+/* exchange-buffer management: uncached (fine-grained) device memory + its 64-byte HIP IPC handle; peers map it with _open.  The caller owns the pointers. */
+int avec_peer_buffer_alloc(void** ptr, long long bytes, void* ipc_handle_64b);
+int avec_peer_buffer_open(const void* ipc_handle_64b, void** ptr);
+int avec_peer_buffer_close(void* ptr);
+int avec_peer_buffer_free(void* ptr);
+
 /* ---- normalisation / elementwise (avec_amd/csrc/norm.hip) ---------------------------------- */
 /* nn.LayerNorm(eps=1e-6) forward/backward: aten::native_layer_norm(_backward) emitted by nnet/modules.py:278,302,373
  * and nnet/blocks.py:267.  x fp32 [M][D]; y act or fp32; dx optionally accumulated (residual merge). */

@@ -11,14 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_step_equals_single_process(tmp_path):
+@pytest.mark.parametrize("peer_exchange", ["1", "0"], ids=["peer-write SyncBN exchange", "torch.distributed SyncBN exchange"])
+def test_two_rank_step_equals_single_process(tmp_path, peer_exchange):
     single, ddp = str(tmp_path / "single.pt"), str(tmp_path / "ddp.pt")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AVEC_PEER_SYNCBN=peer_exchange)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", single], check=True, env=env, timeout=600)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", "gloo", "--share-gpu"],
                    check=True, env=env, timeout=900)
     a, b = torch.load(single), torch.load(ddp)
+    assert b["peer"] == (peer_exchange == "1")      # the statistics really travelled the way this case names (IPC peer writes work between two processes on one GPU)
     # the overlapped exchange really ran: (fusion + audio-visual encoder + head) and (audio encoder) ranges, disjoint, inside the arena
     assert len(b["early"]) == 2 and not a["early"], b["early"]
     (l0, h0), (l1, h1) = sorted(b["early"])
@@ -36,3 +38,30 @@ def test_two_rank_step_equals_single_process(tmp_path):
     assert (rest_num / rest_den) ** 0.5 < 2e-3, (rest_num / rest_den) ** 0.5
     assert (fe_num / fe_den) ** 0.5 < 6e-2, (fe_num / fe_den) ** 0.5
     assert torch.allclose(a["running_mean"], b["running_mean"], atol=1e-5) and torch.allclose(a["running_var"], b["running_var"], rtol=1e-4, atol=1e-6)
+
+
+def test_peer_exchange_stress_and_graph(tmp_path):
+    """avec_amd/peer.py alone: two processes on the one GPU, many sites / vector lengths / rounds against gloo all_reduce, eagerly and replayed from a hipGraph
+    (the epoch counters live on the device)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_stress.py")], env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("PEER STRESS OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_graphed_two_rank_step_equals_eager_two_rank_step(tmp_path):
+    """data-parallel step captured into a hipGraph (forward + backward with peer-write SyncBatchNorm exchanges inside; all-reduce + Adam after the replay) against
+    the eager data-parallel train_step: same parameters after three steps"""
+    outs = {}
+    for mode in ("eager", "graph"):
+        outs[mode] = str(tmp_path / (mode + ".pt"))
+        subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(ROOT, "tools", "ddp_graph_equiv.py"), "--out", outs[mode], "--mode", mode], check=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=900)
+    a, b = torch.load(outs["eager"]), torch.load(outs["graph"])
+    assert a["peer"] and b["peer"] and b["graphed"] and not a["graphed"]
+    # Adam's first moment is linear in the three steps' gradients: it must agree up to fp32 summation order (the parameters themselves move by ~lr * sign(g) in the first
+    # steps, where a rounding-level difference in a near-zero gradient flips a whole update)
+    ea, eb = a["exp_avg"].double(), b["exp_avg"].double()
+    assert a["step"] == b["step"] == 3
+    assert ((ea - eb).norm() / ea.norm()).item() < 2e-3, ((ea - eb).norm() / ea.norm()).item()
+    moved = (a["master"] - a["master0"]).abs().max().item()
+    assert moved > 0 and (b["master"] - b["master0"]).abs().max().item() > 0
+    assert abs(a["loss"] - b["loss"]) < 1e-3 * abs(a["loss"])

@@ -55,7 +55,8 @@ def main():
         bn = model.encoder.video_encoder.front_end[3].blocks[0].layers[1]
         off_of = {id(p_): o for p_, o in zip(model.arena.params, model.arena.offsets)}
         names = {k: (off_of[id(p_)], p_.numel()) for k, p_ in model.named_parameters()}
-        torch.save({"early": early, "numel": model.arena.numel, "grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
+        from avec_amd import peer
+        torch.save({"peer": peer.active() is not None, "early": early, "numel": model.arena.numel, "grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

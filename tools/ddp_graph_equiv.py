@@ -1,0 +1,61 @@
+"""Two data-parallel ranks on one GPU (gloo): three optimisation steps of the AO model, eagerly (Model.train_step) or from a captured hipGraph
+(Model.make_graphed_train_step: forward + backward with peer-write SyncBatchNorm exchanges inside the graph) -- launched by tests/test_gpu_ddp.py."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--mode", default="eager")
+    args = ap.parse_args()
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group(backend="gloo", init_method="env://")
+    import avec_amd
+    import nnet
+    from avec_amd import peer
+    avec_amd.set_compute_dtype("bf16")
+    avec_amd.manual_seed(7)
+    torch.manual_seed(0)
+    model = nnet.AudioEfficientConformerInterCTC(vocab_size=256, att_type="patch", interctc_blocks=[3, 6])
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "drop_rate"):
+            m.drop_rate = 0.0
+    model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
+    model = model.to(dev).train()
+    model.encoder.spec_augment.eval()
+    model.distribute_strategy(rank)
+    master0 = model.arena.master.clone()
+    g = torch.Generator().manual_seed(11 + rank)
+    audio, alen = 0.1 * torch.randn(2, 32000, generator=g), torch.tensor([32000, 25000])
+    labels, llen = torch.randint(1, 256, (2, 6), generator=g), torch.tensor([6, 4])
+    inputs, targets = [audio.to(dev), alen.to(dev)], (labels.to(dev), llen.to(dev))
+    graphed = args.mode == "graph"
+    if graphed:
+        step = model.make_graphed_train_step(inputs, targets, precision=torch.bfloat16, warmup=1)      # the warm-up pass is a real optimisation step
+        for _ in range(2):
+            losses = step()
+    else:
+        for _ in range(3):
+            losses, _, _ = model.train_step(inputs, targets, precision=torch.bfloat16)
+    torch.cuda.synchronize()
+    loss = losses["loss"].detach().float().clone().cpu()
+    torch.distributed.all_reduce(loss)
+    if peer.active() is not None:
+        peer.active().check()
+    if rank == 0:
+        torch.save({"peer": peer.active() is not None, "graphed": graphed, "master": model.arena.master.cpu(), "master0": master0.cpu(), "exp_avg": model.optimizer._flat["exp_avg"].cpu(), "step": int(model.model_step), "loss": float(loss) / world}, args.out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
