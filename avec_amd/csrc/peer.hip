@@ -8,7 +8,7 @@
 // and adds them in rank order (same order on every rank: bit-identical results, as an all-reduce must give).  A granule needs no fence or
 // flag: payload and tag arrive together (MI355X_MICROARCH.md, hand-off rows).  Two pages per site: a rank cannot write epoch e+2 before every
 // rank wrote e+1, which every rank does only after it finished reading e.  No host involvement: capturable into a hipGraph (the epoch
-// counter lives in device memory).  A poll that lasts longer than ~20 s raises the error flag instead of hanging the GPU.
+// counter lives in device memory).  A poll that lasts longer than `timeout_ms` raises the error flag instead of hanging the GPU.
 #include "common.h"
 #include "avec_hip.h"
 #include <string.h>
@@ -20,6 +20,7 @@ struct PeerArgs {
   int rank, world;
   unsigned* epoch;                                  // this site's visit counter (device memory, this rank)
   int* err;
+  long long timeout_cycles;
 };
 
 __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
         gr = __hip_atomic_load(mine + (long long)r * a.n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned)(gr >> 32) == e) break;
         __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 1023) == 0 && __builtin_readcyclecounter() - t0 > 40000000000ll) { *a.err = 1; break; }
+        if ((++spins & 1023) == 0 && __builtin_readcyclecounter() - t0 > a.timeout_cycles) { *a.err = 1; break; }
       }
       s += __uint_as_float((unsigned)gr);
     }
@@ -55,10 +56,10 @@ __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
 }
 
 extern "C" int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
-                                      unsigned* epoch, int* err_flag, hipStream_t stream) {
+                                      unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream) {
   AVEC_CHECK_ARG(in && out && pages && epoch && err_flag && n > 0 && world >= 1 && world <= AVEC_PEER_MAX_WORLD && rank >= 0 && rank < world,
                  "peer_exchange_sum: bad arguments (n=%d rank=%d world=%d)", n, rank, world);
-  PeerArgs a; a.in = in; a.out = out; a.n = n; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag;
+  PeerArgs a; a.in = in; a.out = out; a.n = n; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag; a.timeout_cycles = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 2400000ll;
   for (int r = 0; r < AVEC_PEER_MAX_WORLD; ++r) a.pages[r] = r < world ? (unsigned long long*)pages[r] : nullptr;
   for (int r = 0; r < world; ++r) AVEC_CHECK_ARG(a.pages[r] && (((uintptr_t)a.pages[r]) & 7) == 0, "peer_exchange_sum: page pointer of rank %d is null / not 8-byte aligned", r);
   hipLaunchKernelGGL(peer_exchange_sum_kernel, dim3(1), dim3(256), 0, stream, a);

@@ -34,6 +34,9 @@ class Model(Module):
         out = super().to(device)
         if self.device.type == "cuda":
             self.arena = rt.ParamArena(self)
+            if not getattr(self, "_avec_version_hook", False):       # every forward (training, evaluation, a bare model(x)): weights edited in place since the last pass -> refresh the shadows
+                self._avec_version_hook = True
+                self.register_forward_pre_hook(lambda m, _args: m.arena.check_versions() if m.arena is not None else None)
             if self.compiled and hasattr(self.optimizer, "attach_arena"):
                 self.optimizer.attach_arena(self.arena)
         return out
@@ -143,8 +146,6 @@ class Model(Module):
     def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
         batch_losses, batch_metrics, batch_truths, batch_preds = {}, {}, {}, {}
         total_loss = torch.zeros((), device=self.device)
-        if self.arena is not None:
-            self.arena.check_versions()           # weights edited in place since the last pass -> refresh their compute-dtype shadows
         outputs = self.forward(inputs)
         if isinstance(outputs, list):
             outputs = {"output_" + str(k): v for k, v in enumerate(outputs)}

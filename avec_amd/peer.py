@@ -16,33 +16,37 @@ SITES = 256          # distinct exchange sites (a BatchNorm layer uses two: forw
 
 
 class PeerExchange:
+    """Construction is split so that EVERY rank runs the same sequence of collectives whatever fails locally (setup() below):
+    allocate() -> [all_gather_object of the handles] -> map(handles) -> [agreement all_reduce] -> ready."""
+
     def __init__(self, rank, world, device, group=None):
-        import torch.distributed as dist
         assert 1 < world <= MAX_WORLD, "peer exchange serves 2..%d ranks of one node" % MAX_WORLD
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.site_granules = 2 * world * MAXN                     # two parity pages of world slots
-        nbytes = SITES * self.site_granules * 8
+        self._own, self._opened, self.bases, self.sites = None, [], [], {}
+        self.epochs = self.err = None
+        self.timeout_ms = 30000
+
+    def allocate(self):
+        """-> the 64-byte IPC handle of this rank's exchange buffer"""
         own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-        with torch.cuda.device(device):
-            lib.peer_buffer_alloc(ctypes.byref(own), nbytes, handle)
+        with torch.cuda.device(self.device):
+            lib.peer_buffer_alloc(ctypes.byref(own), SITES * self.site_granules * 8, handle)
         self._own = own.value
-        handles = [None] * world
-        dist.all_gather_object(handles, (handle.raw, os.uname().nodename), group=group)
-        assert all(h[1] == handles[0][1] for h in handles), "ranks on different nodes: no peer mapping"
-        self.bases, self._opened = [], []
-        with torch.cuda.device(device):
-            for r, (h, _) in enumerate(handles):
-                if r == rank:
+        return handle.raw
+
+    def map(self, handles):
+        with torch.cuda.device(self.device):
+            for r, h in enumerate(handles):
+                if r == self.rank:
                     self.bases.append(self._own)
                     continue
                 p = ctypes.c_void_p()
                 lib.peer_buffer_open(h, ctypes.byref(p))
                 self.bases.append(p.value)
                 self._opened.append(p.value)
-        self.epochs = torch.zeros(SITES, dtype=torch.int32, device=device)
-        self.err = torch.zeros(1, dtype=torch.int32, device=device)
-        self.sites = {}
-        dist.barrier(group=group)                                 # every buffer is mapped everywhere before the first write
+        self.epochs = torch.zeros(SITES, dtype=torch.int32, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def all_reduce_sum(self, vec, key):
         """sum of `vec` (fp32, contiguous, <= MAXN elements) over the ranks, identical bits on every rank; `key` names the exchange site (every rank must
@@ -56,13 +60,13 @@ class PeerExchange:
         out = torch.empty_like(vec)
         pages = (ctypes.c_void_p * self.world)(*[b + site * self.site_granules * 8 for b in self.bases])
         lib.peer_exchange_sum(vec.data_ptr(), out.data_ptr(), n, pages, self.world * MAXN, self.rank, self.world,
-                              self.epochs.data_ptr() + 4 * site, self.err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                              self.epochs.data_ptr() + 4 * site, self.err.data_ptr(), self.timeout_ms, torch.cuda.current_stream().cuda_stream)
         return out
 
     def check(self):
         """host-side: raise if a peer ever failed to arrive (synchronises)"""
         if int(self.err.item()) != 0:
-            raise RuntimeError("avec_amd.peer: a SyncBatchNorm peer exchange timed out (a rank did not arrive within ~20 s)")
+            raise RuntimeError("avec_amd.peer: a SyncBatchNorm peer exchange timed out (a rank did not arrive within %d s)" % (self.timeout_ms // 1000))
 
     def close(self):
         for p in self._opened:
@@ -76,8 +80,16 @@ class PeerExchange:
 _STATE = {"px": None, "tried": False}
 
 
+def _agree(ok, device, group):
+    import torch.distributed as dist
+    flag = torch.tensor([int(ok)], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 def setup(device, group=None):
-    """collective over all ranks: create the exchange, prove it against all_reduce, agree on the verdict.  Returns the PeerExchange or None."""
+    """collective over all ranks: create the exchange, prove it against all_reduce, agree on the verdict.  Returns the PeerExchange or None.
+    Every rank executes the same collectives in the same order whatever fails locally."""
     import torch.distributed as dist
     if _STATE["tried"]:
         return _STATE["px"]
@@ -85,37 +97,42 @@ def setup(device, group=None):
     if os.environ.get("AVEC_PEER_SYNCBN", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ok, px = 1, None
     if not (1 < world <= MAX_WORLD):
-        ok = 0
-    try:
-        if ok:
-            px = PeerExchange(rank, world, device, group)
-    except Exception as e:                                       # IPC / allocation refused on this node: fall back, loudly
-        ok = 0
-        print("[avec_amd.peer] rank %d: peer exchange unavailable (%s); SyncBatchNorm statistics go through torch.distributed" % (rank, e), flush=True)
-    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
-        if px is not None:
-            px.close()
         return None
+    px, handle, why = PeerExchange(rank, world, device, group), None, ""
+    try:
+        handle = px.allocate()
+    except Exception as e:
+        why = "allocation / IPC export refused: %s" % e
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (handle, os.uname().nodename), group=group)
+    ok = all(h is not None for h, _ in gathered) and all(n == gathered[0][1] for _, n in gathered)
+    if ok:
+        try:
+            px.map([h for h, _ in gathered])
+        except Exception as e:
+            ok, why = False, "IPC mapping refused: %s" % e
+    elif not why:
+        why = "a peer could not export its buffer, or the ranks span several nodes"
+    if not _agree(ok, device, group):
+        print("[avec_amd.peer] rank %d: peer exchange unavailable (%s); SyncBatchNorm statistics go through torch.distributed" % (rank, why or "a peer failed"), flush=True)
+        px.close()
+        return None
+    dist.barrier(group=group)                                     # every buffer is mapped everywhere before the first write
     # self-test: three rounds over two sites against all_reduce (exercises both parity pages and the epoch counters)
-    good = 1
+    good = True
+    on_dev = dist.get_backend(group) == "nccl"
+    px.timeout_ms = 3000                                          # a peer whose writes never become visible here must not cost minutes
     for it in range(3):
         for site_key, n in (("selftest_a", 1025), ("selftest_b", 7)):
             v = torch.arange(n, dtype=torch.float32, device=device) * (rank + 1) + it
-            got = px.all_reduce_sum(v, site_key)
-            ref = v.clone() if dist.get_backend(group) == "nccl" else v.cpu()
+            got = px.all_reduce_sum(v, site_key) if good else v
+            ref = v.clone() if on_dev else v.cpu()
             dist.all_reduce(ref, group=group)
             torch.cuda.synchronize(device)
-            if not torch.equal(got.cpu(), ref.cpu()):
-                good = 0
-    if int(px.err.item()) != 0:
-        good = 0
-    flag = torch.tensor([good], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
+            good = good and torch.equal(got.cpu(), ref.cpu()) and int(px.err.item()) == 0
+    px.timeout_ms = 30000
+    if not _agree(good, device, group):
         print("[avec_amd.peer] rank %d: peer exchange self-test failed; SyncBatchNorm statistics go through torch.distributed" % rank, flush=True)
         px.close()
         return None

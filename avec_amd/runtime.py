@@ -501,6 +501,9 @@ class ParamArena:
         folded into the Adam kernel's grad_scale.  Ranges already started by early_all_reduce() are only waited for."""
         early = sorted(getattr(self, "_early", []), key=lambda t: t[0])
         pos = 0
+        if os.environ.get("AVEC_DIAG_SKIP_GRAD_ALLREDUCE") == "1":      # diagnostics only (two ranks sharing one GPU over gloo: isolates compute + SyncBatchNorm exchange cost)
+            early = []
+            pos = self.numel
         for lo, hi, _ in early + [(self.numel, self.numel, None)]:
             if lo > pos:
                 all_reduce_flat(self.grad[pos:lo], bucket_bytes)

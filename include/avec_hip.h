@@ -131,10 +131,10 @@ int avec_ffn_fused_bwd(const float* dy, const float* x, const float* mean, const
  * (buffers mapped by all ranks through HIP IPC), polls its own page and adds the slots in rank order (bit-identical on all ranks).
  * pages[r] = base of this exchange site's page pair in rank r's buffer: 2 pages of world * n granules (8 bytes each), `page_stride_granules` apart;
  * epoch = this site's visit counter in the caller's device memory (zero-initialised, advanced by the kernel: graph-capturable);
- * err_flag is set to 1 if a peer did not arrive within ~20 s (the call never hangs the GPU). */
+ * err_flag is set to 1 if a peer did not arrive within timeout_ms (<= 0: 20 s) -- the call never hangs the GPU. */
 #define AVEC_PEER_MAX_WORLD 8
 int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
-                           unsigned* epoch, int* err_flag, hipStream_t stream);
+                           unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream);
 int avec_enable_peer_access(int peer_device);
 /* exchange-buffer management: uncached (fine-grained) device memory + its 64-byte HIP IPC handle; peers map it with _open.  The caller owns the pointers. */
 int avec_peer_buffer_alloc(void** ptr, long long bytes, void* ipc_handle_64b);

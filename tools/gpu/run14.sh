@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 3000 python -m pytest tests/test_gpu_round2.py -x -q -m gpu 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo\|OMP_NUM\|^\*\*\*\*\|^$" | tail -40 > gpurun_out/r2_tests14.log
