@@ -17,11 +17,12 @@ struct AttnArgs {
   void *pbuf, *dsbuf; long long ldt;         // backward scratch, act [B*H][T][ldt]: probabilities and dS (written by the dQ pass)
   void* dsrel; long long ldr;                // optional act [H][B*T][ldr]: dS re-indexed by E row r = j + (T-1) - i (zero elsewhere; caller zero-fills)
   int B, H, T, d; float scale;
+  int Tk;                                    // keys / values per batch element (= T unless a key/value cache is attached: decoding, forward + probability pass only)
 };
 
 template <typename T>
 __device__ __forceinline__ bool key_keep(const AttnArgs& a, int b, int i, int j) {
-  if (a.mask) return a.mask[(long long)b * a.mask_bstride + (long long)i * a.T + j] != 0.f;
+  if (a.mask) return a.mask[(long long)b * a.mask_bstride + (long long)i * a.Tk + j] != 0.f;
   if (i >= a.q_full) return false;
   if (a.lens) return j < (int)(a.lens[b] / a.len_div);
   return true;

@@ -15,6 +15,7 @@ static constexpr int TQ = 32;    // query rows per workgroup (fwd / bwd1): 4 wav
 static constexpr int RPW = TQ / 4;
 static constexpr int TK = 64;    // keys per tile = one per lane
 static constexpr int QC = 32;    // queries staged per chunk in the column pass (dK/dV/dE)
+static constexpr int NCS = 3;    // output channels per lane in the row passes (lane, lane + 64, lane + 128): head widths up to 192 (grouped attention: 3 x 45 + 1)
 
 // cooperative load of `rows` rows x d channels (act dtype -> fp32 LDS, zero outside [0, limit)).
 // VW elements per access: 16 B when the head width allows it (d % 8 == 0 for bf16, d % 4 == 0 for fp32), 4/8 B for even d,
@@ -68,7 +69,7 @@ __device__ __forceinline__ void load_rows(float* dst, int DP, const T* src, long
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int d = a.d, DP = d | 1, Tn = a.T;
+  const int d = a.d, DP = d | 1, Tn = a.T, Tk = a.Tk;
   float* Ks = sm; float* Vs = Ks + TK * DP; float* Es = Vs + TK * DP; float* Qs = Es + (TQ + TK - 1) * DP;
   float* Gs = Qs + TQ * DP;                  // BWD: dO rows
   float* Ps = Gs + (BWD ? TQ * DP : 0);      // [4][64]
@@ -76,16 +77,16 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int i0 = blockIdx.x * TQ;
   const T* qp = (const T*)a.q + (long long)b * Tn * a.ld + h * d;
-  const T* kp = (const T*)a.k + (long long)b * Tn * a.ld + h * d;
-  const T* vp = (const T*)a.v + (long long)b * Tn * a.ld + h * d;
+  const T* kp = (const T*)a.k + (long long)b * Tk * a.ld + h * d;
+  const T* vp = (const T*)a.v + (long long)b * Tk * a.ld + h * d;
   const T* ep = (const T*)a.e + h * d;
   load_rows<T>(Qs, DP, qp, a.ld, i0, TQ, Tn, d);
   if (BWD) load_rows<T>(Gs, DP, (const T*)a.dout + (long long)b * Tn * a.ldo + h * d, a.ldo, i0, TQ, Tn, d);
   __syncthreads();
 
-  float m_run[RPW], l_run[RPW], acc[RPW][2], Li[RPW], Il[RPW], dl[RPW];
+  float m_run[RPW], l_run[RPW], acc[RPW][NCS], Li[RPW], Il[RPW], dl[RPW];
 #pragma unroll
-  for (int rr = 0; rr < RPW; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr][0] = acc[rr][1] = 0.f; Li[rr] = 0.f; Il[rr] = 0.f; dl[rr] = 0.f; }
+  for (int rr = 0; rr < RPW; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; for (int u = 0; u < NCS; ++u) acc[rr][u] = 0.f; Li[rr] = 0.f; Il[rr] = 0.f; dl[rr] = 0.f; }
   if (BWD) {
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -100,18 +101,18 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
     }
   }
 
-  for (int j0 = 0; j0 < Tn; j0 += TK) {
+  for (int j0 = 0; j0 < Tk; j0 += TK) {
     __syncthreads();
-    load_rows<T>(Ks, DP, kp, a.ld, j0, TK, Tn, d);
-    load_rows<T>(Vs, DP, vp, a.ld, j0, TK, Tn, d);
+    load_rows<T>(Ks, DP, kp, a.ld, j0, TK, Tk, d);
+    load_rows<T>(Vs, DP, vp, a.ld, j0, TK, Tk, d);
     const int rbase = (Tn - 1) - (i0 + TQ - 1) + j0;
-    load_rows<T>(Es, DP, ep, a.lde, rbase, TQ + TK - 1, 2 * Tn - 1, d);
+    load_rows<T>(Es, DP, ep, a.lde, rbase, TQ + TK - 1, Tk + Tn - 1, d);
     __syncthreads();
     const int j = j0 + lane;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int ri = w * RPW + rr, i = i0 + ri;
-      const bool iv = i < Tn, jv = j < Tn;
+      const bool iv = i < Tn, jv = j < Tk;
       const float* qrow = Qs + ri * DP; const float* krow = Ks + lane * DP; const float* erow = Es + (TQ - 1 - ri + lane) * DP;
       float s = 0.f, dp = 0.f;
       if (BWD) { const float* grow = Gs + ri * DP; const float* vrow = Vs + lane * DP;
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
         float alpha = (m_run[rr] == -INFINITY) ? 0.f : __expf(m_run[rr] - m_new);
         pval = (iv && jv) ? __expf(s - m_new) : 0.f;
         l_run[rr] = l_run[rr] * alpha + wave_sum(pval);
-        acc[rr][0] *= alpha; acc[rr][1] *= alpha; m_run[rr] = m_new;
+        for (int u = 0; u < NCS; ++u) acc[rr][u] *= alpha;
+        m_run[rr] = m_new;
       } else {
         float p = (iv && jv) ? __expf(s - Li[rr]) * Il[rr] : 0.f;
         pval = p * (dp - dl[rr]) * a.scale;   // dS
@@ -141,15 +143,15 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
       if (!BWD) {
         for (int jj = 0; jj < TK; ++jj) {
           const float pj = Ps[w * 64 + jj];
-          if (lane < d) acc[rr][0] += pj * Vs[jj * DP + lane];
-          if (lane + 64 < d) acc[rr][1] += pj * Vs[jj * DP + lane + 64];
+#pragma unroll
+          for (int u = 0; u < NCS; ++u) if (lane + 64 * u < d) acc[rr][u] += pj * Vs[jj * DP + lane + 64 * u];
         }
       } else {
         const float* ebase = Es + (TQ - 1 - ri) * DP;
         for (int jj = 0; jj < TK; ++jj) {
           const float dsj = Ps[w * 64 + jj];
-          if (lane < d) acc[rr][0] += dsj * (Ks[jj * DP + lane] + ebase[jj * DP + lane]);
-          if (lane + 64 < d) acc[rr][1] += dsj * (Ks[jj * DP + lane + 64] + ebase[jj * DP + lane + 64]);
+#pragma unroll
+          for (int u = 0; u < NCS; ++u) if (lane + 64 * u < d) acc[rr][u] += dsj * (Ks[jj * DP + lane + 64 * u] + ebase[jj * DP + lane + 64 * u]);
         }
       }
       __syncthreads();
@@ -162,13 +164,13 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnArgs a) {
     if (!BWD) {
       const float inv = 1.f / l_run[rr];
       T* op = (T*)a.o + ((long long)b * Tn + i) * a.ldo + h * d;
-      if (lane < d) stf(op + lane, acc[rr][0] * inv);
-      if (lane + 64 < d) stf(op + lane + 64, acc[rr][1] * inv);
+#pragma unroll
+      for (int u = 0; u < NCS; ++u) if (lane + 64 * u < d) stf(op + lane + 64 * u, acc[rr][u] * inv);
       if (lane == 0) { a.lse[((long long)bh * Tn + i) * 2] = m_run[rr]; a.lse[((long long)bh * Tn + i) * 2 + 1] = l_run[rr]; }
     } else {
       T* op = (T*)a.dq + ((long long)b * Tn + i) * a.lddq + h * d;
-      if (lane < d) stf(op + lane, acc[rr][0]);
-      if (lane + 64 < d) stf(op + lane + 64, acc[rr][1]);
+#pragma unroll
+      for (int u = 0; u < NCS; ++u) if (lane + 64 * u < d) stf(op + lane + 64 * u, acc[rr][u]);
     }
   }
 }
@@ -244,9 +246,9 @@ static int fill_args(AttnArgs& a, const avec_attn_t* p) {
   a.q = p->q; a.k = p->k; a.v = p->v; a.ld = p->ld; a.e = p->e; a.lde = p->lde; a.lens = p->lens; a.len_div = p->len_div > 0 ? p->len_div : 1; a.q_full = p->q_full > 0 ? p->q_full : p->T;
   a.mask = p->mask; a.mask_bstride = p->mask_bstride; a.o = p->o; a.ldo = p->ldo; a.lse = p->lse; a.dout = p->dout;
   a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lddq = p->lddq; a.ldd = p->ldd; a.de = p->de; a.ldde = p->ldde; a.pbuf = p->pbuf; a.dsbuf = p->dsbuf; a.ldt = p->ldt; a.dsrel = p->dsrel; a.ldr = p->ldr;
-  a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale;
+  a.B = p->B; a.H = p->H; a.T = p->T; a.d = p->d; a.scale = p->scale; a.Tk = p->Tk > 0 ? p->Tk : p->T;
   AVEC_CHECK_ARG(a.q && a.k && a.v && a.e && a.o && a.lse, "attention: null pointer");
-  AVEC_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.d > 0 && a.d <= 96, "attention: bad dims B=%d H=%d T=%d d=%d (d <= 96 supported)", a.B, a.H, a.T, a.d);
+  AVEC_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.d > 0 && a.d <= 64 * NCS && a.Tk >= a.T, "attention: bad dims B=%d H=%d T=%d Tk=%d d=%d (d <= %d, Tk >= T)", a.B, a.H, a.T, a.Tk, a.d, 64 * NCS);
   return 0;
 }
 template <typename K> static int set_lds(K kern, size_t bytes) {
@@ -281,11 +283,12 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
     if (int r = set_lds(attn_rows_kernel<T, true>, lds1)) return r;
     hipLaunchKernelGGL((attn_rows_kernel<T, true>), grid1, dim3(256), lds1, st, a);
   }
-  if (a.dsrel) return 0;            // dK/dV/dE are computed by the caller with avec_gemm_tn_batched on P / dS / dSrel (MFMA path)
+  if (a.dsrel || a.Tk != a.T) return 0;            // (Tk != T: key/value cache attached -- only the probability / dQ row pass is defined)  dK/dV/dE are computed by the caller with avec_gemm_tn_batched on P / dS / dSrel (MFMA path)
   size_t lds2 = (size_t)(2 * QC + 2 * 64) * DP * 4;
   const int ktiles = (a.T + 63) / 64, rtiles = (2 * a.T - 1 + 63) / 64;
   dim3 grid2(ktiles + rtiles, a.B * a.H);
 #define LB(DPAD) do { if (int r = set_lds(attn_bwd_cols_kernel<T, DPAD>, lds2)) return r; hipLaunchKernelGGL((attn_bwd_cols_kernel<T, DPAD>), grid2, dim3(256), lds2, st, a, ktiles); } while (0)
+  AVEC_CHECK_ARG(a.d <= 96, "attention_bwd: the register-accumulating column pass serves d <= 96 (d=%d): pass dsrel and use avec_gemm_tn_batched", a.d);
   if (a.d <= 48) LB(48); else if (a.d <= 64) LB(64); else LB(96);
 #undef LB
   return 0;
@@ -293,7 +296,7 @@ template <typename T> static int launch_bwd(AttnArgs& a, hipStream_t st) {
 
 extern "C" int avec_relpos_attention_bwd(int dtype, const avec_attn_t* p, hipStream_t st) {
   AttnArgs a; AVEC_CHECK_ARG(p, "attention_bwd: null args"); if (int r = fill_args(a, p)) return r;
-  AVEC_CHECK_ARG(a.dout && a.dq && a.pbuf && a.dsbuf && a.ldt >= a.T && (a.dsrel ? a.ldr >= 2 * a.T - 1 : (a.dk && a.dv && a.de)), "attention_bwd: null gradient / scratch pointer");
+  AVEC_CHECK_ARG(a.dout && a.dq && a.pbuf && a.dsbuf && a.ldt >= a.Tk && (a.dsrel ? a.ldr >= a.Tk + a.T - 1 : (a.Tk != a.T || (a.dk && a.dv && a.de))), "attention_bwd: null gradient / scratch pointer");
   int r = (dtype == AVEC_BF16) ? launch_bwd<bf16>(a, st) : launch_bwd<float>(a, st);
   if (r) return r;
   AVEC_LAUNCH_CHECK(); return 0;

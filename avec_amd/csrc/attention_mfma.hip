@@ -400,7 +400,7 @@ template <typename K> static int mfma_set_lds(K kern, size_t bytes) {
 }
 
 int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
-  if (g_mfma_off || a.mask || a.d > 96 || a.T > 32 * NTMAX) return 1;
+  if (g_mfma_off || a.mask || a.d > 96 || a.T > 32 * NTMAX || a.Tk != a.T) return 1;
   const int pitch = a.d <= 64 ? 128 : 256;
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, false);
   if (G.total > 160 * 1024) return 1;
@@ -415,7 +415,7 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
 }
 
 int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) {
-  if (g_mfma_off || a.mask || a.d > 96 || a.T > 32 * NTMAX || !a.pbuf || !a.dsbuf || !a.dq || !a.dout) return 1;
+  if (g_mfma_off || a.mask || a.d > 96 || a.T > 32 * NTMAX || a.Tk != a.T || !a.pbuf || !a.dsbuf || !a.dq || !a.dout) return 1;
   const int pitch = a.d <= 64 ? 128 : 256;
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, true);
   if (G.total > 160 * 1024) return 1;

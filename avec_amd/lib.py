@@ -41,7 +41,7 @@ class Attn(ctypes.Structure):
                 ("dout", ctypes.c_void_p),
                 ("dq", ctypes.c_void_p), ("dk", ctypes.c_void_p), ("dv", ctypes.c_void_p), ("lddq", ctypes.c_longlong), ("ldd", ctypes.c_longlong),
                 ("de", ctypes.c_void_p), ("ldde", ctypes.c_longlong), ("pbuf", ctypes.c_void_p), ("dsbuf", ctypes.c_void_p), ("ldt", ctypes.c_longlong), ("dsrel", ctypes.c_void_p), ("ldr", ctypes.c_longlong),
-                ("B", ctypes.c_int), ("H", ctypes.c_int), ("T", ctypes.c_int), ("d", ctypes.c_int), ("scale", ctypes.c_float)]
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("T", ctypes.c_int), ("d", ctypes.c_int), ("scale", ctypes.c_float), ("Tk", ctypes.c_int)]
 
 
 class TnItem(ctypes.Structure):

@@ -112,7 +112,7 @@ class AudioEfficientConformerEncoder(nn.Module):
 
     def __init__(self, include_head=True, vocab_size=256, att_type="patch", interctc_blocks=[3, 6, 10, 13], num_blocks=[5, 6, 5], loss_prefix="ctc"):
         super().__init__()
-        assert att_type in ("regular", "patch"), "grouped attention: no shipped config selects it (SURVEY a11 / 8f rank 4)"
+        assert att_type in ("regular", "grouped", "patch")
         filters, n_mels, dim_model, H = 180, 80, [180, 256, 360], 4
         self.audio_preprocessing = preprocessing.AudioPreprocessing(16000, 512, 25, 10, n_mels, False, -5.6501, 4.2280)
         self.spec_augment = preprocessing.SpecAugment(mF=2, F=27, mT=5, pS=0.05)
@@ -122,9 +122,13 @@ class AudioEfficientConformerEncoder(nn.Module):
         self.reshape = layers.Reshape(shape=(filters * n_mels // 2, -1), include_batch=False)
         self.transpose = layers.Transpose(1, 2)
         self.linear = layers.Linear(filters * n_mels // 2, dim_model[0])
-        first = _relpos(H, 0.0, 10000, patch_size=3) if att_type == "patch" else _relpos(H, 0.0, 10000)
+        if att_type == "grouped":             # nnet/networks.py:389-392: Transformer-XL biases everywhere, 3-frame groups in the first stage
+            grouped = lambda G: {"class": "GroupedRelPosMultiHeadSelfAttention", "params": {"num_heads": H, "group_size": G, "attn_drop_rate": 0.0, "max_pos_encoding": 10000, "causal": False}}
+            att = [grouped(3), grouped(1), grouped(1)]
+        else:
+            att = [_relpos(H, 0.0, 10000, patch_size=3) if att_type == "patch" else _relpos(H, 0.0, 10000), _relpos(H, 0.0, 10000), _relpos(H, 0.0, 10000)]
         self.back_end = ConformerInterCTC(dim_model=dim_model, num_blocks=num_blocks, interctc_blocks=interctc_blocks, vocab_size=vocab_size,
-                                          att_params=[first, _relpos(H, 0.0, 10000), _relpos(H, 0.0, 10000)],
+                                          att_params=att,
                                           conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}, ff_ratio=4, drop_rate=0.1,
                                           pos_embedding=None, mask=attentions.Mask(), conv_stride=2, batch_norm=True, loss_prefix=loss_prefix)
         self.head = layers.Linear(dim_model[-1], vocab_size) if include_head else nn.Identity()

@@ -614,6 +614,92 @@ class AttentionModuleFn(torch.autograd.Function):
         return (dx.view(B, T, D),) + (None,) * 20
 
 
+class RelPosCoreFn(torch.autograd.Function):
+    """softmax((Q K^T + rel_to_abs(Q E^T)) * scale + mask) V per (batch, head) on packed activation-dtype operands (the core of nnet/attentions.py:299-315 /
+    :621-640 without the projections): qkv [B*T][3*H*d] = q | k | v, e [2T-1][H*d] (row r <-> relative offset T-1-r) -> o [B*T][H*d].
+    Used by the Transformer-XL style / grouped attention classes, whose u / v biases and frame grouping are expressed on the operands."""
+
+    @staticmethod
+    def forward(ctx, qkv, e, lens, len_div, mask, B, H, T, d, scale):
+        rt.require_gpu(qkv)
+        D, adt = H * d, rt.act_dtype()
+        assert qkv.dtype == adt and e.dtype == adt and qkv.is_contiguous() and e.is_contiguous() and qkv.shape == (B * T, 3 * D) and e.shape == (2 * T - 1, D)
+        assert d % 2 == 0, "the batched-GEMM backward needs an even head width (pad the operands)"
+        if mask is not None:
+            mask = mask.reshape(mask.shape[0], T, T).float().contiguous()
+        o = empty((B * T, D), adt, qkv)
+        lse = empty((B * H, T, 2), torch.float32, qkv)
+        a = _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D)
+        a.scale = scale
+        lib.relpos_attention_fwd(rt.dt(), _byref(a), rt.stream())
+        ctx.saved = (qkv, e, o, lse, lens, len_div, mask, B, H, T, d, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, e, o, lse, lens, len_div, mask, B, H, T, d, scale = ctx.saved
+        D, adt = H * d, rt.act_dtype()
+        do = do.to(adt).contiguous()
+        dqkv = empty((B * T, 3 * D), adt, do)
+        de = torch.zeros((2 * T - 1, D), dtype=torch.float32, device=do.device)
+        a = _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D)
+        a.scale = scale
+        a.dout = do.data_ptr()
+        esz = dqkv.element_size()
+        a.dq, a.lddq = dqkv.data_ptr(), 3 * D
+        a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
+        a.de, a.ldde = de.data_ptr(), D
+        Tld, Rld = (T + 7) // 8 * 8, (2 * T - 1 + 7) // 8 * 8
+        scratch = empty((2, B * H, T, Tld), adt, do)
+        a.pbuf, a.dsbuf, a.ldt = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * esz, Tld
+        dsrel = torch.zeros((H, B * T, Rld), dtype=adt, device=do.device)
+        a.dsrel, a.ldr = dsrel.data_ptr(), Rld
+        lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())
+        L6 = ctypes.c_longlong * 6
+        lib.gemm_tn_batched_store(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D, T, T, d, B, H,
+                                  L6(H * T * Tld, T * Tld, T * 3 * D, d, T * 3 * D, d), rt.stream())
+        lib.gemm_tn_batched_store(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D, T, T, d, B, H,
+                                  L6(H * T * Tld, T * Tld, T * D, d, T * 3 * D, d), rt.stream())
+        lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * T, 2 * T - 1, d, 1, H,
+                            L6(0, B * T * Rld, 0, d, 0, d), rt.stream())
+        return dqkv, de.to(adt), None, None, None, None, None, None, None, None
+
+
+def relpos_core_infer(q, k, v, e, lens, mask, B, H, T, Tk, d, scale, want_probs=False):
+    """inference form with a key/value cache: q [B*T][H*d], k / v [B*Tk][H*d] (Tk >= T), e [Tk+T-1][H*d], optional dense mask (Bm, T, Tk) -> o [B*T][H*d]
+    (and the attention probabilities (B, H, T, Tk) when asked: the reference returns them next to the updated cache, nnet/attentions.py:552)"""
+    rt.require_gpu(q)
+    D, adt = H * d, rt.act_dtype()
+    for t in (q, k, v, e):
+        assert t.dtype == adt and t.is_contiguous()
+    assert q.shape == (B * T, D) and k.shape == (B * Tk, D) and v.shape == (B * Tk, D) and e.shape == (Tk + T - 1, D)
+    if mask is not None:
+        mask = mask.reshape(mask.shape[0], T, Tk).float().contiguous()
+    o = empty((B * T, D), adt, q)
+    lse = empty((B * H, T, 2), torch.float32, q)
+    a = Attn()
+    a.q, a.k, a.v, a.ld = q.data_ptr(), k.data_ptr(), v.data_ptr(), D
+    a.e, a.lde = e.data_ptr(), D
+    a.lens, a.len_div = _p(lens), 1
+    if mask is not None:
+        a.mask, a.mask_bstride = mask.data_ptr(), (T * Tk if mask.shape[0] > 1 else 0)
+    a.o, a.ldo, a.lse = o.data_ptr(), D, lse.data_ptr()
+    a.B, a.H, a.T, a.d, a.scale, a.Tk = B, H, T, d, scale, Tk
+    lib.relpos_attention_fwd(rt.dt(), _byref(a), rt.stream())
+    if not want_probs:
+        return o, None
+    Tld = (Tk + 7) // 8 * 8
+    scratch = empty((2, B * H, T, Tld), adt, q)
+    dq = empty((B * T, D), adt, q)
+    zero = torch.zeros((B * T, D), dtype=adt, device=q.device)
+    dsrel = torch.zeros((H, B * T, (Tk + T - 1 + 7) // 8 * 8), dtype=adt, device=q.device)
+    a.dout, a.dq, a.lddq = zero.data_ptr(), dq.data_ptr(), D
+    a.pbuf, a.dsbuf, a.ldt = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * scratch.element_size(), Tld
+    a.dsrel, a.ldr = dsrel.data_ptr(), dsrel.shape[2]
+    lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())         # the row pass recomputes the probabilities from (max, sum) and stores them
+    return o, scratch[0].view(B, H, T, Tld)[..., :Tk].float()
+
+
 def _pool_mask(mask, T, P):
     """reference min-pool of the padded (B,1,T,T) mask (nnet/attentions.py:140-171,357-362) -- exact 0/1 index work on the host side API path"""
     pad = (P - T % P) % P

@@ -215,6 +215,9 @@ typedef struct avec_attn {
   void *pbuf, *dsbuf; long long ldt;          /* backward scratch, act [B*H][T][ldt] each (probabilities, dS) */
   void* dsrel; long long ldr;                 /* optional act [H][B*T][ldr] (zero-filled): dS indexed by E row; when given, dK/dV/dE are left to avec_gemm_tn_batched */
   int B, H, T, d; float scale;
+  int Tk;                                     /* keys / values per batch element, 0 = T.  Tk > T: a key/value cache (`hidden`, nnet/attentions.py:506-512) precedes the T new frames:
+                                                 k, v = act [B*Tk][ld], e = act [Tk+T-1][lde] (row r <-> relative position Tk-1-r), dense mask (Bm,T,Tk); forward and the probability
+                                                 pass of avec_relpos_attention_bwd (pbuf) only */
 } avec_attn_t;
 /* RelPos1dMultiHeadAttention.forwardQKV core (nnet/attentions.py:299-315): bmm + rel_to_abs + mask + softmax + bmm */
 int avec_relpos_attention_fwd(int dtype, const avec_attn_t* args, hipStream_t stream);

@@ -195,6 +195,64 @@ def rel_pos_attention(sd, prefix, x, mask, H):
     return linear(sd, prefix + ".output_layer", o)
 
 
+def grouped_pos_table(T, Th, D, G):
+    """nnet/embeddings.py:160-216, full context: the rows the slice [max_len - T + G//2 - Th : max_len - G%2 + T - G//2) selects, i.e. the frame offsets
+    T + Th - 1 - G//2 ... -(T - G//2 - 1) (for even G the table holds position 0 twice and so does the slice)."""
+    hi, lo = T - 1 - G // 2 + Th, -(T - G // 2 - 1)
+    if G % 2:
+        pos = torch.arange(hi, lo - 1, -1, dtype=torch.float32)
+    else:
+        pos = torch.cat([torch.arange(hi, -1, -1, dtype=torch.float32), torch.arange(0, lo - 1, -1, dtype=torch.float32)])
+    inv = 10000 ** (2 * torch.arange(0, D // 2, dtype=torch.float32).unsqueeze(0) / D)
+    ang = pos.unsqueeze(1) / inv
+    pe = torch.zeros(pos.shape[0], D)
+    pe[:, 0::2] = ang.sin()
+    pe[:, 1::2] = ang.cos()
+    return pe
+
+
+def grouped_rel_pos_attention(sd, prefix, x, mask, H, G, hidden=None, return_hidden=False):
+    """GroupedRelPosMultiHeadSelfAttention.forwardQKV (nnet/attentions.py:579-650; G = 1 is RelPosMultiHeadSelfAttention, :491-554), full context:
+    projections; optional key/value cache (the cache keeps all frames, the attention drops its first Th % G); zero padding to multiples of G AFTER the
+    projections (:140-171; a missing mask becomes an all-zero one when keys were padded); Qu = Q + u, Qv = Q + v; G frames -> one token by reshape;
+    scores[i,j] = (Qu_i.K_j + Qv_i.E_{(Th/G + i) - j}) / sqrt(G*D/H) with rel_to_abs (:417-489) restated as direct indexing; mask[::G, ::G]."""
+    B, T, D = x.shape
+    dh = G * D // H
+    q, k, v = linear(sd, prefix + ".query_layer", x), linear(sd, prefix + ".key_layer", x), linear(sd, prefix + ".value_layer", x)
+    new_hidden = {"K": k.detach(), "V": v.detach()}
+    if hidden:
+        new_hidden = {"K": torch.cat([hidden["K"], k], 1).detach(), "V": torch.cat([hidden["V"], v], 1).detach()}
+        cut = hidden["K"].shape[1] % G
+        k, v = torch.cat([hidden["K"][:, cut:], k], 1), torch.cat([hidden["V"][:, cut:], v], 1)
+    pq, pk = (-T) % G, (-k.shape[1]) % G
+    Tkv = k.shape[1]
+    q, k, v = F.pad(q, (0, 0, 0, pq)), F.pad(k, (0, 0, 0, pk)), F.pad(v, (0, 0, 0, pk))
+    if mask is not None:
+        mask = F.pad(mask, (0, pk) if mask.shape[2] == 1 else (0, pq, 0, pk), value=0)      # (sic) the reference pads (last dim by padding_Q, rows by padding_KV); equal when Th = 0
+    elif pk:
+        mask = F.pad(q.new_zeros(B, 1, 1, Tkv), (0, pk), value=0)
+    Tp, Tkp = T + pq, Tkv + pk
+    Tg, Tkg = Tp // G, Tkp // G
+    qu = (q + sd[prefix + ".u"]).reshape(B, Tg, H, dh).transpose(1, 2)
+    qv = (q + sd[prefix + ".v"]).reshape(B, Tg, H, dh).transpose(1, 2)
+    k = k.reshape(B, Tkg, H, dh).transpose(1, 2)
+    v = v.reshape(B, Tkg, H, dh).transpose(1, 2)
+    e = linear(sd, prefix + ".pos_layer", grouped_pos_table(Tp, Tkp - Tp, D, G).to(x.dtype)).reshape(-1, H, dh).transpose(0, 1)     # (H, Tkg + Tg - 1, dh)
+    s_k = qu @ k.transpose(2, 3)
+    s_all = qv @ e.transpose(1, 2).unsqueeze(0)
+    i = torch.arange(Tg).unsqueeze(1)
+    j = torch.arange(Tkg).unsqueeze(0)
+    idx = (Tg - 1) - i + j                                   # row r <-> group offset (Tkg - 1 - r); needed: (Tkg - Tg + i) - j
+    s_e = s_all.gather(3, idx.expand(B, H, Tg, Tkg))
+    scores = (s_k + s_e) / dh ** 0.5
+    if mask is not None:
+        scores = scores + mask[:, :, ::G, ::G].logical_not() * -1e9
+    p = scores.softmax(dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, Tp, D)[:, :T]
+    o = linear(sd, prefix + ".output_layer", o)
+    return (o, p, new_hidden) if return_hidden else o
+
+
 def patch_attention(sd, prefix, x, mask, H, P):
     """nnet/attentions.py:348-382: pad to multiple of P, min-pool mask, avg-pool x (divisor P,
     zeros included), attention on ceil(T/P) tokens, nearest upsample xP, slice to T."""
@@ -230,11 +288,13 @@ def conv_module(sd, prefix, x, stride, train, stats_out, causal=False):
     return F.linear(h, sd[prefix + ".layers.6.weight"][:, :, 0], sd[prefix + ".layers.6.bias"])
 
 
-def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out, causal_conv=False):
-    """nnet/blocks.py:289-306."""
+def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out, causal_conv=False, group=0):
+    """nnet/blocks.py:289-306.  group > 0: GroupedRelPosMultiHeadSelfAttention with that group size (Transformer-XL biases), else patch / plain rel-pos attention."""
     x = x + 0.5 * feed_forward(sd, prefix + ".ff_module1", x)
     h = layer_norm(sd, prefix + ".self_att_module.norm", x)
-    if patch > 1:
+    if group > 0:
+        a = grouped_rel_pos_attention(sd, prefix + ".self_att_module.attention", h, mask, H, group)
+    elif patch > 1:
         a = patch_attention(sd, prefix + ".self_att_module.attention", h, mask, H, patch)
     else:
         a = rel_pos_attention(sd, prefix + ".self_att_module.attention", h, mask, H)
@@ -251,8 +311,9 @@ def conformer_block(sd, prefix, x, mask, H, patch, train, stats_out, causal_conv
 
 
 def conformer_interctc(sd, prefix, x, lengths, num_blocks, interctc_blocks, loss_prefix, patch_sizes,
-                       train, stats_out, H=4, context=None, causal_conv=False):
-    """nnet/networks.py:262-307.  context = (left_context, right_context, mask_start) of a streaming Mask, or None for the key-padding mask."""
+                       train, stats_out, H=4, context=None, causal_conv=False, group_sizes=None):
+    """nnet/networks.py:262-307.  context = (left_context, right_context, mask_start) of a streaming Mask, or None for the key-padding mask.
+    group_sizes: per stage, the group size of GroupedRelPosMultiHeadSelfAttention (att_type="grouped", nnet/networks.py:389-392) instead of patch / plain attention."""
     T = x.shape[1]
     if context is not None:
         mask = context_mask(T, lengths, *context)
@@ -263,7 +324,7 @@ def conformer_interctc(sd, prefix, x, lengths, num_blocks, interctc_blocks, loss
     for stage, nb in enumerate(num_blocks):
         for _ in range(nb):
             x, stride = conformer_block(sd, f"{prefix}.conformer_blocks.{i}", x, mask, H,
-                                        patch_sizes[stage], train, stats_out, causal_conv)
+                                        patch_sizes[stage], train, stats_out, causal_conv, group=group_sizes[stage] if group_sizes else 0)
             logits = None
             if i + 1 in interctc_blocks:
                 p = f"{prefix}.interctc_modules.{j}"
@@ -389,13 +450,13 @@ def softmax_cross_entropy(logits, targets, ignore_index=-1):
     return torch.where(keep, nll, torch.zeros_like(nll)).mean()
 
 
-def ao_forward(sd, audio, audio_len, train=True, stats_out=None, interctc=(3, 6, 10, 13), num_blocks=(5, 6, 5)):
-    """nnet/models_zoo.py:64-97 + nnet/networks.py:411-440 (att_type='patch')."""
+def ao_forward(sd, audio, audio_len, train=True, stats_out=None, interctc=(3, 6, 10, 13), num_blocks=(5, 6, 5), att_type="patch"):
+    """nnet/models_zoo.py:64-97 + nnet/networks.py:411-440 (att_type 'patch', or 'grouped': group sizes 3, 1, 1)."""
     p = "encoder"
     mel, alen = mel_frontend(audio, audio_len)
     a, alen = audio_stem(sd, p, mel, alen, train, stats_out)
     a, alen, inter = conformer_interctc(sd, p + ".back_end", a, alen, list(num_blocks), interctc, "ctc",
-                                        [3, 1, 1], train, stats_out)
+                                        [3, 1, 1] if att_type == "patch" else [1, 1, 1], train, stats_out, group_sizes=[3, 1, 1] if att_type == "grouped" else None)
     x = linear(sd, p + ".head", a)
     out = {"outputs": [x, alen]}
     out.update(inter)

@@ -367,7 +367,54 @@ def streaming_case():
          grads=grads_of(net))
 
 
+def grouped_case():
+    """SURVEY a11 + the key/value cache of 8f rank 4: GroupedRelPosMultiHeadSelfAttention (nnet/attentions.py:556-650; group sizes 3 and 1 as AudioEfficientConformerEncoder
+    (att_type="grouped") uses them, nnet/networks.py:389-392) inside a ConformerBlock (forward, input and parameter gradients), and the attention layer alone decoding
+    two chunks with `hidden` (outputs, attention weights, cache)."""
+    for name, D, T, G, lens, seed in (("block_grouped3", 36, 20, 3, [20, 14, 5], 41), ("block_grouped1", 32, 17, 1, [17, 9], 42), ("block_grouped2", 32, 15, 2, [15, 8], 43)):
+        torch.manual_seed(seed)
+        att = {"class": "GroupedRelPosMultiHeadSelfAttention", "params": {"num_heads": 4, "group_size": G, "attn_drop_rate": 0.0, "max_pos_encoding": 64, "causal": False}}
+        blk = nodrop(nnet.ConformerBlock(dim_model=D, dim_expand=D, ff_ratio=4, att_params=att, drop_rate=0.1, conv_stride=1, conv_params=CONV)).train()
+        with torch.no_grad():
+            for k, p in blk.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))          # also makes u, v non-zero
+        sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        x = torch.randn(len(lens), T, D, requires_grad=True)
+        lengths = torch.tensor(lens)
+        mask = nnet.Mask()(x, lengths)
+        y = blk(x, mask=mask)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        save(name, x=x, lengths=lengths, mask=mask, y=y, w=w, dx=x.grad, sd=sd0, grads=grads_of(blk), meta=np.array([D, D, T, 1, G, 4]))
+    # two-chunk decoding with the key/value cache (inference)
+    for name, D, G, T1, T2, seed in (("attn_hidden_g1", 32, 1, 9, 6, 44), ("attn_hidden_g3", 36, 3, 9, 7, 45)):
+        torch.manual_seed(seed)
+        att = nnet.GroupedRelPosMultiHeadSelfAttention(dim_model=D, num_heads=4, attn_drop_rate=0.0, max_pos_encoding=64, group_size=G, causal=False).eval()
+        with torch.no_grad():
+            att.u.add_(0.3 * torch.randn(D)); att.v.add_(0.3 * torch.randn(D))
+            for p in att.parameters():
+                if p.dim() == 1:
+                    p.add_(0.05 * torch.randn_like(p))
+            x1, x2 = torch.randn(2, T1, D), torch.randn(2, T2, D)
+            o1, w1, h1 = att.forwardQKV(x1, x1, x1, mask=None, return_att_w=True)
+            o2, w2, h2 = att.forwardQKV(x2, x2, x2, mask=None, return_att_w=True, hidden=h1)
+        save(name, x1=x1, x2=x2, o1=o1, w1=w1, o2=o2, w2=w2, h1K=h1["K"], h1V=h1["V"], h2K=h2["K"], h2V=h2["V"], sd=att.state_dict(), meta=np.array([D, G, T1, T2, 4]))
+    # the audio encoder with att_type="grouped": state_dict keys / shapes and the seeded initialisation
+    torch.manual_seed(0)
+    enc = nnet.AudioEfficientConformerEncoder(att_type="grouped", interctc_blocks=[])
+    sd = enc.state_dict()
+    json.dump({"keys": list(sd.keys()), "shapes": [list(v.shape) for v in sd.values()],
+               "probe": {k: float(sd[k].double().sum()) for k in list(sd.keys())[::37] if sd[k].is_floating_point()}, "n_params": sum(p.numel() for p in enc.parameters())},
+              open(os.path.join(HERE, "ao_grouped_state.json"), "w"))
+    print("wrote ao_grouped_state.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "grouped":
+        grouped_case()
+        sys.exit(0)
+
     if len(sys.argv) > 1 and sys.argv[1] == "video_input":
         video_input_case()
         sys.exit(0)
@@ -397,3 +444,4 @@ if __name__ == "__main__":
     full_model_case()
     video_input_case()
     streaming_case()
+    grouped_case()

@@ -133,3 +133,25 @@ def test_lrw_classifier_api_and_seeded_init_match_reference():
         v = sd[k].double()
         assert abs(float(v.sum()) - s1) <= 1e-6 * max(1.0, abs(s1)) and abs(float(v.abs().sum()) - s2) <= 1e-6 * max(1.0, abs(s2)), k
     assert nnet.CategoricalAccuracy()(torch.tensor([1, 2, -1]), torch.tensor([[0., 1., 0.], [0., 1., 0.], [1., 0., 0.]])) == 50.0
+
+
+def test_grouped_audio_encoder_state_dict_and_init_match_reference():
+    """AudioEfficientConformerEncoder(att_type="grouped") (nnet/networks.py:389-392): same state_dict keys / shapes, same parameter count and the same seeded
+    initialisation (scaled_uniform weights, zero biases, zero u / v) as the reference (tests/golden/ao_grouped_state.json)"""
+    import json
+    import os
+    import nnet
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ao_grouped_state.json")))
+    torch.manual_seed(0)
+    enc = nnet.AudioEfficientConformerEncoder(att_type="grouped", interctc_blocks=[])
+    sd = enc.state_dict()
+    ref_keys = [k for k in g["keys"] if not k.endswith(("Spectrogram.window", "MelScale.fb"))]
+    mine = [k for k in sd.keys() if not k.endswith(("Spectrogram.window", "MelScale.fb"))]
+    assert mine == ref_keys
+    for k, shp in zip(g["keys"], g["shapes"]):
+        if k in sd:
+            assert list(sd[k].shape) == shp, k
+    assert sum(p.numel() for p in enc.parameters()) == g["n_params"]
+    for k, v in g["probe"].items():
+        if k in sd:
+            assert abs(float(sd[k].double().sum()) - v) <= 1e-6 * max(1.0, abs(v)), k

@@ -233,3 +233,35 @@ def test_oracle_fullsize_vs_reference_itself():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "check_oracle_fullsize.py")], cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "ORACLE FULL-SIZE CHECK: PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["block_grouped3", "block_grouped1", "block_grouped2"])
+def test_grouped_attention_block(name):
+    """ConformerBlock with GroupedRelPosMultiHeadSelfAttention (group sizes 3 / 1 / 2) -- oracle against the reference's output and gradients"""
+    g = load_npz(name)
+    D, De, T, stride, G, H = [int(v) for v in g["meta"]]
+    sd = _grad_sd(prefixed(g["sd"]))
+    x = g["x"].clone().requires_grad_(True)
+    y, s = O.conformer_block(sd, "m", x, g["mask"], H, 1, True, {}, group=G)
+    assert rel_err(y, g["y"]) < TOL
+    (y * g["w"]).sum().backward()
+    assert rel_err(x.grad, g["dx"]) < 1e-4
+    for k, gr in g["grads"].items():
+        if k.endswith("conv_module.layers.3.bias") or (k.endswith(("key_layer.bias", "pos_layer.bias")) and gr.abs().max() < 1e-4):
+            # analytically zero: bias before BatchNorm; key / position bias = a per-query constant on every score -- the key bias only when no frame was zero-padded
+            # AFTER the projection (T % G == 0)
+            assert sd["m." + k].grad.abs().max() < 1e-4 and gr.abs().max() < 1e-4
+            continue
+        assert rel_err(sd["m." + k].grad, gr) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["attn_hidden_g1", "attn_hidden_g3"])
+def test_grouped_attention_hidden_cache(name):
+    """the key/value cache of the Transformer-XL / grouped attention (nnet/attentions.py:506-512, :588-600): two chunks, outputs + attention weights + caches"""
+    g = load_npz(name)
+    D, G, T1, T2, H = [int(v) for v in g["meta"]]
+    sd = prefixed(g["sd"])
+    o1, w1, h1 = O.grouped_rel_pos_attention(sd, "m", g["x1"], None, H, G, return_hidden=True)
+    o2, w2, h2 = O.grouped_rel_pos_attention(sd, "m", g["x2"], None, H, G, hidden=h1, return_hidden=True)
+    for got, ref in ((o1, g["o1"]), (w1, g["w1"]), (o2, g["o2"]), (w2, g["w2"]), (h1["K"], g["h1K"]), (h1["V"], g["h1V"]), (h2["K"], g["h2K"]), (h2["V"], g["h2V"])):
+        assert got.shape == ref.shape and rel_err(got, ref) < TOL
