@@ -26,7 +26,12 @@ class LRS(torch.utils.data.Dataset):
         g = torch.Generator().manual_seed(self.seed * 100003 + n)
         ta = int(16000 * self.durations[n])
         tv = ta // 640 + 1
-        video = torch.randn(tv, 88, 88, 1, generator=g)
+        if self.video_transform is not None:
+            # as the reference pipeline hands it over (nnet/datasets.py:187-196,348-352): normalised grayscale (1, T, 96, 96) -> config transform (crop 88x88, flip,
+            # time masks) -> (T, 88, 88, 1).  The clip has the frames of its video track; align_video_to_audio pads to Ta // 640 + 1 afterwards
+            video = self.video_transform(torch.randn(1, tv, 96, 96, generator=g)).permute(1, 2, 3, 0).contiguous()
+        else:
+            video = torch.randn(tv, 88, 88, 1, generator=g)
         audio = 0.1 * torch.randn(ta, generator=g)
         L = max(1, math.ceil(2.4 * self.durations[n]))
         label = torch.randint(1, 256, (L,), generator=g)

@@ -13,6 +13,10 @@ _STATE = {"dtype": None, "rng": {}, "stream_id": 0, "seed": 0x5EED5EED, "sync_bn
 
 def set_compute_dtype(name):
     """'f32' : fp32 storage + fp32 MFMA (exact, parity mode);  'bf16' : bf16 storage + bf16 MFMA, fp32 accumulate."""
+    if name is torch.float16 and not _STATE.get("warned_fp16"):
+        _STATE["warned_fp16"] = True
+        print("[avec_amd] precision torch.float16 (the reference configs' AMP dtype) runs as bf16 storage + bf16 MFMA with fp32 accumulation on MI355X: "
+              "same 16-bit traffic, fp32 exponent range, no GradScaler")
     name = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "bf16"}.get(name, name)
     assert name in ("f32", "bf16"), name
     _STATE["dtype"] = name

@@ -19,6 +19,8 @@ import functions  # noqa: E402
 
 
 def load_config(path):
+    from avec_amd.compat import ensure_torchvision
+    ensure_torchvision()              # configs do `import torchvision` for three transform classes: a stand-in when the package is absent (avec_amd/compat)
     spec = importlib.util.spec_from_file_location("avec_config", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
