@@ -342,13 +342,13 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ out, unsigned char* __restrict__ idx,
-                                                            long long Fr, int H, int W, int C, int OH, int OW) {
+                                                            T* __restrict__ ymax, long long Fr, int H, int W, int C, int OH, int OW) {
   const long long n4 = Fr * OH * OW * (C / 4);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const unsigned iu = (unsigned)i, C4 = (unsigned)C >> 2;      // host-checked: fewer than 2^31 work items -> 32-bit divisions
     const int c = (int)(iu % C4) * 4; unsigned r = iu / C4; const int ow = (int)(r % (unsigned)OW); r /= (unsigned)OW; const int oh = (int)(r % (unsigned)OH); const long long fr = r / (unsigned)OH;
     float sc[4], sh[4]; ld4<float>(ss + c, sc); ld4<float>(ss + C + c, sh);
-    float best[4] = {0.f, 0.f, 0.f, 0.f}; unsigned bi[4] = {255u, 255u, 255u, 255u};
+    float best[4] = {0.f, 0.f, 0.f, 0.f}, braw[4] = {0.f, 0.f, 0.f, 0.f}; unsigned bi[4] = {255u, 255u, 255u, 255u};
     float v[9][4]; bool ok[9];                          // unconditional (clamped) loads first: loads under divergent `continue`s are serialised
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -358,8 +358,9 @@ __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict_
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q)
-      for (int e = 0; e < 4; ++e) { const float a = v[q][e] * sc[e] + sh[e]; if (ok[q] && a > best[e]) { best[e] = a; bi[e] = q; } }
+      for (int e = 0; e < 4; ++e) { const float a = v[q][e] * sc[e] + sh[e]; if (ok[q] && a > best[e]) { best[e] = a; bi[e] = q; braw[e] = v[q][e]; } }
     st4<T>(out + i * 4, best);
+    if (ymax) st4<T>(ymax + i * 4, braw);              // the conv output under the winning tap: lets the backward statistics pass run over the pooled domain
     *(uint32_t*)(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
   }
 }
@@ -514,12 +515,51 @@ extern "C" int avec_stem_im2col(int dtype, const float* video, void* A, long lon
   DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3((unsigned)nb), dim3(256), lds, st, video, (T*)A, T_, H, W, OH, OW, ldk, WP));
   AVEC_LAUNCH_CHECK(); return 0;
 }
-extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t st) {
+extern "C" int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, void* ymax, long long frames, int H, int W, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && idx && frames > 0 && H > 0 && W > 0 && C % 4 == 0 && frames * H * W * (C / 4) < (1ll << 31), "stem_pool_fwd: bad arguments");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1; long long n4 = frames * OH * OW * (C / 4); long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)out, idx, frames, H, W, C, OH, OW));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)out, idx, (T*)ymax, frames, H, W, C, OH, OW));
   AVEC_LAUNCH_CHECK(); return 0;
 }
+// BatchNorm-backward statistics of the stem over the POOLED domain: the gradient of the BN output is non-zero only where a max-pool window picked its winner, and
+// the forward pass kept that winner's pre-BN value (ymax): dstats[c] += sum dp, dstats[C + c] += sum dp * (ymax - mean) * rstd over the pooled elements with a winner.
+// Reads dp + idx + ymax (0.5 GB at the bench shape) instead of the whole 0.8 GB conv output plus the gathered gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_reduce_pooled_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx, const T* __restrict__ ymax,
+                                                                          const float* __restrict__ ss, float* dstats, long long P, int C, ColWs ws) {
+  const Col8 m = col8_map(C);
+  float part[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[0][e] = part[1][e] = 0.f;
+  if (m.active) {
+    const int c = m.l * 8;
+    float mu[8], rs[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
+    for (long long row = (long long)blockIdx.x * m.R + m.r; row < P; row += (long long)gridDim.x * m.R) {
+      float g[8], v[8]; ld8<T>(dp + row * C + c, g); ld8<T>(ymax + row * C + c, v);
+      const uint2 sel = *(const uint2*)(idx + row * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned q = ((e < 4 ? sel.x : sel.y) >> (8 * (e & 3))) & 255u;
+        const float d = q != 255u ? g[e] : 0.f;
+        part[0][e] += d; part[1][e] += d * (v[e] - mu[e]) * rs[e];
+      }
+    }
+  }
+  float* const dst[2] = {dstats, dstats + C};
+  colreduce8_atomic<2>(part, dst, m, ws);
+}
+extern "C" int avec_stem_pool_bwd_reduce_pooled(int dtype, const void* dpool, const unsigned char* idx, const void* ymax, const float* ss, float* dstats,
+                                                long long frames, int H, int W, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dpool && idx && ymax && ss && dstats && frames > 0 && C % 8 == 0 && C <= 2048, "stem_pool_bwd_reduce_pooled: bad arguments (C %% 8 == 0, C <= 2048)");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long P = frames * OH * OW;
+  ColWs ws; const unsigned nb8 = col8_cfg(P, C, 2, &ws, st);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_reduce_pooled_kernel<T>, dim3(nb8), dim3(256), 0, st, (const T*)dpool, idx, (const T*)ymax, ss, dstats, P, C, ws));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb8, 2, C, dst, C, st); }
+  return 0;
+}
+
 extern "C" int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                                   const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dpool && idx && y && ss && gamma && dstats && (phase == 0 || dy) && frames > 0 && C % 4 == 0 && frames * H * W * (C / 4) < (1ll << 31), "stem_pool_bwd: bad arguments");

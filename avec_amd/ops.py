@@ -1219,18 +1219,22 @@ class VideoStemFn(torch.autograd.Function):
         PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
         out = empty((B * T, PH, PW, C), rt.act_dtype(), v)
         idx = torch.empty((B * T, PH, PW, C), dtype=torch.uint8, device=v.device)
-        lib.stem_pool_fwd(rt.dt(), y.data_ptr(), st.ss.data_ptr(), out.data_ptr(), idx.data_ptr(), B * T, OH, OW, C, rt.stream())
-        ctx.saved = (v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training)
+        ymax = torch.empty_like(out) if (training and C % 8 == 0) else None           # winners' pre-BN values: the backward statistics pass then reads pooled-size tensors only
+        lib.stem_pool_fwd(rt.dt(), y.data_ptr(), st.ss.data_ptr(), out.data_ptr(), idx.data_ptr(), _p(ymax), B * T, OH, OW, C, rt.stream())
+        ctx.saved = (v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training, ymax)
         return out
 
     @staticmethod
     def backward(ctx, dpool):
-        v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training = ctx.saved
+        v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training, ymax = ctx.saved
         assert training, "VideoStem backward is implemented for training-mode BatchNorm"
         dpool = dpool.to(rt.act_dtype()).contiguous()
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
         args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
-        lib.stem_pool_bwd(rt.dt(), *args, 0, None, None, None, B * T, OH, OW, C, rt.stream())
+        if ymax is not None:
+            lib.stem_pool_bwd_reduce_pooled(rt.dt(), dpool.data_ptr(), idx.data_ptr(), ymax.data_ptr(), st.ss.data_ptr(), dstats.data_ptr(), B * T, OH, OW, C, rt.stream())
+        else:
+            lib.stem_pool_bwd(rt.dt(), *args, 0, None, None, None, B * T, OH, OW, C, rt.stream())
         gw, gb = grad_of(bn.weight), grad_of(bn.bias)
         dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
         if synced:

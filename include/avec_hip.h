@@ -245,7 +245,11 @@ int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, in
 int avec_stem3d_supported(long long clips, int T, int H, int W);
 int avec_stem3d_fwd(const float* video, const void* w_shadow, int ldw, const float* bias, void* y, float* stats, long long clips, int T, int H, int W, hipStream_t stream);
 int avec_stem3d_wgrad(const float* video, const void* dy, float* dw, long long clips, int T, int H, int W, hipStream_t stream);
-int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, long long frames, int H, int W, int C, hipStream_t stream);
+/* ymax (optional, act, pooled shape): the conv output under each window's winning tap -- lets avec_stem_pool_bwd_reduce_pooled compute the BatchNorm-backward sums from
+ * pooled-size tensors instead of the full-resolution conv output */
+int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, void* ymax, long long frames, int H, int W, int C, hipStream_t stream);
+int avec_stem_pool_bwd_reduce_pooled(int dtype, const void* dpool, const unsigned char* idx, const void* ymax, const float* ss, float* dstats,
+                                     long long frames, int H, int W, int C, hipStream_t stream);
 int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, const void* y, const float* ss, const float* gamma, float* dstats,
                        const float* count_ptr, float count, int phase, void* dy, float* dgamma, float* dbeta, long long frames, int H, int W, int C, hipStream_t stream);
 
