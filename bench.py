@@ -75,13 +75,20 @@ def cpu_baseline(budget_s=28.0, B=8, thread_counts=(8, 16, 32, 64)):
                       "the reference itself measured 1.79 utt/s on 8 Xeon cores at B=2 (BASELINE.md section 3, build container)" % (B, sweep, ncpu)}
 
 
+def pmc_summary_path():
+    """newest committed profiles/rNN_pmc_traffic.json (one per round), or None"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return found[-1] if found else None
+
+
 def pmc_traffic(family):
-    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 --pmc summary (profiles/r01_pmc_traffic.json, made by
+    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 --pmc summary (newest profiles/rNN_pmc_traffic.json, made by
     tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950).  None when the summary is absent or has no kernel of that family."""
     import re
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not family or not os.path.exists(path):
+    path = pmc_summary_path()
+    if not family or path is None:
         return None
     if family.startswith("conv3x3"):
         ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith("conv3x3_c64_kernel") or k.startswith("wgrad3x3_c64_kernel")]
@@ -216,7 +223,7 @@ def main():
         roof = ops.KERNEL_TIMER.summary(peak)
         if roof is not None and args.dtype == "bf16" and args.batch == 32:
             roof["traffic"] = pmc_traffic(roof["kernel"])
-            roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/%s)" % os.path.basename(pmc_summary_path() or "none")
         out = {
             "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
