@@ -18,6 +18,12 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// kernel ablation builds (tools/build_abl.sh): bit 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no barrier, 16 no global stores, 32 no epilogue,
+// 64 / 128 no A / B DMA of the shifted-window kernel.  0 in the product.
+#ifndef AVEC_ABL
+#define AVEC_ABL 0
+#endif
+
 static constexpr int BKB = 128;      // bytes of K per LDS tile row
 static constexpr int LDS_ROW = 144;  // padded LDS row stride in bytes
 
@@ -132,7 +138,21 @@ struct Epi {
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
 };
 
-struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv; };   // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
+struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
+                  // parity classes (backward-data of a stride-2 convolution, glds kernel): input pixels are visited class by class, class = (ih & 1) * 2 + (iw & 1);
+                  // inside a class every row uses the same taps (kh = ih + pad mod 2, kw likewise), so a tile runs only those K-steps: 9 of 36 tap-rows for 3x3
+                  int perm2, pTs[5]; long long pImgs; };     // pTs: first tile of each class (pTs[4] = grid size), pImgs: images
+
+__device__ __host__ __forceinline__ long long perm2_count(const RowSrc& s, int cls, long long imgs) {      // pixels of a class
+  return imgs * ((s.H + 1 - (cls >> 1)) >> 1) * ((s.W + 1 - (cls & 1)) >> 1);
+}
+
+// parity-class order -> pixel (img, ih, iw) of class-local index mc
+__device__ __forceinline__ void perm2_pixel(const RowSrc& s, int cls, long long mc, long long& img, int& ih, int& iw) {
+  const int Wc = (s.W + 1 - (cls & 1)) >> 1, Hc = (s.H + 1 - (cls >> 1)) >> 1;
+  const int bq = (int)(mc % Wc); const long long t = mc / Wc; const int aq = (int)(t % Hc); img = t / Hc;
+  ih = 2 * aq + (cls >> 1); iw = 2 * bq + (cls & 1);
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -166,8 +186,16 @@ __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wm,
 
 // ---- shared epilogue of the NT kernels ----
 template <typename T, int BM, int BN, int MT, int NT>
-__device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, long long m0, int n0, int tid, int lane, int wm, int wn) {
+__device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, long long m0, int n0, int tid, int lane, int wm, int wn, int perm_cls = 0) {
   // ---- epilogue: accumulators -> LDS (64-row passes) -> coalesced 4-wide rows with fused bias/act/dropout/residual/stats ----
+#if AVEC_ABL
+  if (AVEC_ABL & 32) {            // (every accumulator stays live: no dead-code elimination of the main loop)
+    float sacc = 0.f;
+    for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 1234.5f) ((float*)g.e.out)[0] = 1.f;
+    return;
+  }
+#endif
   const Epi& e = g.e;
   constexpr int CLD = BN + 4;                 // fp32 row stride of the staged C tile
   constexpr int TPR = BN / 4;                 // threads per tile row
@@ -183,23 +211,32 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
   float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int pass = 0; pass < BM / 64; ++pass) {
-    if (BM == 64 || wm == pass) {
+    // a wave owns BM/2 rows = MT 32-row blocks; a pass stages 64 tile rows: both waves' single block (BM 64), one wave's two blocks (BM 128),
+    // or one half of a wave's four blocks (BM 256).  The block index stays a compile-time constant (no indexed register access).
+    if (BM == 64 || wm == pass / (BM / 128 > 0 ? BM / 128 : 1)) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
+        if (BM == 256 && (i >> 1) != (pass & 1)) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int lr = (BM == 64 ? wm * 32 : 0) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int lr = (BM == 64 ? wm * 32 : 0) + (i & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             Cs[lr * CLD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
           }
+      }
     }
     __syncthreads();
     // 4-wide vector I/O whenever the 4 columns are inside N and every row stride keeps them 8/16-byte aligned
     const bool v4 = vec_ok && !(e.ldo & 3) && !(e.ldpre & 3) && !(e.ldres & 3) && !(e.ldz & 3);
 #pragma unroll 1
     for (int lr = tid / TPR; lr < 64; lr += 256 / TPR) {
-      const long long row = m0 + pass * 64 + lr;
+      long long row = m0 + pass * 64 + lr;
+      if (g.perm2) {                            // m0 is class-local here: map to the pixel's row of the output
+        if (row >= perm2_count(g.a, perm_cls, g.pImgs) || col >= g.N) continue;
+        long long img; int ih, iw; perm2_pixel(g.a, perm_cls, row, img, ih, iw);
+        row = (img * g.a.H + ih) * (long long)g.a.W + iw;
+      }
       if (row >= g.M || col >= g.N) continue;
       float v[4];
       { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -220,6 +257,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
           if (e.res_act) ld4<T>((const T*)e.res + row * e.ldres + col, r4); else ld4<float>((const float*)e.res + row * e.ldres + col, r4);
           for (int c = 0; c < 4; ++c) v[c] += r4[c];
         }
+#if AVEC_ABL
+        if (AVEC_ABL & 16) { if (v[0] == 1234.5f) st4<T>((T*)e.out + row * e.ldo + col, v); continue; }
+#endif
         if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
         continue;
       }
@@ -257,7 +297,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
       for (int c = 0; c < 4; ++c) { red[(wv * 2 + 0) * BN + cg + c] = csum[c]; red[(wv * 2 + 1) * BN + cg + c] = csq[c]; }
     }
     __syncthreads();
-    if (tid < 2 * BN) { float t = 0.f; for (int w = 0; w < 4; ++w) t += red[(w * 2) * BN + tid]; red[8 * BN + tid] = t; }   // [sum | sq] totals behind the partials
+    for (int c = tid; c < 2 * BN; c += 256) { float t = 0.f; for (int w = 0; w < 4; ++w) t += red[(w * 2) * BN + c]; red[8 * BN + c] = t; }   // [sum | sq] totals behind the partials
     __syncthreads();
     red += 8 * BN;
     if (tid < BN && n0 + tid < g.N) {
@@ -354,7 +394,7 @@ template <int RB> __device__ __forceinline__ int glds_swz(int row) { return RB =
 
 // RB: bytes of K per LDS row (128: 8 chunks, swizzle (row>>1)&7;  64: 4 chunks, swizzle (row>>2)&3 -- half the ring, twice the resident workgroups)
 template <typename T, int BM, int BN, int MODE, int STAGES, bool FASTC = false, int RB = 128>
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_glds_kernel(GemmArgs g) {
   static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
   constexpr int VEC = Elt<T>::VEC;
   constexpr int KE = RB / (int)sizeof(T);
@@ -365,12 +405,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  constexpr bool PERM = MODE == MODE_CONV_BWD && FASTC;        // parity-class order possible (g.perm2 says whether it is on)
+  const bool perm = PERM && g.perm2;
+  const int cls = perm ? ((int)blockIdx.x >= g.pTs[2] ? ((int)blockIdx.x >= g.pTs[3] ? 3 : 2) : ((int)blockIdx.x >= g.pTs[1] ? 1 : 0)) : 0;
+  const long long m0 = perm ? (long long)((int)blockIdx.x - g.pTs[cls]) * BM : (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  const long long pMc = perm ? perm2_count(g.a, cls, g.pImgs) : 0;
   // chunk c = tid + i*256 of a tile -> row c>>3, physical slot c&7; it carries logical K-chunk (c&7) ^ ((row>>1)&7)
   RowInfo ra[NCA]; RowInfo rb[NCB]; int ka[NCA], kb[NCB];
   RowSrc ws; ws.ptr = g.W; ws.ld = g.ldw; ws.step = 0; ws.rows_out = ws.rows_in = 1;
 #pragma unroll
-  for (int i = 0; i < NCA; ++i) { const int row = tid / CPR + i * RPP; ra[i] = row_info<MODE>(g.a, m0 + row, g.M); ka[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC; }
+  for (int i = 0; i < NCA; ++i) {
+    const int row = tid / CPR + i * RPP;
+    if (perm) {
+      RowInfo r; r.valid = m0 + row < pMc; r.base = 0; r.a = 0; r.b = 0;
+      if (r.valid) { long long img; int ih, iw; perm2_pixel(g.a, cls, m0 + row, img, ih, iw); r.base = img * (long long)g.a.OH * g.a.OW * g.a.C; r.a = ih + g.a.pad; r.b = iw + g.a.pad; }
+      ra[i] = r;
+    } else ra[i] = row_info<MODE>(g.a, m0 + row, g.M);
+    ka[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC;
+  }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) { const int row = tid / CPR + i * RPP; rb[i] = row_info<MODE_PLAIN>(ws, n0 + row, g.N); kb[i] = ((tid % CPR) ^ glds_swz<RB>(row)) * VEC; }
   // fast convolution addressing (host-checked: C % KE == 0 so a K-step lies inside one tap, <= 32 taps, < 2^31 source elements, backward
@@ -407,9 +459,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const int KT = (g.K + KE - 1) / KE;
+  int KT = (g.K + KE - 1) / KE;
   int f_tap = 0, f_kh = 0, f_kw = 0, f_c0 = 0;       // fast path: running (tap, kh, kw, channel offset) of the next K-step to be issued (issue() is called with kt = 0, 1, 2, ...)
+  unsigned tapmask = 0xffffffffu;                    // parity classes: the taps this tile's class can reach (wave-uniform); the others are skipped
+  if (perm) {
+    tapmask = 0u; int ntap = 0;
+    for (int kh = 0; kh < g.a.KH; ++kh)
+      for (int kw = 0; kw < g.a.KW; ++kw)
+        if (!((((cls >> 1) + g.a.pad - kh) | ((cls & 1) + g.a.pad - kw)) & 1)) { tapmask |= 1u << (kh * g.a.KW + kw); ++ntap; }
+    KT = ntap * (g.a.C / KE);
+    while (f_tap < g.a.KH * g.a.KW && !((tapmask >> f_tap) & 1u)) { ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } }
+  }
   auto issue = [&](int kt, int buf) {
+    if (AVEC_ABL & 2) return;
     char* As = smem + buf * TILE; char* Bs = As + BM * RB;
     if (fast) {
       const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;
@@ -421,8 +483,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
         const void* src = ((rmask[i] >> f_tap) & 1u) ? (const void*)sp : (const void*)avec_zero16;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
       }
-      f_c0 += KE;
-      if (f_c0 >= g.a.C) { f_c0 = 0; ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } }
     } else {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
@@ -439,11 +499,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
     }
     }
+    const int kbase = fast ? f_tap * g.a.C + f_c0 : kt * KE;       // (fast: the K offset follows the tap actually issued)
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
-      const int k = kt * KE + kb[i];
+      const int k = kbase + kb[i];
       const void* src = (rb[i].valid && k < g.K) ? (const void*)((const T*)g.W + rb[i].base + k) : (const void*)avec_zero16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+    if (fast) {
+      f_c0 += KE;
+      if (f_c0 >= g.a.C) {
+        f_c0 = 0;
+        do { ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } } while (PERM && f_tap < 32 && !((tapmask >> f_tap) & 1u));
+      }
     }
   };
   // fragment addressing: lane (row = lane&31 within a 32-row block, k-half g = lane>>5), K-substep kk: logical chunk 2*kk + g
@@ -470,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
     else if (newer == 4) AVEC_WAIT_VM(4 * LPT);
     else if (newer == 5) AVEC_WAIT_VM(5 * LPT);
     else AVEC_WAIT_VM(6 * LPT);
-    __builtin_amdgcn_s_barrier();
+    if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
     const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * RB;
@@ -483,9 +551,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < KG; ++q) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[q][i] = *(const chunk16*)(As + offa[i] + ((((k0 + q) * 2 + gsel) ^ swa[i]) << 4));
+        for (int i = 0; i < MT; ++i) { if (AVEC_ABL & 4) { fa[q][i].w[0] = fa[q][i].w[1] = fa[q][i].w[2] = fa[q][i].w[3] = kt + i; } else fa[q][i] = *(const chunk16*)(As + offa[i] + ((((k0 + q) * 2 + gsel) ^ swa[i]) << 4)); }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[q][j] = *(const chunk16*)(Bs + offb[j] + ((((k0 + q) * 2 + gsel) ^ swb[j]) << 4));
+        for (int j = 0; j < NT; ++j) { if (AVEC_ABL & 4) { fb[q][j].w[0] = fb[q][j].w[1] = fb[q][j].w[2] = fb[q][j].w[3] = kt + j; } else fb[q][j] = *(const chunk16*)(Bs + offb[j] + ((((k0 + q) * 2 + gsel) ^ swb[j]) << 4)); }
       }
       asm volatile("" ::: "memory");            // keeps the reads above the MFMAs (the scheduler otherwise sinks each pair next to its consumer)
 #pragma unroll
@@ -493,11 +561,166 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) Mma<T>::run(fa[q][i], fb[q][j], acc[i][j]);
+          for (int j = 0; j < NT; ++j) {
+            if (AVEC_ABL & 1) { asm volatile("" :: "v"(fa[q][i].w[0]), "v"(fa[q][i].w[1]), "v"(fa[q][i].w[2]), "v"(fa[q][i].w[3]), "v"(fb[q][j].w[0]), "v"(fb[q][j].w[1]), "v"(fb[q][j].w[2]), "v"(fb[q][j].w[3])); }
+            else Mma<T>::run(fa[q][i], fb[q][j], acc[i][j]);
+          }
     }
   }
 #undef AVEC_WAIT_VM
   __syncthreads();                            // every wave is done with the ring before the epilogue reuses the LDS
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, cls);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 / pad-1 convolution (forward and backward-data), bf16, as a SHIFTED-WINDOW implicit GEMM.
+// The tile rows are BM consecutive pixels p of the NHWC tensor; tap (kh, kw) of pixel p reads pixel p + s, s = (kh-1)*W + (kw-1)
+// (backward-data: p - s), so all nine A tiles of one 32-channel chunk are shifted views of ONE window of BM + 2(W+1) pixels.  The
+// window is fetched once per chunk (LDS-DMA, double-buffered) instead of once per tap: the A operand crosses L2 -> LDS 1.2x instead
+// of 9x (the im2col gather of gemm_nt_glds_kernel: ablation showed that kernel bound by the LDS-DMA, 135-160 us of loads alone for
+// 95-103 us of MFMA + fragment reads).  Taps that fall outside the image are removed by a per-row 9-bit mask applied to the A
+// fragments (4 v_cndmask per fragment).  K order = chunk-major, tap-minor; B tiles ([BN][32 channels] of tap t) ride a 3-stage ring.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ u32x4 lds_read128(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
+  typedef bf16 T;
+  constexpr int RB = 64, KE = 32, STAGES = 3;
+  constexpr int NCB = BN / 64, NA = (BM + 64) / 64;           // DMA passes (64 rows of 64 B each) per B tile / per A window
+  constexpr int WROWS = BM + 64;                              // window rows: BM + 2 * halo, halo = W + 1 <= 32
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int BTILE = BN * RB, AWIN = WROWS * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Bring = smem; char* const Awin = smem + STAGES * BTILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  const int Wd = g.a.W, H = g.a.H, C = g.a.C, halo = Wd + 1;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // DMA descriptors: window row wr = i*64 + tid/4 holds source pixel m0 - halo + wr; physical slot tid%4 carries logical chunk slot ^ swz(row)
+  int aoff[NA], boff[NCB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int wr = i * 64 + (tid >> 2); const long long p = m0 - halo + wr;
+    aoff[i] = (p >= 0 && p < g.M && wr < BM + 2 * halo) ? (int)(p * C) + (((tid & 3) ^ glds_swz<RB>(wr)) * 8) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int row = i * 64 + (tid >> 2);
+    boff[i] = (n0 + row < g.N) ? (int)((long long)(n0 + row) * g.ldw) + (((tid & 3) ^ glds_swz<RB>(row)) * 8) : -1;
+  }
+  auto issueA = [&](int cc, int buf) {
+    if (AVEC_ABL & (2 | 64)) return;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const void* src = aoff[i] >= 0 ? (const void*)((const T*)g.a.ptr + (aoff[i] + cc * KE)) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Awin + buf * AWIN + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto issueB = [&](int koff, int buf) {
+    if (AVEC_ABL & (2 | 128)) return;
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const void* src = boff[i] >= 0 ? (const void*)((const T*)g.W + (boff[i] + koff)) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bring + buf * BTILE + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // fragment rows and the taps each of them may use
+  int arow[MT]; unsigned amask[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int r = wm * (BM / 2) + i * 32 + (lane & 31);
+    arow[i] = r + halo;
+    const long long p = m0 + r;
+    unsigned mk = 0u;
+    if (p < g.M) {
+      const int x = (int)(p % Wd), y = (int)((p / Wd) % H);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int yy = MODE == MODE_CONV_FWD ? y + kh - 1 : y - kh + 1, xx = MODE == MODE_CONV_FWD ? x + kw - 1 : x - kw + 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) mk |= 1u << (kh * 3 + kw);
+        }
+    }
+    amask[i] = mk;
+  }
+  int offb[NT], swb[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * RB; swb[j] = glds_swz<RB>(row); }
+  const int gsel = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int NC = C / KE, KT = NC * 9;
+  const unsigned bring0 = (unsigned)(uintptr_t)(lptr_t)Bring, awin0 = (unsigned)(uintptr_t)(lptr_t)Awin;
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  // issue order: A(0), B(0), B(1); then in iteration ks (after its barrier): [A(cc+1) when t == 0], B(ks+2)
+  issueA(0, 0);
+  issueB(0, 0);
+  issueB(C, 1);                                   // step 1 = (chunk 0, tap 1): K offset 1 * C
+  int cc = 0, t = 0;                              // chunk / tap of step ks
+  int i_cc = 0, i_t = 2;                          // chunk / tap of the next B tile to issue (step ks + 2)
+  bool a_prev = false;                            // an A window was issued in the previous iteration (it is newer than B(ks))
+  for (int ks = 0; ks < KT; ++ks) {
+    const bool last = ks == KT - 1;
+    if (last) AVEC_WAIT_VM(0);
+    else if (a_prev) AVEC_WAIT_VM(NCB + NA);
+    else AVEC_WAIT_VM(NCB);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int kh = t / 3, kw = t - kh * 3;
+    const int sh = (MODE == MODE_CONV_FWD ? 1 : -1) * ((kh - 1) * Wd + (kw - 1));
+    const unsigned Ac = awin0 + (cc & 1) * AWIN, Bs = bring0 + (ks % STAGES) * BTILE;
+    // all fragment reads of the step are requested at once (inline asm: in-order returns, counted waits); the first MFMA group
+    // waits only for its own K-substep while the second one's reads are still in flight
+    u32x4 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { const int w = arow[i] + sh; fa[q][i] = lds_read128(Ac + w * RB + (((q * 2 + gsel) ^ glds_swz<RB>(w)) << 4)); }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[q][j] = lds_read128(Bs + offb[j] + (((q * 2 + gsel) ^ swb[j]) << 4));
+    }
+    // the DMA of the tiles two steps ahead goes out while the fragment reads are in flight
+    a_prev = false;
+    if (t == 0 && cc + 1 < NC) { issueA(cc + 1, (cc + 1) & 1); a_prev = true; }
+    if (ks + 2 < KT) { issueB(i_t * C + i_cc * KE, (ks + 2) % STAGES); if (++i_t == 9) { i_t = 0; ++i_cc; } }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q][i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[q][j]));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool ok = (amask[i] >> t) & 1u;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 a = ok ? fa[q][i] : z;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (AVEC_ABL & 1) asm volatile("" :: "v"(a), "v"(fb[q][j])); else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // (keeps this group's MFMAs above the next group's wait)
+    }
+    if (++t == 9) { t = 0; ++cc; }
+  }
+#undef AVEC_WAIT_VM
+  __syncthreads();
   nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
@@ -868,7 +1091,8 @@ template <typename K> static int want_lds(K kern, size_t bytes) {
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <typename T, int BM, int BN>
-static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
+static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream_t st) {
+  GemmArgs g = g_in;
   dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN));
   size_t lds = (size_t)2 * (BM + BN) * LDS_ROW;
   constexpr int VEC = Elt<T>::VEC;
@@ -876,6 +1100,11 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   // every chunk address 16-byte aligned?  (then each chunk is one global_load_dwordx4 instead of two dwordx2)
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
+  static const bool use_glds_ = getenv("AVEC_NO_GLDS") == nullptr;
+  if (g.perm2 && mode == MODE_CONV_BWD && g.fast_conv && a16 && !f32src && use_glds_) {     // parity-class order: only the fast LDS-DMA kernel knows it
+    g.pTs[0] = 0; for (int c = 0; c < 4; ++c) g.pTs[c + 1] = g.pTs[c] + (int)((perm2_count(g.a, c, g.pImgs) + BM - 1) / BM);
+    grid.x = (unsigned)g.pTs[4];
+  } else g.perm2 = 0;
   constexpr int STG = (BM + BN) <= 128 ? 4 : 2;      // ring depth: deep for the small latency-bound tiles; the big tiles keep 3 workgroups per CU instead (measured)
   static const bool rb_env_set = getenv("AVEC_NT_RB") != nullptr;
   static const int rb_env = rb_env_set ? atoi(getenv("AVEC_NT_RB")) : 128;
@@ -906,6 +1135,47 @@ static int launch_nt_mode(const GemmArgs& g, int mode, int src_f32, hipStream_t 
   return 0;
 }
 
+// wide tiles of the fast implicit-GEMM kernel (bf16, 64-byte LDS rows, 3-stage ring)
+template <int BM, int BN>
+static int launch_nt_wide(const GemmArgs& g_in, int mode, hipStream_t st) {
+  GemmArgs g = g_in;
+  dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN));
+  if (g.perm2 && mode == MODE_CONV_BWD) {
+    g.pTs[0] = 0; for (int c = 0; c < 4; ++c) g.pTs[c + 1] = g.pTs[c] + (int)((perm2_count(g.a, c, g.pImgs) + BM - 1) / BM);
+    grid.x = (unsigned)g.pTs[4];
+  } else g.perm2 = 0;
+  const size_t epi_lds = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4, ring = (size_t)3 * (BM + BN) * 64;
+  const size_t lds = ring > epi_lds ? ring : epi_lds;
+  if (mode == MODE_CONV_FWD) {
+    if (int r = want_lds(gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>, lds)) return r;
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>), grid, dim3(256), lds, st, g);
+  } else {
+    if (int r = want_lds(gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_BWD, 3, true, 64>, lds)) return r;
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_BWD, 3, true, 64>), grid, dim3(256), lds, st, g);
+  }
+  return 0;
+}
+
+// host side: 1 = not applicable (caller continues with the generic kernels), 0 = launched, other = error
+static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
+  static const bool off = getenv("AVEC_NO_CONV_SHIFT") != nullptr;
+  const RowSrc& a = g_in.a;
+  if (off || mode == MODE_PLAIN || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW || a.W > 31 || a.C % 32 != 0) return 1;
+  if (!aligned16(a.ptr) || !aligned16(g_in.W) || g_in.ldw % 8 != 0 || g_in.M * a.C >= (1ll << 31) || (long long)g_in.N * g_in.ldw >= (1ll << 31) || g_in.N < 64) return 1;
+  GemmArgs g = g_in; g.perm2 = 0;
+#define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
+    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
+    if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
+  // 256-row tiles halve the weight-tile DMA per FLOP (measured 5-15 % on the 3200-image ResNet stages 2-3, slower once fewer than ~3 tiles per CU remain)
+  static const int bm_env = getenv("AVEC_SHIFT_BM") ? atoi(getenv("AVEC_SHIFT_BM")) : 0;
+  const long long t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && t256 >= 768))) { if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD); }
+  if (g.N >= 128) { if (mode == MODE_CONV_FWD) S(128, 128, MODE_CONV_FWD); else S(128, 128, MODE_CONV_BWD); }
+  if (mode == MODE_CONV_FWD) S(128, 64, MODE_CONV_FWD); else S(128, 64, MODE_CONV_BWD);
+#undef S
+  return 0;
+}
+
 template <typename T>
 static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   // tile choice: big tiles only when they still fill the chip (256 CUs)
@@ -915,6 +1185,13 @@ static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
     if (tile_env == 128 && g.N > 64) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
     if (tile_env == 12864) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
     if (tile_env == 64) return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
+  }
+  static const int wide_env = getenv("AVEC_NT_WIDE") ? atoi(getenv("AVEC_NT_WIDE")) : 0;
+  if constexpr (sizeof(T) == 2) {
+    if (wide_env && mode != MODE_PLAIN && g.fast_conv && !src_f32 && aligned16(g.a.ptr) && aligned16(g.W) && g.K % 8 == 0 && g.ldw % 8 == 0) {
+      if (wide_env == 1 && g.N >= 256) return launch_nt_wide<128, 256>(g, mode, st);
+      if (wide_env == 3 && g.N >= 128) return launch_nt_wide<256, 128>(g, mode, st);
+    }
   }
   if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
   if (((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
@@ -935,7 +1212,7 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   AVEC_CHECK_ARG(a_mode == AVEC_ROWS_PLAIN || (a_rows->C % vec == 0 && K == a_rows->KH * a_rows->KW * a_rows->C),
                  "gemm_nt: conv C=%d must be a multiple of %d and K = KH*KW*C", a_rows->C, vec);
   GemmArgs g; g.a = make_src(A, a_rows); g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
-  g.fast_conv = 0;
+  g.fast_conv = 0; g.perm2 = 0; g.pImgs = 0; for (int c = 0; c < 5; ++c) g.pTs[c] = 0;
   if (a_mode != AVEC_ROWS_PLAIN) {
     const int KE = dtype == AVEC_BF16 ? 64 : 32;
     const long long imgs = a_mode == MODE_CONV_FWD ? (M + (long long)a_rows->OH * a_rows->OW - 1) / ((long long)a_rows->OH * a_rows->OW) : (M + (long long)a_rows->H * a_rows->W - 1) / ((long long)a_rows->H * a_rows->W);
@@ -943,6 +1220,10 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
     static const bool no_fast = getenv("AVEC_NO_FAST_CONV") != nullptr;
     g.fast_conv = !no_fast && a_rows->C % KE == 0 && a_rows->KH * a_rows->KW <= 32 && src_elems + (long long)(a_rows->W + a_rows->OW + 2) * a_rows->C * 4 < (1ll << 31) &&
                   (a_mode == MODE_CONV_FWD || a_rows->stride == 1 || a_rows->stride == 2);
+    static const bool no_perm = getenv("AVEC_NO_PERM2") != nullptr;
+    if (!no_perm && dtype == AVEC_BF16 && g.fast_conv && a_mode == MODE_CONV_BWD && a_rows->stride == 2 && M == imgs * (long long)a_rows->H * a_rows->W) {
+      g.perm2 = 1; g.pImgs = imgs;
+    }
   }
   Epi& e = g.e;
   e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
@@ -950,7 +1231,9 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
   AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt: dropout without rng state");
-  int r = (dtype == AVEC_BF16) ? launch_nt<bf16>(g, a_mode, a_f32, stream) : launch_nt<float>(g, a_mode, a_f32, stream);
+  int r = 1;
+  if (dtype == AVEC_BF16 && !a_f32 && a_mode != AVEC_ROWS_PLAIN) r = launch_conv_shift(g, a_mode, stream);      // 3x3 / stride 1: shifted-window kernel
+  if (r == 1) r = (dtype == AVEC_BF16) ? launch_nt<bf16>(g, a_mode, a_f32, stream) : launch_nt<float>(g, a_mode, a_f32, stream);
   if (r) return r;
   AVEC_LAUNCH_CHECK();
   return 0;

@@ -9,7 +9,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "avec_hip.h")
-LIB_PATH = os.path.join(_HERE, "libavec_hip.so")
+LIB_PATH = os.environ.get("AVEC_LIB_PATH") or os.path.join(_HERE, "libavec_hip.so")     # AVEC_LIB_PATH: kernel experiments (tools/build_abl.sh)
 
 F32, BF16 = 0, 1
 ROWS_PLAIN, ROWS_CONV_FWD, ROWS_CONV_BWD, ROWS_STEM3D = 0, 1, 2, 3

@@ -525,3 +525,86 @@ def test_ffn_fused_dropout_masks():
     assert ((dz == 0) & big & ~drop1).float().mean().item() < 1e-3    # kept hidden units (almost) never have a zero gradient ...
     assert (dz[drop1] == 0).all()                                    # ... dropped ones always do
     avec_amd.set_compute_dtype("f32")
+
+
+# ---- 3x3 convolution fast paths: shifted-window kernel (stride 1) and parity-class order (stride-2 backward-data) --------------------------
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,stride", [(7, 11, 128, 128, 1), (5, 6, 256, 256, 1), (9, 3, 512, 512, 1), (3, 22, 64, 64, 1), (2, 31, 32, 96, 1),
+                                                    (3, 22, 64, 128, 2), (5, 11, 128, 256, 2), (7, 6, 256, 512, 2), (4, 7, 64, 64, 2)])
+def test_conv3x3_fast_paths_match_torch_conv2d(Nimg, H, Cin, Cout, stride):
+    """nnet/blocks.py:29-91 (ResNet 3x3 convolutions, NHWC here): forward + BatchNorm statistics epilogue and backward-data of the implicit-GEMM entry point
+    `avec_gemm_nt` against torch.nn.functional.conv2d in fp32 on the CPU, for the shapes that select conv3x3_shift_kernel (stride 1, W <= 31; ragged last
+    tile, windows crossing image and tensor ends) and the parity-class order (stride 2; even and odd image sizes)."""
+    import torch.nn.functional as F
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d, adt = dev(), torch.bfloat16
+        g = torch.Generator().manual_seed(Nimg * 1000 + H)
+        x = torch.randn(Nimg, H, H, Cin, generator=g).to(adt)
+        Wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(adt)
+        OH = (H - 1) // stride + 1
+        M = Nimg * OH * OH
+        dy = torch.randn(M, Cout, generator=g).to(adt)
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = F.conv2d(xr, Wt.float(), stride=stride, padding=1)
+        yr.backward(dy.float().reshape(Nimg, OH, OH, Cout).permute(0, 3, 1, 2))
+        ref = yr.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+        dref = xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+        xd, dyd = x.to(d), dy.to(d)
+        W = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)         # [Cout][kh][kw][Cin]
+        Wb = Wt.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous().to(d)        # [Cin][kh][kw][Cout]
+        y = torch.full((M, Cout), float("nan"), device=d, dtype=adt)
+        st = torch.zeros(64 * 2 * Cout, device=d)
+        ops.gemm_nt(xd, W, y, M, Cout, 9 * Cin, rows=ops.rows_conv(H, H, Cin, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_FWD, stats=st)
+        dx = torch.full((Nimg * H * H, Cin), float("nan"), device=d, dtype=adt)
+        ops.gemm_nt(dyd, Wb, dx, Nimg * H * H, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_BWD)
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+        assert rel(y, ref) < 4e-3, rel(y, ref)                      # bf16 output rounding: 2^-9 rms
+        assert rel(dx, dref) < 4e-3, rel(dx, dref)
+        # every element individually (a wrong tap on one border pixel does not move the norm)
+        assert float((y.float().cpu() - ref).abs().max()) < 0.02 * float(ref.abs().max()) + 1e-3
+        assert float((dx.float().cpu() - dref).abs().max()) < 0.02 * float(dref.abs().max()) + 1e-3
+        s = st.view(64, 2, Cout).sum(0).cpu()
+        assert rel(s[0], ref.sum(0)) < 2e-3 and rel(s[1], (ref * ref).sum(0)) < 2e-3
+    finally:
+        avec_amd.set_compute_dtype("f32")
+
+
+def test_conv3x3_fast_paths_equal_generic_kernels(tmp_path):
+    """The same launches with the fast paths switched off (AVEC_NO_CONV_SHIFT / AVEC_NO_PERM2, read once per process): identical bf16 results up to the
+    summation order (fp32 accumulation, one rounding)."""
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import avec_amd
+from avec_amd import ops
+from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
+avec_amd.set_compute_dtype("bf16")
+d = torch.device("cuda:0"); out = {}
+for (Nimg, H, Cin, Cout, stride) in [(33, 11, 128, 128, 1), (33, 11, 128, 256, 2), (20, 22, 64, 128, 2)]:
+    g = torch.Generator().manual_seed(H + stride)
+    x = torch.randn(Nimg, H, H, Cin, generator=g).bfloat16().to(d); OH = (H - 1) // stride + 1; M = Nimg * OH * OH
+    W = (torch.randn(Cout, 9 * Cin, generator=g) / 30).bfloat16().to(d); Wb = (torch.randn(Cin, 9 * Cout, generator=g) / 30).bfloat16().to(d)
+    dy = torch.randn(M, Cout, generator=g).bfloat16().to(d)
+    y = torch.empty(M, Cout, device=d, dtype=torch.bfloat16); dx = torch.empty(Nimg * H * H, Cin, device=d, dtype=torch.bfloat16)
+    ops.gemm_nt(x, W, y, M, Cout, 9 * Cin, rows=ops.rows_conv(H, H, Cin, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_FWD)
+    ops.gemm_nt(dy, Wb, dx, Nimg * H * H, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_BWD)
+    out["y%%d_%%d" %% (H, stride)] = y.float().cpu(); out["dx%%d_%%d" %% (H, stride)] = dx.float().cpu()
+torch.save(out, sys.argv[1])
+''' % ROOT
+    script = tmp_path / "run.py"
+    script.write_text(code)
+    res = {}
+    for name, env in (("fast", {}), ("generic", {"AVEC_NO_CONV_SHIFT": "1", "AVEC_NO_PERM2": "1"})):
+        e = dict(os.environ); e.update(env)
+        p = tmp_path / (name + ".pt")
+        subprocess.run([sys.executable, str(script), str(p)], check=True, env=e, timeout=600)
+        res[name] = torch.load(p)
+    for k in res["fast"]:
+        a, b = res["fast"][k], res["generic"][k]
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()), k         # at most one bf16 ulp of the largest element
+        assert float((a != b).float().mean()) < 0.05, k                                    # and only where the fp32 sums straddle a rounding boundary
