@@ -724,6 +724,111 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) NT product: A [M][K] and W [N][K] one byte per element, per-tensor scales, fp32 accumulate on
+// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at 2^0).  Same LDS-DMA ring as gemm_nt_glds_kernel with 128-byte rows (= 128 K values
+// = two MFMA K-steps); a lane's 32-byte operand is two adjacent 16-byte chunks of its row -- A and B fragments pick the same chunks, so the
+// pairing of K indices inside the instruction does not matter.  The accumulators are multiplied by scale_a * scale_w and then go through the
+// shared epilogue (bias / activation / dropout / residual / pre-activation copy), output in bf16 or fp32 as for the bf16 kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256, 2) void gemm_nt_fp8_kernel(GemmArgs g, const float* __restrict__ amax_a, const float* __restrict__ amax_w) {
+  typedef bf16 T;                               // dtype of the "act" buffers the epilogue reads / writes
+  constexpr int RB = 128, KE = 128;             // bytes = K elements per LDS row
+  constexpr int NCA = BM * 8 / 256, NCB = BN * 8 / 256;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int TILE = (BM + BN) * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  long long aoff[NCA], boff[NCB]; int ka[NCA], kb[NCB];
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) { const int row = (tid >> 3) + i * 32; aoff[i] = (m0 + row < g.M) ? (m0 + row) * g.a.ld : -1; ka[i] = ((tid & 7) ^ glds_swz<RB>(row)) * 16; }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) { const int row = (tid >> 3) + i * 32; boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldw : -1; kb[i] = ((tid & 7) ^ glds_swz<RB>(row)) * 16; }
+  auto issue = [&](int kt, int buf) {
+    char* As = smem + buf * TILE; char* Bs = As + BM * RB;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int k = kt * KE + ka[i];
+      const void* src = (aoff[i] >= 0 && k < g.K) ? (const void*)((const char*)g.a.ptr + aoff[i] + k) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int k = kt * KE + kb[i];
+      const void* src = (boff[i] >= 0 && k < g.K) ? (const void*)((const char*)g.W + boff[i] + k) : (const void*)avec_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  int offa[MT], swa[MT], offb[NT], swb[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { const int row = wm * (BM / 2) + i * 32 + (lane & 31); offa[i] = row * RB; swa[i] = glds_swz<RB>(row); }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * RB; swb[j] = glds_swz<RB>(row); }
+  const int gsel = lane >> 5;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int KT = (g.K + KE - 1) / KE;
+  constexpr int LPT = NCA + NCB;
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st) if (st < KT) issue(st, st);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int newer = min(STAGES - 2, KT - 1 - kt);
+    if (STAGES <= 2 || newer <= 0) AVEC_WAIT_VM(0);
+    else if (newer == 1) AVEC_WAIT_VM(LPT);
+    else AVEC_WAIT_VM(2 * LPT);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * RB;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {           // two K = 64 steps per 128-byte row; this lane's chunks: 4*s2 + 2*gsel, +1
+      chunk16 fa[MT][2], fb[NT][2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fa[i][h] = *(const chunk16*)(As + offa[i] + (((4 * s2 + 2 * gsel + h) ^ swa[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fb[j][h] = *(const chunk16*)(Bs + offb[j] + (((4 * s2 + 2 * gsel + h) ^ swb[j]) << 4));
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const i32x8 a = {(int)fa[i][0].w[0], (int)fa[i][0].w[1], (int)fa[i][0].w[2], (int)fa[i][0].w[3], (int)fa[i][1].w[0], (int)fa[i][1].w[1], (int)fa[i][1].w[2], (int)fa[i][1].w[3]};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const i32x8 b = {(int)fb[j][0].w[0], (int)fb[j][0].w[1], (int)fb[j][0].w[2], (int)fb[j][0].w[3], (int)fb[j][1].w[0], (int)fb[j][1].w[1], (int)fb[j][1].w[2], (int)fb[j][1].w[3]};
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[i][j], 0, 0, 0, 127, 0, 127);
+        }
+      }
+    }
+  }
+#undef AVEC_WAIT_VM
+  const float sc = (fmaxf(*amax_a, 1e-20f) * (1.0f / 448.0f)) * (fmaxf(*amax_w, 1e-20f) * (1.0f / 448.0f));
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+  __syncthreads();
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
 // ------------------------------------------------------------------------------------------------
 // TN: O[i][j] += sum_m P[m][i] * Q[m][j];   P plain [M][I] (T), Q via row loader ([M][J], plain or im2col)
 // LDS images are [i][m] / [j][m] (reduction index contiguous) filled by transposing stores.
@@ -1073,6 +1178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(TnGroup grp)
 // ------------------------------------------------------------------------------------------------
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 static RowSrc make_src(const void* ptr, const avec_rows_t* d) {
   RowSrc s; s.ptr = ptr; s.ld = d->ld; s.rows_out = d->rows_out; s.rows_in = d->rows_in; s.step = d->step;
   s.H = d->H; s.W = d->W; s.C = d->C; s.KH = d->KH; s.KW = d->KW; s.stride = d->stride; s.pad = d->pad; s.OH = d->OH; s.OW = d->OW;
@@ -1235,6 +1341,34 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   if (dtype == AVEC_BF16 && !a_f32 && a_mode != AVEC_ROWS_PLAIN) r = launch_conv_shift(g, a_mode, stream);      // 3x3 / stride 1: shifted-window kernel
   if (r == 1) r = (dtype == AVEC_BF16) ? launch_nt<bf16>(g, a_mode, a_f32, stream) : launch_nt<float>(g, a_mode, a_f32, stream);
   if (r) return r;
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}
+
+
+/* fp8 forward Linear product (include/avec_hip.h) */
+extern "C" int avec_gemm_nt_fp8(const void* A, long long lda, const void* W, long long ldw, long long M, int N, int K,
+                                const float* amax_a, const float* amax_w, const avec_epilogue_t* ep, hipStream_t stream) {
+  AVEC_CHECK_ARG(A && W && ep && ep->out && amax_a && amax_w, "gemm_nt_fp8: null pointer");
+  AVEC_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 16 == 0 && ldw % 16 == 0 && aligned16(A) && aligned16(W),
+                 "gemm_nt_fp8: M=%lld N=%d K=%d lda=%lld ldw=%lld: K and the row strides must be multiples of 16 bytes, operands 16-byte aligned", M, N, K, lda, ldw);
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.a.ptr = A; g.a.ld = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+  Epi& e = g.e;
+  e.out = ep->out; e.ldo = ep->ldo; e.out_f32 = ep->out_f32; e.out_pre = ep->out_pre; e.ldpre = ep->ldpre; e.bias = ep->bias;
+  e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
+  e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
+  e.colsum = ep->colsum; e.stats = ep->stats;
+  AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt_fp8: dropout without rng state");
+#define F8(BM, BN, S_) do { dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN)); \
+    const size_t ring = (size_t)S_ * (BM + BN) * 128, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
+    if (int r = want_lds(gemm_nt_fp8_kernel<BM, BN, S_>, lds)) return r; \
+    hipLaunchKernelGGL((gemm_nt_fp8_kernel<BM, BN, S_>), grid, dim3(256), lds, stream, g, amax_a, amax_w); } while (0)
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (N > 64 && t128 >= 384) F8(128, 128, 2);
+  else if (((M + 127) / 128) * ((N + 63) / 64) >= 384) F8(128, 64, 2);
+  else F8(64, 64, 4);
+#undef F8
   AVEC_LAUNCH_CHECK();
   return 0;
 }

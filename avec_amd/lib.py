@@ -58,6 +58,12 @@ class LnItem(ctypes.Structure):
                 ("dbeta", ctypes.c_void_p), ("M", ctypes.c_longlong), ("D", ctypes.c_int), ("dy_f32", ctypes.c_int)]
 
 
+class Fp8Item(ctypes.Structure):
+    """avec_fp8_item_t"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_longlong), ("slot", ctypes.c_int), ("K", ctypes.c_int), ("Kp", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
 TN_GROUP_MAX, LN_GROUP_MAX = 32, 40
 
 

@@ -29,6 +29,16 @@ class Model(Module):
         self.arena = None
         self.world_size = 1
 
+    @staticmethod
+    def _pre_forward(model, _args):
+        """before every forward pass: in-place weight edits -> stale shadows; fp8 operands -> fresh activation amax slots"""
+        if model.arena is None:
+            return None
+        model.arena.check_versions()
+        if getattr(model.arena, "_fp8", None) is not None:
+            model.arena._fp8.begin_pass()
+        return None
+
     # -- placement ------------------------------------------------------------------------------
     def to(self, device):
         out = super().to(device)
@@ -36,7 +46,7 @@ class Model(Module):
             self.arena = rt.ParamArena(self)
             if not getattr(self, "_avec_version_hook", False):       # every forward (training, evaluation, a bare model(x)): weights edited in place since the last pass -> refresh the shadows
                 self._avec_version_hook = True
-                self.register_forward_pre_hook(lambda m, _args: m.arena.check_versions() if m.arena is not None else None)
+                self.register_forward_pre_hook(Model._pre_forward)
             if self.compiled and hasattr(self.optimizer, "attach_arena"):
                 self.optimizer.attach_arena(self.arena)
         return out

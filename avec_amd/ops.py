@@ -8,6 +8,7 @@ import os
 
 import torch
 
+from . import fp8
 from . import runtime as rt
 from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnItem, lib
 
@@ -94,6 +95,27 @@ def rows_conv(H, W, C, KH, KW, stride, pad, OH, OW):
     r = Rows()
     r.H, r.W, r.C, r.KH, r.KW, r.stride, r.pad, r.OH, r.OW = H, W, C, KH, KW, stride, pad, OH, OW
     return r
+
+
+def gemm_nt_fp8(A, ent, out, M, N, K, *, bias=None, act=ACT_NONE, out_pre=None, drop_p=0.0, sid=0, res=None, alpha=1.0, out_f32=False, ldo=None):
+    """forward Linear product on e4m3 operands (avec_amd/fp8.py): quantize the bf16 activation with its own max|x|, then avec_gemm_nt_fp8"""
+    Kp = ent.Kp
+    q = torch.empty((M, Kp), dtype=torch.uint8, device=A.device)
+    lib.fp8_quantize(rt.dt(), A.data_ptr(), K, q.data_ptr(), Kp, M, K, ent.a_amax, 1, rt.stream())
+    ep = Epilogue()
+    ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
+    if out_pre is not None:
+        ep.out_pre, ep.ldpre = out_pre.data_ptr(), N
+    ep.bias, ep.act, ep.alpha = _p(bias), act, alpha
+    if drop_p > 0.0:
+        ep.drop_p, ep.rng, ep.rng_stream = drop_p, rt.rng_state(out.device).data_ptr(), sid
+    if res is not None:
+        ep.res, ep.ldres, ep.res_act = res.data_ptr(), N, 0
+    ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+    lib.gemm_nt_fp8(q.data_ptr(), Kp, ent.wq, Kp, M, N, Kp, ent.a_amax, ent.w_amax, _byref(ep), rt.stream())
+    if ev is not None:
+        KERNEL_TIMER.stop(ev, (0, 0), 2.0 * M * N * K)
+    return out
 
 
 def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
@@ -279,6 +301,9 @@ def linear_fwd(x2d, weight, bias, M, *, in_f32, out_f32, act=ACT_NONE, out_pre=N
     sh = rt.shadow(weight)
     N, Kw = sh.A, sh.Tm * sh.C
     out = empty((M, N), torch.float32 if out_f32 else rt.act_dtype(), x2d)
+    ent = fp8.entry(weight, Kw) if (rows is None and not in_f32 and sh.group is None) else None
+    if ent is not None and ent.N == N:
+        return gemm_nt_fp8(x2d, ent, out, M, N, Kw, bias=bias, act=act, out_pre=out_pre, drop_p=drop_p, sid=sid, res=res, alpha=alpha, out_f32=out_f32)
     gemm_nt(x2d, sh.fwd, out, M, N, Kw, rows=rows, a_f32=in_f32, bias=bias, act=act, out_pre=out_pre, drop_p=drop_p, sid=sid,
             res=res, alpha=alpha, out_f32=out_f32)
     return out
@@ -521,7 +546,11 @@ class AttentionModuleFn(torch.autograd.Function):
         qkv = empty((Mp, 3 * D), adt, x2)
         grp = rt.fused_group(wq)
         if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
-            gemm_nt(hp, grp.fwd, qkv, Mp, 3 * D, D, bias=grp.bias)               # Q|K|V in one launch
+            ent = fp8.entry(wq, D)
+            if ent is not None and ent.N == 3 * D:
+                gemm_nt_fp8(hp, ent, qkv, Mp, 3 * D, D, bias=grp.bias)
+            else:
+                gemm_nt(hp, grp.fwd, qkv, Mp, 3 * D, D, bias=grp.bias)               # Q|K|V in one launch
         else:
             for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
                 sh = rt.shadow(w)

@@ -457,6 +457,8 @@ class ParamArena:
             lib.shadow_refresh(dt(), self.master.data_ptr(), self.shadow.data_ptr(), self.table.data_ptr(), self.n_entries,
                                self.total_blocks, stream())
             self.dirty = False
+            if getattr(self, "_fp8", None) is not None:          # e4m3 weight shadows follow the masters too (avec_amd/fp8.py)
+                self._fp8.refresh()
 
     def mark_dirty(self):
         """The master weights changed outside the Adam kernel: refresh the shadows before the next GEMM.  Called automatically by load_state_dict

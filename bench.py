@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--fp8", action="store_true", help="e4m3 operands for the eligible forward Linear products on top of bf16 (BASELINE config 5's arithmetic; DESIGN.md section 15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
@@ -163,6 +164,9 @@ def main():
     import nnet
     from avec_amd import ops
     avec_amd.set_compute_dtype(args.dtype)
+    if args.fp8:
+        from avec_amd import fp8
+        fp8.enable(True)
     avec_amd.manual_seed(1234 + rank)
     torch.manual_seed(0)
     model = nnet.AudioVisualEfficientConformerInterCTC(vocab_size=256, v_interctc_blocks=[3, 6], a_interctc_blocks=[8, 11], f_interctc_blocks=[2])
@@ -227,7 +231,7 @@ def main():
         out = {
             "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype + ("+fp8(e4m3) forward Linear operands" if args.fp8 else ""), "data": "synthetic",
             "config": {"workload": "AV EffConfInterCTC (LRS23/AV) training step: fwd + 6 CTC losses + bwd + grad all-reduce + Adam; "
                                    "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),

@@ -76,6 +76,20 @@ int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows, int a_mode
                  const void* W, long long ldw, long long M, int N, int K,
                  const avec_epilogue_t* ep, hipStream_t stream);
 
+/* ---- fp8 (OCP e4m3) forward Linear products: BASELINE config 5's "fp8 GEMMs" for the FFN / QKV / output / pointwise-conv projections
+ * (nnet/modules.py:257-289,341-385, nnet/attentions.py:60-110; the reference trains them under fp16 autocast, nnet/model.py:404-414).
+ * Per-tensor "current" scaling: amax slots are plain device floats holding max|x|; scale = max(amax, tiny) / 448 is derived by the consumers. */
+typedef struct { const float* src; void* dst; long long n; int slot; int K, Kp; int reserved; } avec_fp8_item_t;   /* fp32 master [n / K][K] -> e4m3 rows of Kp >= K bytes (zero padded, Kp % 16 == 0, K % 4 == 0), amax in amax[slot] */
+/* x [M][K] (fp32 / bf16, row stride ldx) -> q [M][K] e4m3 (row stride ldq bytes); compute_amax != 0: *amax is first raised to max|x| (the caller zeroed it),
+ * else *amax is taken as given.  K % 8 == 0; columns K .. roundup16(K) of q are written as zeros (ldq >= roundup16(K)). */
+int avec_fp8_quantize(int src_dtype, const void* x, long long ldx, void* q, long long ldq, long long M, int K, float* amax, int compute_amax, hipStream_t stream);
+/* every weight of `table` (device memory, n_items entries): amax[slot] = max|w| (caller zeroed the slots), then dst = e4m3(w / scale). */
+int avec_fp8_weights_refresh(const avec_fp8_item_t* table, int n_items, int blocks_per_item, float* amax, hipStream_t stream);
+/* C = epi( (sum_k A[m][k] W[n][k]) * scale_a * scale_w ), A and W e4m3 (row strides in bytes), epilogue fields as avec_gemm_nt with bf16 "act" buffers. */
+int avec_gemm_nt_fp8(const void* A, long long lda, const void* W, long long ldw, long long M, int N, int K,
+                     const float* amax_a, const float* amax_w, const avec_epilogue_t* ep, hipStream_t stream);
+
+
 /* O[i][j] += sum_m P[m][i] Q[m][j]  (fp32 atomics, split over m).  Replaces the weight-gradient aten::mm of
  * Linear backward and convolution_backward(weight). */
 int avec_gemm_tn(int dtype, const void* P, long long ldp, const void* Q, const avec_rows_t* q_rows, int q_mode, int q_f32,

@@ -608,3 +608,92 @@ torch.save(out, sys.argv[1])
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()), k         # at most one bf16 ulp of the largest element
         assert float((a != b).float().mean()) < 0.05, k                                    # and only where the fp32 sums straddle a rounding boundary
+
+
+# ---- fp8 (OCP e4m3) forward Linear products: BASELINE config 5's arithmetic ----------------------------------------------------------------
+def _e4m3_ref(x, amax):
+    """torch's own e4m3 cast (round to nearest even) of x * (1 / scale), scale = amax * (1 / 448) in fp32 like the kernel, clamped like the kernel"""
+    s = torch.tensor(max(float(amax), 1e-20), dtype=torch.float32) * torch.tensor(1.0 / 448.0, dtype=torch.float32)
+    inv = (torch.tensor(1.0, dtype=torch.float32) / s).to(x.device)
+    return (x.float() * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn), float(s)
+
+
+@pytest.mark.parametrize("M,N,K", [(3200, 1024, 256), (800, 360, 1440), (37, 96, 64), (6400, 1080, 360), (130, 520, 2080)])
+def test_fp8_quantizer_and_gemm_match_torch_e4m3(M, N, K):
+    """avec_fp8_quantize is bit-exact against torch's float8_e4m3fn cast; avec_gemm_nt_fp8 equals the fp32 product of the dequantized operands
+    (fp32 accumulation order only) through the bias + Swish + pre-activation epilogue of the FFN's first Linear (nnet/modules.py:257-289)."""
+    from avec_amd.lib import lib, Epilogue, BF16, ACT_SWISH
+    from avec_amd import runtime as rt
+    import ctypes
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.7).bfloat16().to(d)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(d)
+    bias = torch.randn(N, generator=g).to(d)
+    amax = torch.zeros(2, device=d)
+    Kp = (K + 15) // 16 * 16                      # rows padded to whole 16-byte chunks (K = 360 -> 368), pad written as zeros
+    q = torch.full((M, Kp), 0x55, dtype=torch.uint8, device=d)
+    lib.fp8_quantize(BF16, x.data_ptr(), K, q.data_ptr(), Kp, M, K, amax.data_ptr(), 1, rt.stream())
+    wq = torch.full((N, Kp), 0x55, dtype=torch.uint8, device=d)
+    lib.fp8_quantize(0, w.data_ptr(), K, wq.data_ptr(), Kp, N, K, amax.data_ptr() + 4, 1, rt.stream())
+    torch.cuda.synchronize()
+    assert float(amax[0]) == float(x.float().abs().max()) and float(amax[1]) == float(w.abs().max())
+    xr, sx = _e4m3_ref(x, amax[0]); wr, sw = _e4m3_ref(w, amax[1])
+    assert torch.equal(q[:, :K].contiguous().view(torch.float8_e4m3fn).float(), xr.float()), "activation quantizer differs from torch's e4m3 cast"
+    assert torch.equal(wq[:, :K].contiguous().view(torch.float8_e4m3fn).float(), wr.float())
+    assert int(q[:, K:].max()) == 0 and int(wq[:, K:].max()) == 0 if Kp > K else True
+    out = torch.empty(M, N, device=d, dtype=torch.bfloat16); pre = torch.empty_like(out)
+    ep = Epilogue(); ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), N, 0
+    ep.out_pre, ep.ldpre, ep.bias, ep.act, ep.alpha = pre.data_ptr(), N, bias.data_ptr(), ACT_SWISH, 1.0
+    lib.gemm_nt_fp8(q.data_ptr(), Kp, wq.data_ptr(), Kp, M, N, Kp, amax.data_ptr(), amax.data_ptr() + 4, ctypes.byref(ep), rt.stream())
+    torch.cuda.synchronize()
+    z = (xr.float().double() @ wr.float().double().t()) * (sx * sw) + bias.double()
+    ref = z * torch.sigmoid(z)
+    assert float((pre.double() - z).abs().max()) < 2.0 ** -8 * float(z.abs().max()) + 1e-6         # bf16 output rounding
+    assert float((out.double() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max()) + 1e-6
+
+
+def test_fp8_full_model_config5_shape_losses():
+    """BASELINE config 5 (15 s clips + fp8 GEMMs): the AV model with e4m3 operands in every eligible forward Linear against the fp32 oracle -- the seven losses
+    within 5e-2 relative (the bf16 bound of test_full_model_config5_shape_matches_oracle), gradients finite and close to the bf16 run's; and the e4m3 path must
+    actually have run: every weight slot and most activation slots carry a maximum."""
+    import avec_amd
+    from avec_amd import fp8
+    from oracle import avec_oracle as O
+    model, sd0 = probe.build_model()
+    torch.manual_seed(5)
+    B = 2
+    video = torch.randn(B, 376, 88, 88, 1)
+    audio = 0.1 * torch.randn(B, 240000)
+    vlen, alen = torch.tensor([376, 251]), torch.tensor([240000, 160000])
+    labels, llen = torch.randint(1, 256, (B, 36)), torch.tensor([36, 22])
+    with torch.no_grad():
+        ref = O.av_forward(sd0, video, vlen, audio, alen, train=True, stats_out={})
+        ref_losses = {k: float(v) for k, v in O.total_loss(ref, labels, llen, O.AV_LOSS_WEIGHTS).items()}
+    d = dev()
+    grads = {}
+    try:
+        for mode in ("bf16", "fp8"):
+            model.load_state_dict(sd0)
+            avec_amd.set_compute_dtype("bf16")
+            fp8.enable(mode == "fp8")
+            model.arena.zero_grad()
+            losses, _, _, _ = model.forward_model([video.to(d), vlen.to(d), audio.to(d), alen.to(d)], (labels.to(d), llen.to(d)), compute_metrics=False)
+            for k, v in ref_losses.items():
+                assert abs(float(losses[k]) - v) < 5e-2 * abs(v), (mode, k, float(losses[k]), v)
+            losses["loss"].backward()
+            torch.cuda.synchronize()
+            assert torch.isfinite(model.arena.grad).all(), mode
+            grads[mode] = model.arena.grad.clone()
+        st = model.arena._fp8
+        assert st.n >= 100, st.n                                            # ~19 blocks x (FFN 4 + QKV + out + pos + 2 pointwise) minus the 180-channel stage
+        am = st.amax.cpu()
+        assert (am[:st.n] > 0).all(), "a weight was not quantized"
+        assert float((am[st.n:] > 0).float().mean()) > 0.8, "most eligible products must have run on e4m3 operands"
+        # e4m3 operands perturb the gradients (through the activations the backward pass re-reads) but do not change their scale or direction
+        a, b = grads["fp8"].double(), grads["bf16"].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.98 and 0.9 < float(a.norm() / b.norm()) < 1.1, (cos, float(a.norm() / b.norm()))
+    finally:
+        fp8.enable(False)
+        avec_amd.set_compute_dtype("f32")
