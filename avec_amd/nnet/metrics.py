@@ -13,8 +13,23 @@ def _edit_distance(r, h):
     return d[len(h)]
 
 
+_CONTRACTIONS = (("won't", "will not"), ("can't", "can not"), ("let's", "let us"), ("n't", " not"), ("'re", " are"), ("'s", " is"), ("'d", " would"),
+                 ("'ll", " will"), ("'t", " not"), ("'ve", " have"), ("'m", " am"))
+
+
+def standardize(text):
+    """What jiwer.wer(..., standardize=True) applies before counting (nnet/metrics.py:110; jiwer is an un-vendored dependency -- its documented default
+    transform restated: lower case, common English contractions expanded, Kaldi non-words `[..]` / `<..>` removed, white space collapsed).  "parity unpinned"."""
+    import re
+    text = text.lower()
+    for a, b in _CONTRACTIONS:
+        text = text.replace(a, b)
+    text = re.sub(r"[<\[][^>\]]*[>\]]", "", text)
+    return " ".join(text.split())
+
+
 class WordErrorRate(nn.Module):
-    """100 * (S + D + I) / N over the batch (corpus-level, like jiwer.wer on lists)."""
+    """100 * (S + D + I) / N over the given sentences (corpus-level, like jiwer.wer on lists) after jiwer's `standardize` normalisation."""
 
     def __init__(self, name="wer"):
         super().__init__()
@@ -23,8 +38,8 @@ class WordErrorRate(nn.Module):
     def forward(self, targets, outputs):
         errs = words = 0
         for t, o in zip(targets, outputs):
-            tw = t.split() if isinstance(t, str) else list(t)
-            ow = o.split() if isinstance(o, str) else list(o)
+            tw = standardize(t).split() if isinstance(t, str) else list(t)
+            ow = standardize(o).split() if isinstance(o, str) else list(o)
             errs += _edit_distance(tw, ow)
             words += len(tw)
         return 100.0 * errs / max(words, 1)

@@ -341,16 +341,43 @@ class Model(Module):
             return res[0] if len(res) == 1 else res
         self.eval()
         sums, count = {}, 0
+        metric_keys, truths, preds = [], {}, {}
         for step, batch in enumerate(dataset_eval):
             inputs = self.transfer_to_device(batch["inputs"])
             targets = self.transfer_to_device(batch["targets"])
-            losses, metrics, _, _ = self.eval_step(inputs, targets, verbose)
+            losses, metrics, batch_truths, batch_preds = self.eval_step(inputs, targets, verbose)
             for k, v in list(losses.items()) + list(metrics.items()):
                 sums[k] = sums.get(k, 0.0) + float(v)
+            metric_keys = list(metrics.keys())
+            if recompute_metrics:                           # keep the decoded references / hypotheses: corpus-level metrics (nnet/model.py:899-903, 928-931)
+                for k in metric_keys:
+                    if isinstance(batch_truths.get(k), (list, tuple)) and isinstance(batch_preds.get(k), (list, tuple)):
+                        truths.setdefault(k, []).extend(batch_truths[k])
+                        preds.setdefault(k, []).extend(batch_preds[k])
             count += 1
             if eval_steps is not None and step + 1 >= eval_steps:
                 break
-        return {k: v / max(count, 1) for k, v in sums.items()}
+        if self.is_distributed:                             # sum over ranks (nnet/model.py:912-918: reduce_losses_metrics / gather_truths_preds)
+            import torch.distributed as dist
+            keys = sorted(sums)
+            vec = torch.tensor([sums[k] for k in keys] + [float(count)], dtype=torch.float64, device=self.device if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(vec)
+            sums, count = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}, int(vec[-1].item())
+            if truths:
+                gathered = [None] * dist.get_world_size()
+                dist.all_gather_object(gathered, (truths, preds))
+                truths, preds = {}, {}
+                for t, p in gathered:
+                    for k in t:
+                        truths.setdefault(k, []).extend(t[k])
+                        preds.setdefault(k, []).extend(p[k])
+        res = {k: v / max(count, 1) for k, v in sums.items()}
+        for k in truths:                                    # metric of the whole evaluation set, not the mean of per-batch values
+            cands = [mt for mt in (self.metrics.values() if isinstance(self.metrics, dict) else [self.metrics]) if mt is not None]
+            metric = next((mt for mt in cands if mt.name == k), None) or next((mt for mt in cands if k.startswith(mt.name + "_")), None)
+            if metric is not None:
+                res[k] = float(metric(truths[k], preds[k]))
+        return res
 
     def eval_time(self, dataset_eval, eval_steps=None, **kwargs):
         if isinstance(dataset_eval, (list, tuple)):

@@ -155,3 +155,15 @@ def test_grouped_audio_encoder_state_dict_and_init_match_reference():
     for k, v in g["probe"].items():
         if k in sd:
             assert abs(float(sd[k].double().sum()) - v) <= 1e-6 * max(1.0, abs(v)), k
+
+
+def test_word_error_rate_standardizes_and_is_corpus_level():
+    """nnet/metrics.py:101-110: 100 * jiwer.wer(targets, outputs, standardize=True) -- lower-casing, contraction expansion, Kaldi non-words and white space are
+    normalised before counting, and the rate is errors over ALL reference words of the list (not the mean of per-sentence rates)."""
+    from avec_amd.nnet.metrics import WordErrorRate, standardize
+    assert standardize("I  CAN'T  [noise] go <unk> It's") == "i can not go it is"
+    wer = WordErrorRate()
+    assert wer(["It's a test"], ["it is a TEST"]) == 0.0
+    # 1 substitution in a 2-word sentence + 0 errors in an 8-word sentence: corpus level 10 %, mean of sentence rates 25 %
+    assert abs(wer(["hello world", "a b c d e f g h"], ["hello word", "a b c d e f g h"]) - 10.0) < 1e-9
+    assert abs(wer(["a b c"], ["a c"]) - 100.0 / 3) < 1e-9 and abs(wer(["a b"], ["a x b y"]) - 100.0) < 1e-9      # deletion; two insertions
