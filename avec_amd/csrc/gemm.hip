@@ -1274,8 +1274,11 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
     if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
   // 256-row tiles halve the weight-tile DMA per FLOP (measured 5-15 % on the 3200-image ResNet stages 2-3, slower once fewer than ~3 tiles per CU remain)
   static const int bm_env = getenv("AVEC_SHIFT_BM") ? atoi(getenv("AVEC_SHIFT_BM")) : 0;
-  const long long t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && t256 >= 768))) { if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD); }
+  // tile height by wave quantisation: workgroups / (rounds * resident slots), slots = 256 CUs x 3 (128 rows, 136 VGPRs) or x 2 (256 rows, 237 VGPRs);
+  // e.g. the 512-channel stage (28 800 rows x 512): 900 tiles of 128 rows = 1.17 rounds (59 %), 452 of 256 rows = 0.88 round (88 %)
+  const long long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+  const double e128 = (double)t128 / (double)(((t128 + 767) / 768) * 768), e256 = 1.08 * (double)t256 / (double)(((t256 + 511) / 512) * 512);
+  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && e256 > e128))) { if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD); }
   if (g.N >= 128) { if (mode == MODE_CONV_FWD) S(128, 128, MODE_CONV_FWD); else S(128, 128, MODE_CONV_BWD); }
   if (mode == MODE_CONV_FWD) S(128, 64, MODE_CONV_FWD); else S(128, 64, MODE_CONV_BWD);
 #undef S
