@@ -20,7 +20,7 @@ struct PeerArgs {
   int rank, world;
   unsigned* epoch;                                  // this site's visit counter (device memory, this rank)
   int* err;
-  long long timeout_cycles;
+  long long timeout_spins;                          // polls (each followed by s_sleep 8, >= ~0.25 us) before a slot is given up
 };
 
 __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
@@ -37,21 +37,23 @@ __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
   }
   // gather: own page, all slots, in rank order
   const unsigned long long* mine = a.pages[a.rank] + poff;
-  const long long t0 = __builtin_readcyclecounter();
   for (int i = threadIdx.x; i < a.n; i += 256) {
     float s = 0.f;
+    bool lost = false;
     for (int r = 0; r < a.world; ++r) {
       unsigned long long gr;
-      int spins = 0;
+      long long spins = 0;
       while (true) {
         gr = __hip_atomic_load(mine + (long long)r * a.n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned)(gr >> 32) == e) break;
         __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 1023) == 0 && __builtin_readcyclecounter() - t0 > a.timeout_cycles) { *a.err = 1; break; }
+        if (++spins > a.timeout_spins) { *a.err = 1; lost = true; break; }      // counted in polls, not by the cycle counter: s_memtime is not monotonic for a wave that was
+                                                                  // context-switched out and resumed elsewhere (two processes sharing a GPU), and a spurious
+                                                                  // time-out here means a wrong sum
       }
       s += __uint_as_float((unsigned)gr);
     }
-    a.out[i] = s;
+    a.out[i] = lost ? __uint_as_float(0x7fc00000u) : s;        // a missing peer must not look like a sum: NaN propagates into the loss
   }
 }
 
@@ -59,7 +61,7 @@ extern "C" int avec_peer_exchange_sum(const float* in, float* out, int n, void* 
                                       unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream) {
   AVEC_CHECK_ARG(in && out && pages && epoch && err_flag && n > 0 && world >= 1 && world <= AVEC_PEER_MAX_WORLD && rank >= 0 && rank < world,
                  "peer_exchange_sum: bad arguments (n=%d rank=%d world=%d)", n, rank, world);
-  PeerArgs a; a.in = in; a.out = out; a.n = n; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag; a.timeout_cycles = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 2400000ll;
+  PeerArgs a; a.in = in; a.out = out; a.n = n; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag; a.timeout_spins = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 4000ll;
   for (int r = 0; r < AVEC_PEER_MAX_WORLD; ++r) a.pages[r] = r < world ? (unsigned long long*)pages[r] : nullptr;
   for (int r = 0; r < world; ++r) AVEC_CHECK_ARG(a.pages[r] && (((uintptr_t)a.pages[r]) & 7) == 0, "peer_exchange_sum: page pointer of rank %d is null / not 8-byte aligned", r);
   hipLaunchKernelGGL(peer_exchange_sum_kernel, dim3(1), dim3(256), 0, stream, a);

@@ -322,6 +322,10 @@ class Model(Module):
                 targets = self.transfer_to_device(batch["targets"])
                 losses, _, acc_step = self.train_step(inputs, targets, precision, None, accumulated_steps, acc_step, eval_training)
                 n += 1
+                if self.is_distributed and step % step_log_period == 0:
+                    from .. import peer
+                    if peer.active() is not None:
+                        peer.active().check()            # a SyncBatchNorm peer exchange that lost a rank raises here (its sums were NaN from that step on)
                 if self.rank == 0 and step % step_log_period == 0:
                     print("epoch %d step %d model_step %d loss %.4f" % (epoch + 1, step, int(self.model_step), float(losses["loss"].detach())))
                 if steps_per_epoch is not None and step + 1 >= steps_per_epoch:

@@ -218,6 +218,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(last["loss"].detach())
+    if world > 1 and peer.active() is not None:
+        peer.active().check()                # a rank that never arrived at a SyncBatchNorm exchange: say so (its sums were NaN)
     assert loss == loss and abs(loss) < 1e6, "training step produced a non-finite loss"
 
     if rank == 0:

@@ -39,7 +39,7 @@ def main():
     sl = slice(rank * B // world, (rank + 1) * B // world)
     inputs = [t[sl].to(dev) for t in (video, vlen, audio, alen)]
     targets = (labels[sl].to(dev), llen[sl].to(dev))
-    if world > 1:
+    if world > 1 and os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0":
         model.arena.arm_early_all_reduce(True)               # as train_step does: two arena ranges are exchanged while backward is still running
     losses, _, _, _ = model.forward_model(inputs, targets, compute_metrics=False)
     losses["loss"].backward()
@@ -51,12 +51,22 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(loss)
         loss /= world
+    site_orders = None
+    if world > 1:
+        from avec_amd import peer as _peer
+        px = _peer.active()
+        name_of = {id(m_): n_ for n_, m_ in model.named_modules()}
+        mine = [] if px is None else [(name_of.get(k[0], str(k[0])) if isinstance(k, tuple) else str(k), k[1] if isinstance(k, tuple) else "", v) for k, v in px.sites.items()]
+        site_orders = [None] * world
+        torch.distributed.all_gather_object(site_orders, mine)
+        if px is not None:
+            px.check()
     if rank == 0:
         bn = model.encoder.video_encoder.front_end[3].blocks[0].layers[1]
         off_of = {id(p_): o for p_, o in zip(model.arena.params, model.arena.offsets)}
         names = {k: (off_of[id(p_)], p_.numel()) for k, p_ in model.named_parameters()}
         from avec_amd import peer
-        torch.save({"peer": peer.active() is not None, "early": early, "numel": model.arena.numel, "grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
+        torch.save({"site_orders": site_orders, "peer": peer.active() is not None, "early": early, "numel": model.arena.numel, "grad": grad.cpu(), "names": names, "loss": loss.cpu(), "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu()}, args.out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
