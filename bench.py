@@ -187,8 +187,22 @@ def main():
     # without the peer exchange (refused IPC, gloo debugging on CPU tensors, ...) the step runs eagerly.
     from avec_amd import peer
     use_graph = not args.eager and (world == 1 or peer.active() is not None)
+    graphed = None
     if use_graph:
-        graphed = model.make_graphed_train_step(inputs, targets, precision=precision, warmup=min(max(args.warmup, 1), 3))
+        try:
+            graphed = model.make_graphed_train_step(inputs, targets, precision=precision, warmup=min(max(args.warmup, 1), 3))
+        except Exception as e:                                   # (multi-GPU: all ranks must take the same path, see the agreement below)
+            if world == 1:
+                raise
+            print("[bench] rank %d: graph capture of the data-parallel step failed (%s: %s); falling back to eager steps" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            graphed = None
+        if world > 1:
+            ok = torch.tensor([int(graphed is not None)], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graphed = None
+        use_graph = graphed is not None
+    if use_graph:
         run_step = lambda: graphed()
     else:
         run_step = lambda: model.train_step(inputs, targets, precision=precision)[0]
