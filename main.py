@@ -50,7 +50,8 @@ def run(args):
     elif args.mode == "evaluation":
         loaders = dataset_eval if isinstance(dataset_eval, list) else [dataset_eval]
         for loader in loaders:
-            res = model.evaluate(loader, eval_steps=getattr(cfg, "eval_steps", args.eval_steps), verbose=args.verbose_eval)
+            res = model.evaluate(loader, eval_steps=getattr(cfg, "eval_steps", args.eval_steps), verbose=args.verbose_eval,
+                                 recompute_metrics=getattr(cfg, "recompute_metrics", False))
             if args.rank == 0:
                 print("Evaluation:", {k: round(v, 4) for k, v in res.items()})
     elif args.mode == "eval_time":

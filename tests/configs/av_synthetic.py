@@ -14,6 +14,7 @@ accumulated_steps = 1
 eval_training = False
 precision = torch.bfloat16
 epochs = 1
+recompute_metrics = True          # evaluation: the word error rate of the whole set from the gathered hypotheses (nnet/model.py:899-931), not the mean of per-batch rates
 callback_path = os.environ.get("AVEC_TEST_CALLBACKS", os.path.join(tempfile.gettempdir(), "avec_callbacks", "av_synthetic"))
 
 model = nnet.AudioVisualEfficientConformerInterCTC(vocab_size=vocab_size, v_interctc_blocks=[3, 6], a_interctc_blocks=[8, 11], f_interctc_blocks=[2])

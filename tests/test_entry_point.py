@@ -32,7 +32,7 @@ def test_main_training_resume_evaluation(tmp_path):
     assert "Mode: training" in out and "epoch 1 step 1" in out
     ckpts = [f for f in os.listdir(tmp_path) if f.endswith(".ckpt")]
     assert ckpts == ["checkpoints_epoch_1_step_2.ckpt"], ckpts
-    out = _run(["-c", cfg, "-m", "evaluation", "--load_last", "--eval_steps", "1"], env)
-    assert "Evaluation:" in out and "loss" in out
+    out = _run(["-c", cfg, "-m", "evaluation", "--load_last", "--eval_steps", "2"], env)
+    assert "Evaluation:" in out and "loss" in out and "'wer'" in out
     out = _run(["-c", cfg, "-m", "eval_time", "--load_last", "--eval_steps", "1"], env)
     assert "Eval time:" in out
