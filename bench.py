@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU multi-process debugging)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (before the HIP runtime starts) dmabuf IPC: RCCL and the peer exchange buffers need it on this driver
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))          # plain `python bench.py --gpus N`: start one rank per GPU ourselves (the reference self-spawns too, main.py:179-190)
