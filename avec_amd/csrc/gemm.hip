@@ -1488,8 +1488,10 @@ extern "C" int avec_gemm_tn_batched_store(int dtype, const void* P, long long ld
 // ---- grouped weight gradients -------------------------------------------------------------------------------------------------------------
 static bool tn_item_ok(int dtype, const avec_tn_item_t& t) {
   if (dtype != AVEC_BF16 || !t.P || !t.Q || !t.O || t.M <= 0 || t.I <= 0 || t.J <= 0) return false;
-  const int Iq = (t.ldp >= (t.I + 7) / 8 * 8) ? (t.I + 7) / 8 * 8 : t.I, Jq = (t.ldq >= (t.J + 7) / 8 * 8) ? (t.J + 7) / 8 * 8 : t.J;
-  if (!aligned16(t.P) || !aligned16(t.Q) || Iq % 8 || Jq % 8 || t.ldp % 8 || t.ldq % 8) return false;
+  // No alignment requirement: the LDS-DMA takes any source alignment (tools/glds_align_probe.hip).  Rows whose width is not a multiple of 8 elements are
+  // read in whole 16-byte chunks up to the next multiple of 8 -- past the row end into the next row, and past the LAST row by up to 14 bytes, which the
+  // caller must keep readable (include/avec_hip.h); whatever is read there only reaches output rows / columns >= I / J, which are not stored.
+  if (t.ldp < t.I || t.ldq < t.J) return false;
   if (t.p_colsum && (t.I % 4 || t.ldp % 4)) return false;
   return t.M < (1ll << 31) && t.ldp < (1ll << 31) && t.ldq < (1ll << 31) && t.ldo < (1ll << 31);
 }
@@ -1497,7 +1499,7 @@ extern "C" int avec_gemm_tn_grouped_ok(int dtype, const avec_tn_item_t* item) { 
 
 extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int n, hipStream_t stream) {
   AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_TN_GROUP_MAX, "gemm_tn_grouped: need 1..%d items (got %d)", AVEC_TN_GROUP_MAX, n);
-  for (int k = 0; k < n; ++k) AVEC_CHECK_ARG(tn_item_ok(dtype, items[k]), "gemm_tn_grouped: item %d is not eligible (bf16, 16-byte aligned operands, row strides %% 8 == 0)", k);
+  for (int k = 0; k < n; ++k) AVEC_CHECK_ARG(tn_item_ok(dtype, items[k]), "gemm_tn_grouped: item %d is not eligible (bf16 operands, row strides >= widths, bias sums need I %% 4 == 0)", k);
   // tile size: 128x128 tiles read each operand byte half as often as 64x64 (these products are bound by L2 traffic), but a group must still cover the
   // chip: take the big tile when the group has enough of them
   static const int bt_env = getenv("AVEC_TNG_TILE") ? atoi(getenv("AVEC_TNG_TILE")) : 0;
@@ -1518,7 +1520,7 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
   for (int k = 0; k < n; ++k) {
     const avec_tn_item_t& s = items[k]; TnItem& t = grp.it[k];
     t.P = s.P; t.Q = s.Q; t.O = s.O; t.pcs = s.p_colsum; t.ldp = (int)s.ldp; t.ldq = (int)s.ldq; t.ldo = (int)s.ldo; t.M = (int)s.M; t.I = s.I; t.J = s.J;
-    t.Iq = (s.ldp >= (s.I + 7) / 8 * 8) ? (s.I + 7) / 8 * 8 : s.I; t.Jq = (s.ldq >= (s.J + 7) / 8 * 8) ? (s.J + 7) / 8 * 8 : s.J;
+    t.Iq = (s.I + 7) / 8 * 8; t.Jq = (s.J + 7) / 8 * 8;
     t.rows_out = s.q_rows_out > 0 ? s.q_rows_out : 1; t.rows_in = s.q_rows_in > 0 ? s.q_rows_in : 1; t.step = s.q_step;
     long long mp = per; if (mp > s.M) mp = (s.M + 63) / 64 * 64;
     t.m_per_block = (int)mp; t.split = (int)((s.M + mp - 1) / mp);

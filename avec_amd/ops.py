@@ -82,7 +82,28 @@ def grad_of(p):
 
 
 def empty(shape, dtype, ref):
+    """uninitialised device tensor.  16-bit matrices whose row is not a whole number of 16-byte chunks (the 180-channel audio stage) get 16 readable bytes behind
+    the last row: the LDS-DMA kernels fetch whole chunks (avec_gemm_tn_grouped)."""
+    if dtype == torch.bfloat16 and len(shape) == 2 and shape[1] % 8:
+        n = shape[0] * shape[1]
+        return torch.empty(n + 8, dtype=dtype, device=ref.device)[:n].view(shape)
     return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+TNG_ALIGNED_ONLY = os.environ.get("AVEC_TNG_ALIGNED_ONLY", "0") == "1"       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
+
+
+def _chunk_readable(t, ld, width, rows):
+    """rows of `width` 16-bit elements at stride `ld`: may the kernels read whole 8-element chunks behind the last row?"""
+    if width % 8 == 0 and ld % 8 == 0 and t.data_ptr() % 16 == 0:
+        return True
+    if TNG_ALIGNED_ONLY:
+        return False
+    if ld >= (width + 7) // 8 * 8:
+        return True
+    st = t.untyped_storage()
+    end = (t.storage_offset() + (rows - 1) * ld + (width + 7) // 8 * 8) * t.element_size()
+    return end <= st.nbytes()
 
 
 def rows_plain(ld, rows_out=1, rows_in=1, step=0):
@@ -228,7 +249,7 @@ def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32
         it.P, it.Q, it.O, it.p_colsum = P.data_ptr(), Q.data_ptr(), O.data_ptr(), _p(p_colsum)
         it.ldp, it.ldq, it.ldo, it.M, it.I, it.J = (I if ldp is None else ldp), q_rows.ld, (J if ldo is None else ldo), M, I, J
         it.q_rows_out, it.q_rows_in, it.q_step = q_rows.rows_out, q_rows.rows_in, q_rows.step
-        if lib.raw("avec_gemm_tn_grouped_ok")(BF16, _byref(it)):
+        if lib.raw("avec_gemm_tn_grouped_ok")(BF16, _byref(it)) and _chunk_readable(P, it.ldp, I, M) and _chunk_readable(Q, it.ldq, J, M):
             q = _pending()
             q.tn.append(it)
             q.keep += [P, Q]

@@ -103,7 +103,9 @@ int avec_gemm_tn_bias(int dtype, const void* P, long long ldp, const void* Q, co
 /* Grouped weight gradients: up to AVEC_TN_GROUP_MAX independent products O_k[I_k][J_k] += P_k^T Q_k (+ optional column sums of P_k = bias gradients) as ONE launch --
  * the ~10 weight-gradient products of a ConformerBlock backward (nnet/blocks.py:289-306: two FFN modules, attention projections, two pointwise convs) only feed the
  * optimizer, so the caller may queue them and submit them together; one grid over all their tiles fills the chip where each product alone is latency-bound.
- * bf16 only, operands 16-byte aligned with row strides that are multiples of 8 elements (avec_gemm_tn_grouped_ok tells; others go through avec_gemm_tn_bias). */
+ * bf16 only (avec_gemm_tn_grouped_ok tells; others go through avec_gemm_tn_bias).  No alignment requirement.  Operand rows are read in 16-byte chunks up to the next
+ * multiple of 8 elements: when I (J) is not a multiple of 8 and ldp (ldq) is smaller than that multiple, the chunk runs into the next row, and behind the LAST row
+ * the caller must keep 16 bytes readable (what is read there never reaches a stored result). */
 #define AVEC_TN_GROUP_MAX 32
 typedef struct avec_tn_item {
   const void* P; const void* Q; float* O; float* p_colsum;

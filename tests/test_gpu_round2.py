@@ -347,7 +347,9 @@ def test_gemm_tn_grouped_matches_torch(tile):
     torch.manual_seed(0)
     d = dev()
     shapes = [(3200, 1024, 256, None, False), (3200, 256, 1024, None, True), (1600, 360, 360, 1080, True), (1600, 1440, 360, None, True),
-              (333, 64, 72, None, False), (800, 360, 256, None, True, 2), (70, 256, 256, None, True)]
+              (333, 64, 72, None, False), (800, 360, 256, None, True, 2), (70, 256, 256, None, True),
+              # the 180-channel audio stage: rows of 360 / 1080 bytes (8-byte aligned only), widths that are not a multiple of 8, a 2-byte-aligned column slice
+              (6400, 720, 180, None, True), (6400, 180, 720, None, True), (1613, 540, 180, None, True), (250, 180, 180, 541, False), (250, 180, 180, 544, True), (97, 44, 45, None, True)]
     if tile == "128":                            # enough 128x128 tiles in the group (>= 96) for the launcher to choose the big tile
         shapes.append((3200, 1440, 360, None, True))
     items, refs, outs, keep = [], [], [], []
@@ -355,9 +357,10 @@ def test_gemm_tn_grouped_matches_torch(tile):
         M, I, J, ldp, bias = sh[:5]
         step = sh[5] if len(sh) > 5 else 0
         ldp_ = ldp or I
-        P = torch.randn(M, ldp_, device=d).to(torch.bfloat16)
+        # (16 readable bytes behind the last row: rows that are not whole 16-byte chunks are fetched up to the next chunk boundary)
+        P = torch.randn(M * ldp_ + 8, device=d).to(torch.bfloat16)[:M * ldp_].view(M, ldp_)
         Mq = M * step if step else M
-        Q = torch.randn(Mq, J, device=d).to(torch.bfloat16)
+        Q = torch.randn(Mq * J + 8, device=d).to(torch.bfloat16)[:Mq * J].view(Mq, J)
         O = torch.randn(I, J, device=d)
         bsum = torch.randn(I, device=d) if bias else None
         Pv = P[:, ldp_ - I:] if ldp else P                        # a column slice (e.g. the V third of dQ|dK|dV)
@@ -376,11 +379,11 @@ def test_gemm_tn_grouped_matches_torch(tile):
         assert ((O.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3, sh
         if refb is not None:
             assert ((bsum.double() - refb).abs().max() / refb.abs().max()).item() < 2e-3, sh
-    # an unaligned operand (row stride 180 elements) is not eligible
+    # a row stride smaller than the width is refused
     bad = TnItem()
     P = torch.randn(64, 180, device=d).to(torch.bfloat16)
     bad.P, bad.Q, bad.O = P.data_ptr(), P.data_ptr(), outs[0][0].data_ptr()
-    bad.ldp, bad.ldq, bad.ldo, bad.M, bad.I, bad.J = 180, 180, 180, 64, 180, 180
+    bad.ldp, bad.ldq, bad.ldo, bad.M, bad.I, bad.J = 176, 180, 180, 64, 180, 180
     assert lib.raw("avec_gemm_tn_grouped_ok")(BF16, ctypes.byref(bad)) == 0
 
 
