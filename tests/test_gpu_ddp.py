@@ -61,7 +61,9 @@ def test_graphed_two_rank_step_equals_eager_two_rank_step(tmp_path):
     # steps, where a rounding-level difference in a near-zero gradient flips a whole update)
     ea, eb = a["exp_avg"].double(), b["exp_avg"].double()
     assert a["step"] == b["step"] == 3
-    assert ((ea - eb).norm() / ea.norm()).item() < 2e-3, ((ea - eb).norm() / ea.norm()).item()
+    # bf16 steps with atomically accumulated gradients are not bit-reproducible: two runs of the SAME mode differ by 1.5e-3 .. 1.9e-3 here, eager vs graph by
+    # 1.5e-3 .. 2.0e-3 (tools/gpu/dge.sh, six runs) -- the bound is twice that floor; a step that lost or doubled a term is O(0.1)
+    assert ((ea - eb).norm() / ea.norm()).item() < 4e-3, ((ea - eb).norm() / ea.norm()).item()
     moved = (a["master"] - a["master0"]).abs().max().item()
     assert moved > 0 and (b["master"] - b["master0"]).abs().max().item() > 0
     assert abs(a["loss"] - b["loss"]) < 1e-3 * abs(a["loss"])
