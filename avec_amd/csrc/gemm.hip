@@ -141,7 +141,8 @@ struct Epi {
 struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
                   // parity classes (backward-data of a stride-2 convolution, glds kernel): input pixels are visited class by class, class = (ih & 1) * 2 + (iw & 1);
                   // inside a class every row uses the same taps (kh = ih + pad mod 2, kw likewise), so a tile runs only those K-steps: 9 of 36 tap-rows for 3x3
-                  int perm2, pTs[5]; long long pImgs; };     // pTs: first tile of each class (pTs[4] = grid size), pImgs: images
+                  int perm2, pTs[5]; long long pImgs;        // pTs: first tile of each class (pTs[4] = grid size), pImgs: images
+                  int ktail; };                              // plain bf16 rows whose K is 8n + 4 (the 180- / 540-wide audio stage), glds kernel: the last chunk is fixed up in LDS
 
 __device__ __host__ __forceinline__ long long perm2_count(const RowSrc& s, int cls, long long imgs) {      // pixels of a class
   return imgs * ((s.H + 1 - (cls >> 1)) >> 1) * ((s.W + 1 - (cls & 1)) >> 1);
@@ -488,7 +489,11 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
     for (int i = 0; i < NCA; ++i) {
       const int k = kt * KE + ka[i];
       long long off;
-      if (MODE == MODE_PLAIN) off = (ra[i].valid && k < g.K) ? ra[i].base + k : -1;
+      if (MODE == MODE_PLAIN) {
+        off = (ra[i].valid && k < g.K) ? ra[i].base + k : -1;
+        // K = 8n + 4: the last chunk of a row runs 8 bytes into the next row (fixed up in LDS below); the last row of the matrix re-reads its own last 16 bytes instead
+        if (g.ktail && off >= 0 && k + VEC > g.K && m0 + (tid / CPR + i * RPP) == g.M - 1) off = ra[i].base + g.K - VEC;
+      }
       else {
         int tap, c;
         if (g.a.C % KE == 0) { const int k0 = kt * KE; tap = k0 / g.a.C; c = k0 - tap * g.a.C + ka[i]; } else { tap = k / g.a.C; c = k - tap * g.a.C; }
@@ -503,7 +508,9 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int k = kbase + kb[i];
-      const void* src = (rb[i].valid && k < g.K) ? (const void*)((const T*)g.W + rb[i].base + k) : (const void*)avec_zero16;
+      long long boffs = rb[i].base + k;
+      if (MODE == MODE_PLAIN && g.ktail && k + VEC > g.K && n0 + (tid / CPR + i * RPP) == g.N - 1) boffs = rb[i].base + g.K - VEC;
+      const void* src = (rb[i].valid && k < g.K) ? (const void*)((const T*)g.W + boffs) : (const void*)avec_zero16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (i * 256 + wave * 64) * 16), 16, 0, 0);
     }
     if (fast) {
@@ -541,6 +548,20 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
     if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    if (MODE == MODE_PLAIN && sizeof(T) == 2 && g.ktail && kt == KT - 1) {
+      // the chunk that holds elements K-4 .. K-1 also holds 4 elements of the next row: zero them (A rows, then W rows; the last row of each matrix was
+      // fetched 8 bytes early: move its upper half down first).  Nothing is in flight any more (vmcnt(0) above).
+      char* tile = smem + (kt % STAGES) * TILE;
+      const int ctail = ((g.K - 4) % KE) / VEC;
+      if (tid < BM + BN) {
+        const int row = tid < BM ? tid : tid - BM;
+        char* p = tile + (tid < BM ? 0 : BM * RB) + row * RB + ((ctail ^ glds_swz<RB>(row)) << 4);
+        const bool last = tid < BM ? (m0 + row == g.M - 1) : (n0 + row == g.N - 1);
+        if (last) *(uint2*)p = *(const uint2*)(p + 8);
+        *(uint2*)(p + 8) = make_uint2(0u, 0u);
+      }
+      __syncthreads();
+    }
     const char* As = smem + (kt % STAGES) * TILE; const char* Bs = As + BM * RB;
     // all operand fragments of the step are requested before the first MFMA (small tiles otherwise wait one LDS latency per MFMA:
     // the compiler keeps the reads next to their consumer); at most 2 K-substeps of fragments are held at a time for the big tiles
@@ -1207,6 +1228,11 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
   static const bool use_glds_ = getenv("AVEC_NO_GLDS") == nullptr;
+  static const bool no_ktail = getenv("AVEC_NO_KTAIL") != nullptr;
+  // plain bf16 products take the LDS-DMA kernel whatever their alignment (the DMA takes any source address); K = 8n + 4 with the in-LDS tail fix-up
+  const bool plain_any = sizeof(T) == 2 && mode == MODE_PLAIN && !f32src && use_glds_ && !no_ktail && (g.K % 8 == 0 || g.K % 8 == 4) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
+                         g.a.step <= 1;
+  g.ktail = (plain_any && g.K % 8 == 4) ? 4 : 0;
   if (g.perm2 && mode == MODE_CONV_BWD && g.fast_conv && a16 && !f32src && use_glds_) {     // parity-class order: only the fast LDS-DMA kernel knows it
     g.pTs[0] = 0; for (int c = 0; c < 4; ++c) g.pTs[c + 1] = g.pTs[c] + (int)((perm2_count(g.a, c, g.pImgs) + BM - 1) / BM);
     grid.x = (unsigned)g.pTs[4];
@@ -1227,7 +1253,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
-  if (a16 && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
+  if ((a16 || plain_any) && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G2
 #undef G3
 #undef G
@@ -1321,7 +1347,7 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   AVEC_CHECK_ARG(a_mode == AVEC_ROWS_PLAIN || (a_rows->C % vec == 0 && K == a_rows->KH * a_rows->KW * a_rows->C),
                  "gemm_nt: conv C=%d must be a multiple of %d and K = KH*KW*C", a_rows->C, vec);
   GemmArgs g; g.a = make_src(A, a_rows); g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
-  g.fast_conv = 0; g.perm2 = 0; g.pImgs = 0; for (int c = 0; c < 5; ++c) g.pTs[c] = 0;
+  g.fast_conv = 0; g.perm2 = 0; g.pImgs = 0; g.ktail = 0; for (int c = 0; c < 5; ++c) g.pTs[c] = 0;
   if (a_mode != AVEC_ROWS_PLAIN) {
     const int KE = dtype == AVEC_BF16 ? 64 : 32;
     const long long imgs = a_mode == MODE_CONV_FWD ? (M + (long long)a_rows->OH * a_rows->OW - 1) / ((long long)a_rows->OH * a_rows->OW) : (M + (long long)a_rows->H * a_rows->W - 1) / ((long long)a_rows->H * a_rows->W);

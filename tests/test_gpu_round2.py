@@ -700,3 +700,31 @@ def test_fp8_full_model_config5_shape_losses():
     finally:
         fp8.enable(False)
         avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(6400, 720, 180, None), (1613, 540, 180, None), (6400, 180, 540, None), (250, 180, 180, 542), (129, 64, 12, None), (37, 200, 180, 182),
+                                       (3200, 256, 360, None)])
+def test_gemm_nt_unaligned_rows_and_k_tail(M, N, K, lda):
+    """Linear products of the 180-channel audio stage through the LDS-DMA kernel: rows that are only 8- / 2-byte aligned, K = 8n + 4 with the tail chunk fixed
+    up in LDS (the 4 elements of the NEXT row it drags in must not reach the result; the last row of A and of W is fetched without reading behind the matrix:
+    both matrices sit at the very end of their allocation here).  Against fp64 torch with the bias + residual epilogue of nnet/modules.py:257-289."""
+    import avec_amd
+    from avec_amd import ops
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d = dev()
+        g = torch.Generator().manual_seed(M + N + K)
+        lda_ = lda or K
+        A = torch.randn(M, lda_, generator=g).bfloat16().to(d)
+        Av = A[:, lda_ - K:] if lda else A                       # a column slice: odd element offsets when lda - K is odd
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+        bias = torch.randn(N, generator=g).to(d)
+        res = torch.randn(M, N, generator=g).to(d)
+        out = torch.full((M, N), float("nan"), device=d)
+        ops.gemm_nt(Av, W, out, M, N, K, rows=ops.rows_plain(lda_), bias=bias, res=res, alpha=0.5, out_f32=True)
+        torch.cuda.synchronize()
+        ref = res.double() + 0.5 * (Av.double() @ W.double().t() + bias.double())
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, err                                   # fp32 accumulation of exact bf16 products: only the summation order differs
+    finally:
+        avec_amd.set_compute_dtype("f32")
