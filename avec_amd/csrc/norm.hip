@@ -676,6 +676,30 @@ extern "C" int avec_dropout_f32(const float* x, float* y, float p, const unsigne
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+// ---- stand-alone activations (nnet/activations.py:39-69): on the hot path they live in GEMM / BatchNorm epilogues; these entries serve a bare nnet.Swish()(x),
+// nnet.ReLU()(x), nnet.GLU(dim=-1)(x) on fp32 tensors.  act: 1 Swish, 2 ReLU, 3 GLU (x = [rows][2*C] -> y = [rows][C], a * sigmoid(b)) ----
+__global__ __launch_bounds__(256) void act_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int act, long long rows, int C, int bwd) {
+  const long long n = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    if (act == 3) {
+      const long long r = i / C; const int c = (int)(i - r * C);
+      const float a = x[r * 2 * C + c], b = x[r * 2 * C + C + c], sg = sigmoidf_(b);
+      if (!bwd) out[i] = a * sg;
+      else { const float g = dy[i]; out[r * 2 * C + c] = g * sg; out[r * 2 * C + C + c] = g * a * sg * (1.f - sg); }
+    } else {
+      const float v = x[i];
+      if (!bwd) out[i] = act == 1 ? swishf_(v) : fmaxf(v, 0.f);
+      else out[i] = dy[i] * (act == 1 ? dswishf_(v) : (v > 0.f ? 1.f : 0.f));
+    }
+  }
+}
+extern "C" int avec_act_f32(int act, const float* x, const float* dy, float* out, long long rows, int C, int backward, hipStream_t st) {
+  AVEC_CHECK_ARG(x && out && rows > 0 && C > 0 && act >= 1 && act <= 3 && (!backward || dy), "act_f32: bad arguments (act=%d)", act);
+  long long nb = (rows * C + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(act_f32_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, dy, out, act, rows, C, backward);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // =============================================================================================
 // patch attention helpers (nnet/attentions.py:348-382): avg-pool by P with zero padding (divisor P),
 // nearest up-sample x P sliced to T fused with dropout + residual add.

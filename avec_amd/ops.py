@@ -403,6 +403,32 @@ class LayerNormFn(torch.autograd.Function):
         return dx.view(shp), None, None, None
 
 
+class ActivationFn(torch.autograd.Function):
+    """stand-alone Swish / ReLU / GLU(dim=-1) (nnet/activations.py:39-69) on fp32 device tensors"""
+
+    @staticmethod
+    def forward(ctx, x, act, dim):
+        rt.require_gpu(x)
+        assert act in (1, 2, 3)
+        assert act != 3 or dim in (-1, x.dim() - 1), "GLU over the last axis"
+        x2 = _f32c(x)
+        C = x2.shape[-1] // 2 if act == 3 else x2.shape[-1]
+        assert act != 3 or x2.shape[-1] == 2 * C, "GLU needs an even last axis"
+        rows = x2.numel() // x2.shape[-1]
+        y = torch.empty(x2.shape[:-1] + (C,), dtype=torch.float32, device=x2.device)
+        lib.act_f32(act, x2.data_ptr(), None, y.data_ptr(), rows, C, 0, rt.stream())
+        ctx.saved = (x2, act, rows, C)
+        return y.to(x.dtype) if x.dtype != torch.float32 else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, act, rows, C = ctx.saved
+        dyc = _f32c(dy)
+        dx = torch.empty_like(x2)
+        lib.act_f32(act, x2.data_ptr(), dyc.data_ptr(), dx.data_ptr(), rows, C, 1, rt.stream())
+        return dx, None, None
+
+
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, sid):

@@ -196,6 +196,9 @@ int avec_softmax_fwd(int dtype, const float* logits, void* probs, long long M, i
 int avec_softmax_bwd(int dtype, const void* dprobs, const float* logits, float* dlogits, const float* dadd, long long M, int V, hipStream_t stream);
 int avec_cast_rows(int dtype, const float* src, long long ld_src, void* dst, long long ld_dst, long long M, int N, hipStream_t stream);
 int avec_to_f32_rows(int dtype, const void* src, long long ld_src, float* dst, long long ld_dst, long long M, int N, int accum, hipStream_t stream);
+/* Stand-alone activations on fp32 tensors (nnet/activations.py:39-69; on the hot path they are epilogues of the producing kernels): act 1 Swish, 2 ReLU,
+ * 3 GLU over the last axis (x [rows][2C] -> out [rows][C]).  backward != 0: out = d(loss)/dx from dy (GLU: out is [rows][2C]). */
+int avec_act_f32(int act, const float* x, const float* dy, float* out, long long rows, int C, int backward, hipStream_t stream);
 int avec_dropout_f32(const float* x, float* y, float p, const unsigned long long* rng, unsigned rng_stream, long long n, hipStream_t stream);
 /* patch attention pooling (layers.AvgPool1d / Upsample, nnet/attentions.py:342-346,365-380) */
 int avec_patch_pool_fwd(int dtype, const void* x, void* y, int B, int T, int D, int P, hipStream_t stream);

@@ -728,3 +728,20 @@ def test_gemm_nt_unaligned_rows_and_k_tail(M, N, K, lda):
         assert err < 1e-5, err                                   # fp32 accumulation of exact bf16 products: only the summation order differs
     finally:
         avec_amd.set_compute_dtype("f32")
+
+
+def test_standalone_activations_match_torch():
+    """nnet/activations.py:39-69: nnet.Swish / ReLU / GLU(dim=-1) called on their own (outside the fused composites) -- values and input gradients against torch"""
+    import nnet
+    d = dev()
+    torch.manual_seed(3)
+    for name, ref in (("Swish", lambda t: t * torch.sigmoid(t)), ("ReLU", torch.relu), ("GLU", lambda t: torch.nn.functional.glu(t, dim=-1))):
+        x = torch.randn(5, 37, 64, device=d, requires_grad=True)
+        y = nnet.activations.act_dict[name]()(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        xr = x.detach().clone().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(g)
+        assert y.shape == yr.shape and torch.allclose(y, yr, rtol=1e-5, atol=1e-6), name
+        assert torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-6), name
