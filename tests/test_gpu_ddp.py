@@ -67,3 +67,19 @@ def test_graphed_two_rank_step_equals_eager_two_rank_step(tmp_path):
     moved = (a["master"] - a["master0"]).abs().max().item()
     assert moved > 0 and (b["master"] - b["master0"]).abs().max().item() > 0
     assert abs(a["loss"] - b["loss"]) < 1e-3 * abs(a["loss"])
+
+
+def test_two_rank_evaluate_reduces_losses_and_gathers_hypotheses(tmp_path):
+    """Model.evaluate(recompute_metrics=True) on two ranks (nnet/model.py:899-931): every rank reports the same numbers, the loss is the mean over both shards'
+    batches and the corpus-level word error rate lies between the two shards' own rates"""
+    out = str(tmp_path / "eval.pt")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                    os.path.join(ROOT, "tools", "ddp_eval.py"), "--out", out], check=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=900)
+    r = torch.load(out)
+    (l0, l1), (g0, g1) = r["local"], r["global"]
+    assert g0.keys() == g1.keys() and all(abs(g0[k] - g1[k]) < 1e-9 for k in g0), (g0, g1)
+    assert "wer" in g0 and "loss" in g0
+    # bf16 forward passes are reproducible up to atomics order: the reduced loss is the mean of the two shards' means (same number of batches per shard)
+    assert abs(g0["loss"] - 0.5 * (l0["loss"] + l1["loss"])) < 2e-2 * abs(g0["loss"]), (g0["loss"], l0["loss"], l1["loss"])
+    lo, hi = min(l0["wer"], l1["wer"]), max(l0["wer"], l1["wer"])
+    assert lo - 1.0 <= g0["wer"] <= hi + 1.0, (g0["wer"], l0["wer"], l1["wer"])
