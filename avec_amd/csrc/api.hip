@@ -11,6 +11,13 @@ void avec_set_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* avec_last_error() { return g_err; }
+
+// name of the kernel instance the last GEMM-family entry point launched on this thread (bench.py's per-kernel roofline rows use it as the key)
+static thread_local char g_kname[128] = "";
+void avec_note_kernel(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_kname, sizeof(g_kname), fmt, ap); va_end(ap);
+}
+extern "C" const char* avec_last_kernel() { return g_kname; }
 extern "C" int avec_version() { return AVEC_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------

@@ -77,5 +77,6 @@ __device__ __forceinline__ float dswishf_(float x) { float s = sigmoidf_(x); ret
 // ---- host-side error plumbing (api.hip) ----
 extern "C" const char* avec_last_error();
 void avec_set_error(const char* fmt, ...);
+void avec_note_kernel(const char* fmt, ...);      // api.hip: remembers which kernel instance an entry point chose (avec_last_kernel)
 #define AVEC_CHECK_ARG(cond, ...) do { if (!(cond)) { avec_set_error(__VA_ARGS__); return -1; } } while (0)
 #define AVEC_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { avec_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)

@@ -476,6 +476,7 @@ extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long
   const int kinds = (C / 64) * (C / 128);
   const long long groups = (images + a.IT - 1) / a.IT;
   long long per_kind = 256 / kinds; if (per_kind < 1) per_kind = 1; if (per_kind > groups) per_kind = groups;
+  avec_note_kernel("wgrad3x3_wide_kernel");
   hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3((unsigned)(per_kind * kinds)), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;
@@ -498,6 +499,7 @@ extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const voi
   static const int wgs_env = getenv("AVEC_C3_WGS") ? atoi(getenv("AVEC_C3_WGS")) : 256;
   C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
+  avec_note_kernel("conv3x3_c64_kernel");
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;
@@ -515,6 +517,7 @@ extern "C" int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long 
   }
   C3WArgs a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W;
   const int grid = (int)(images < 256 ? images : 256);
+  avec_note_kernel("wgrad3x3_c64_kernel");
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;

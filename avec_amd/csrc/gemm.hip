@@ -1242,14 +1242,14 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   static const int rb_env = rb_env_set ? atoi(getenv("AVEC_NT_RB")) : 128;
   const size_t epi_lds = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4;
 #define G2(MODE, FC, RB_) do { const size_t l2 = (size_t)STG * (BM + BN) * RB_ > epi_lds ? (size_t)STG * (BM + BN) * RB_ : epi_lds; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>), grid, dim3(256), l2, st, g); return 0; } while (0)
+    avec_note_kernel("gemm_nt_glds_kernel<%s,%d,%d,%d,%d,%d,%d>", (sizeof(T) == 2 ? "bf16" : "float"), BM, BN, MODE, STG, (int)FC, RB_); if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, STG, FC, RB_>), grid, dim3(256), l2, st, g); return 0; } while (0)
   // 64-byte rows (K-step 32): half the ring, 4 resident workgroups per CU instead of 2 -- measured +4..18 % on the implicit-GEMM layers with
   // thousands of tiles, -16 % on the deep-K / few-tile ones (512-channel 3x3 stage): chosen by tile count.  AVEC_NT_RB=64/128 forces it.
   const long long ntiles = (long long)grid.x * grid.y;
   const bool rb64 = sizeof(T) == 2 && (rb_env_set ? rb_env == 64 : ntiles >= 1536);
   static const int stg_env = getenv("AVEC_NT_STG") ? atoi(getenv("AVEC_NT_STG")) : 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
 #define G3(MODE, S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
-    if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
+    avec_note_kernel("gemm_nt_glds_kernel<%s,%d,%d,%d,%d,1,64>", (sizeof(T) == 2 ? "bf16" : "float"), BM, BN, MODE, S_); if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
@@ -1257,7 +1257,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
 #undef G2
 #undef G3
 #undef G
-#define L(MODE, F, A) do { if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
+#define L(MODE, F, A) do { avec_note_kernel("gemm_nt_kernel<%s,%d,%d,%d,%d,%d>", (sizeof(T) == 2 ? "bf16" : "float"), BM, BN, MODE, (int)F, (int)A); if (int r = want_lds(gemm_nt_kernel<T, BM, BN, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
     else { if (a16) L(MODE_PLAIN, false, true); else L(MODE_PLAIN, false, false); }
@@ -1278,6 +1278,7 @@ static int launch_nt_wide(const GemmArgs& g_in, int mode, hipStream_t st) {
   } else g.perm2 = 0;
   const size_t epi_lds = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4, ring = (size_t)3 * (BM + BN) * 64;
   const size_t lds = ring > epi_lds ? ring : epi_lds;
+  avec_note_kernel("gemm_nt_glds_kernel<bf16,%d,%d,%d,3,1,64>", BM, BN, mode);
   if (mode == MODE_CONV_FWD) {
     if (int r = want_lds(gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>, lds)) return r;
     hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>), grid, dim3(256), lds, st, g);
@@ -1297,7 +1298,7 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
   GemmArgs g = g_in; g.perm2 = 0;
 #define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
-    if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
+    avec_note_kernel("conv3x3_shift_kernel<%d,%d,%d>", BM, BN, MODE); if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
   // 256-row tiles halve the weight-tile DMA per FLOP (measured 5-15 % on the 3200-image ResNet stages 2-3, slower once fewer than ~3 tiles per CU remain)
   static const int bm_env = getenv("AVEC_SHIFT_BM") ? atoi(getenv("AVEC_SHIFT_BM")) : 0;
   // tile height by wave quantisation: workgroups / (rounds * resident slots), slots = 256 CUs x 3 (128 rows, 136 VGPRs) or x 2 (256 rows, 237 VGPRs);
@@ -1432,7 +1433,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
       static const int kt_env = getenv("AVEC_TN_KT") ? atoi(getenv("AVEC_TN_KT")) : 32;
       const long long q_elems = mode == MODE_PLAIN ? 0 : ((g.M + (long long)g.q.OH * g.q.OW - 1) / ((long long)g.q.OH * g.q.OW) + 1) * g.q.H * g.q.W * g.q.C;
       const bool q32 = q_elems < (1ll << 31);
-#define LT(MODE, Q32, KT_) do { const size_t l2 = (size_t)2 * KT_ * (BI + BJ) * 2; if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>, l2)) return r; \
+#define LT(MODE, Q32, KT_) do { const size_t l2 = (size_t)2 * KT_ * (BI + BJ) * 2; avec_note_kernel("gemm_tn_tr_kernel<%d,%d,%d,2,%d,%d>", BI, BJ, MODE, (int)Q32, KT_); if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>, l2)) return r; \
         hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>), grid, dim3(256), l2, st, g); return 0; } while (0)
 #define LK(KT_) do { if (mode == MODE_PLAIN) LT(MODE_PLAIN, false, KT_); else if (q32) LT(MODE_CONV_FWD, true, KT_); else LT(MODE_CONV_FWD, false, KT_); } while (0)
       if (kt_env == 64) LK(64); else LK(32);
@@ -1444,7 +1445,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
     static const bool side_wgrad = getenv("AVEC_WGRAD_STREAM") && getenv("AVEC_WGRAD_STREAM")[0] == '1';
     if (int r = colsum_launch(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, !side_wgrad, st)) return r;
   }     // kernels without the fused column sums
-#define L(MODE, F, A) do { if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
+#define L(MODE, F, A) do { avec_note_kernel("gemm_tn_kernel<%s,%d,%d,%d,%d,%d>", (sizeof(T) == 2 ? "bf16" : "float"), BI, BJ, MODE, (int)F, (int)A); if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
     else { if (a16) L(MODE_PLAIN, false, true); else L(MODE_PLAIN, false, false); }
@@ -1555,6 +1556,7 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
   }
   grp.total = first;
   const size_t lds = (size_t)2 * 32 * (BT + BT) * 2;
+  avec_note_kernel("gemm_tn_tr_grouped_kernel<%d>", BT);
   if (BT == 128) {
     if (int r = want_lds(gemm_tn_tr_grouped_kernel<128>, lds)) return r;
     hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel<128>, dim3((unsigned)first), dim3(256), lds, stream, grp);

@@ -374,7 +374,13 @@ extern "C" int avec_argmax_rows(const float* x, long long* out, long long M, int
 // g <- g*gscale; g += wd*p; m,v updates; p -= lr * mhat / (sqrt(v)/sqrt(bc2) + eps);  optionally zero the gradient arena.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ state,
-                                                   float beta1, float beta2, float eps, float wd, float gscale, int zero_grad, long long n4) {
+                                                   float beta1, float beta2, float eps, float wd, float gscale, int zero_grad, long long n4, const int* __restrict__ skip_flag) {
+  // skip_flag (optional, device): non-zero = this step's gradients are poisoned (a SyncBatchNorm peer exchange timed out and produced NaN sums):
+  // parameters and moments stay untouched, the gradient arena is still cleared so that the next step starts clean
+  if (skip_flag && *skip_flag != 0) {
+    if (zero_grad) for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) { const float z[4] = {0.f, 0.f, 0.f, 0.f}; st4<float>(g + i * 4, z); }
+    return;
+  }
   const float step = state[0], lr = state[1];
   const float bc1 = 1.f - powf(beta1, step), bc2s = sqrtf(1.f - powf(beta2, step));
   const float step_size = lr / bc1;
@@ -392,12 +398,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     if (zero_grad) st4<float>(g + i * 4, gg);
   }
 }
-extern "C" int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
-                              float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t st) {
+extern "C" int avec_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
+                                      float weight_decay, float grad_scale, int zero_grad, long long n, const int* skip_flag, hipStream_t st) {
   AVEC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && state_dev && n > 0 && n % 4 == 0, "adam_step: bad arguments (n=%lld must be a multiple of 4)", n);
   long long n4 = n / 4; long long nb = (n4 + 255) / 256; if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, state_dev, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, n4);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, state_dev, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, n4, skip_flag);
   AVEC_LAUNCH_CHECK(); return 0;
+}
+extern "C" int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t st) {
+  return avec_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, state_dev, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, n, nullptr, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
 #pragma unroll
     for (int k = 0; k < 16; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     mean = s1 / n; var = fmaxf(s2 / n - mean * mean, 0.f);
-    if (rmean) {
+    if (rmean && isfinite(mean) && isfinite(var)) {      // (a SyncBatchNorm exchange that lost a rank delivers NaN sums: the running statistics must survive that step)
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
       if (c == 0 && nbt) *nbt += 1;

@@ -156,6 +156,7 @@ class Model(Module):
     def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
         batch_losses, batch_metrics, batch_truths, batch_preds = {}, {}, {}, {}
         total_loss = torch.zeros((), device=self.device)
+        Model._pre_forward(self, None)       # self.forward() is called directly (no __call__): the pre-forward hook would not fire on the training / evaluation paths
         outputs = self.forward(inputs)
         if isinstance(outputs, list):
             outputs = {"output_" + str(k): v for k, v in enumerate(outputs)}
@@ -268,7 +269,12 @@ class Model(Module):
         with torch.cuda.graph(graph):                   # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
             static_losses = body()
 
+        replays = [0]
+
         def step(new_inputs=None, new_targets=None):
+            replays[0] += 1
+            if dist_mode and replays[0] % 100 == 0:
+                peer.active().check()               # (synchronises) a lost rank: the guarded Adam launch skipped those steps, say so instead of training on
             if new_inputs is not None:
                 for d, s_ in zip(static_in, new_inputs):
                     d.copy_(s_, non_blocking=True)
@@ -279,6 +285,8 @@ class Model(Module):
             finish()
             return static_losses
 
+        if dist_mode:
+            self.arena.arm_early_all_reduce(os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0")      # later eager train_steps keep their overlapped exchange
         step.graph = graph
         return step
 
@@ -363,11 +371,18 @@ class Model(Module):
                 break
         if self.is_distributed:                             # sum over ranks (nnet/model.py:912-918: reduce_losses_metrics / gather_truths_preds)
             import torch.distributed as dist
-            keys = sorted(sums)
+            # every collective below must be issued by every rank with the same shapes, whatever this rank saw (zero batches, no list-type hypotheses):
+            # agree on the key sets first
+            all_keys = [None] * dist.get_world_size()
+            dist.all_gather_object(all_keys, (sorted(sums), bool(truths)))
+            keys = sorted(set(k for ks, _ in all_keys for k in ks))
+            for k in keys:
+                sums.setdefault(k, 0.0)
+            any_truths = any(t for _, t in all_keys)
             vec = torch.tensor([sums[k] for k in keys] + [float(count)], dtype=torch.float64, device=self.device if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(vec)
             sums, count = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}, int(vec[-1].item())
-            if truths:
+            if any_truths:
                 gathered = [None] * dist.get_world_size()
                 dist.all_gather_object(gathered, (truths, preds))
                 truths, preds = {}, {}

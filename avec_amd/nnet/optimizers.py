@@ -70,9 +70,11 @@ class Adam(optim.Adam):
         return None
 
     def _launch(self, g):
-        lib.adam_step(self.arena.master.data_ptr(), self.arena.grad.data_ptr(), self._flat["exp_avg"].data_ptr(), self._flat["exp_avg_sq"].data_ptr(),
-                      self._flat["state"].data_ptr(), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale, 1,
-                      self.arena.numel, rt.stream())
+        from .. import peer
+        px = peer.active()            # data parallel with the peer exchange: its device error flag guards the update (a lost rank -> NaN sums -> skipped step)
+        lib.adam_step_guarded(self.arena.master.data_ptr(), self.arena.grad.data_ptr(), self._flat["exp_avg"].data_ptr(), self._flat["exp_avg_sq"].data_ptr(),
+                              self._flat["state"].data_ptr(), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.grad_scale, 1,
+                              self.arena.numel, px.err.data_ptr() if px is not None else None, rt.stream())
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:

@@ -38,32 +38,37 @@ class KernelTimer:
     def stop(self, e0, key, flops):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((key, flops, e0, e1))
+        name = lib.raw("avec_last_kernel")()                  # the kernel instance the entry point chose (api.hip)
+        self.records.append((key, flops, e0, e1, name.decode() if name else ""))
 
-    def summary(self, peak_tflops):
+    def summary(self, peak_tflops, steps=1):
+        """`roofline` object of bench.py: one row per kernel INSTANCE (rocprofv3's kernel names), the top row = the kernel with the largest total time;
+        `families` groups the same launches by addressing mode.  FLOPs are algorithmic (2 x MACs of the product the launch stands for: structurally
+        zero taps of a strided backward-data convolution are not counted)."""
         if not self.records:
             return None
         torch.cuda.synchronize()
-        agg = {}
-        for key, flops, e0, e1 in self.records:
+        agg, rows = {}, {}
+        for key, flops, e0, e1, name in self.records:
+            dt = e0.elapsed_time(e1) * 1e-3
             a = agg.setdefault(key, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
-            a[1] += flops
-            a[2] += 1
-        # the dominant KERNEL = the GEMM template (NT: forward / backward-data products and implicit-GEMM convolutions; TN: weight gradients) with the
-        # largest total time; its addressing-mode families are listed below it
-        tmpl = {}
-        for k, v in agg.items():
-            a = tmpl.setdefault(k[0], [0.0, 0.0, 0])
-            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]
-        kid = max(tmpl, key=lambda k: tmpl[k][0])
-        t, fl, n = tmpl[kid]
-        achieved = fl / t / 1e12
-        return {"bound": "mfma", "kernel": {0: "gemm_nt (plain + implicit-GEMM conv fwd / bwd-data)", 1: "gemm_tn (weight gradients)", 2: "conv3x3_c64 slab kernel", 3: "ffn_fused (macaron feed-forward)"}[kid],
-                "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s",
-                "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
-                "alg_gflop_per_launch": round(fl / n / 1e9, 3),
-                "families": {self.NAMES.get(k, str(k)): {"ms_total": round(1e3 * v[0], 3), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2]}
+            a[0] += dt; a[1] += flops; a[2] += 1
+            r = rows.setdefault(name or self.NAMES.get(key, str(key)), [0.0, 0.0, 0])
+            r[0] += dt; r[1] += flops; r[2] += 1
+
+        def row(name, v):
+            return {"kernel": name, "launches_per_step": round(v[2] / steps, 1), "avg_us": round(1e6 * v[0] / v[2], 2), "ms_per_step": round(1e3 * v[0] / steps, 3),
+                    "alg_gflop_per_launch": round(v[1] / v[2] / 1e9, 3), "tflops": round(v[1] / v[0] / 1e12, 1), "frac": round(v[1] / v[0] / 1e12 / peak_tflops, 4)}
+        ordered = sorted(rows.items(), key=lambda kv: -kv[1][0])
+        top_name, top = ordered[0]
+        t_all = sum(v[0] for v in rows.values()); f_all = sum(v[1] for v in rows.values())
+        achieved = top[1] / top[0] / 1e12
+        return {"bound": "mfma", "kernel": top_name, "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(achieved / peak_tflops, 5), "traffic": None, "launches": round(top[2] / steps, 1), "avg_launch_ms": round(1e3 * top[0] / top[2], 5),
+                "alg_gflop_per_launch": round(top[1] / top[2] / 1e9, 3),
+                "rows": [row(n, v) for n, v in ordered[:8]],
+                "gemm_family_total": {"ms_per_step": round(1e3 * t_all / steps, 3), "tflops": round(f_all / t_all / 1e12, 1), "frac": round(f_all / t_all / 1e12 / peak_tflops, 4)},
+                "families": {self.NAMES.get(k, str(k)): {"ms_total": round(1e3 * v[0] / steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": round(v[2] / steps, 1)}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
 
 
@@ -141,7 +146,7 @@ def gemm_nt_fp8(A, ent, out, M, N, K, *, bias=None, act=ACT_NONE, out_pre=None, 
 
 def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
             drop_p=0.0, sid=0, res=None, res_act=False, alpha=1.0, dact_z=None, dact=0, colsum=None, stats=None, out_f32=False,
-            ldo=None, ldres=None, dtype=None):
+            ldo=None, ldres=None, dtype=None, flops=None):
     ep = Epilogue()
     ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
     if out_pre is not None:
@@ -162,7 +167,7 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     lib.gemm_nt(rt.dt() if dtype is None else dtype, A.data_ptr(), _byref(rows), mode, int(a_f32), W.data_ptr(),
                 K if ldw is None else ldw, M, N, K, _byref(ep), rt.stream())
     if ev is not None:
-        KERNEL_TIMER.stop(ev, (0, mode), 2.0 * M * N * K)
+        KERNEL_TIMER.stop(ev, (0, mode), 2.0 * M * N * K if flops is None else flops)
     return out
 
 
@@ -195,6 +200,9 @@ def _pending():
         q = _DEFER["queues"][st.cuda_stream] = _PendingGrads(st)
     task = torch._C._current_graph_task_id()
     if _DEFER["task"] != task:                    # first queued item of this backward pass: flush whatever is left when the pass ends
+        if _DEFER["task"] != -1:                  # the previous pass never reached its end-of-pass callback (it raised midway): its queued products
+            for old in _DEFER["queues"].values():  # belong to another batch and must not be added to this step's gradients
+                old.tn, old.ln, old.keep, old.flops = [], [], [], 0.0
         _DEFER["task"] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end)
     return q
@@ -280,7 +288,7 @@ def layernorm_fwd(x, w, b, M, D, out_f32, eps):
 def layernorm_bwd(dy, dy_f32, x, mean, rstd, w, b, M, D, dres=None):
     dx = empty((M, D), torch.float32, x)
     gw, gb = grad_of(w), grad_of(b)
-    if D <= 1024 and _in_backward():          # dx now (one wave per row); d(gamma), d(beta) with the other queued parameter gradients
+    if D <= 1024 and D % 4 == 0 and _in_backward():          # (the dx-only kernel and the grouped launch use 4-wide accesses) dx now (one wave per row); d(gamma), d(beta) with the other queued parameter gradients
         lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
                           None, None, M, D, rt.stream())
         it = LnItem()
@@ -466,7 +474,7 @@ def defer_ln_param_grads(dy, dy_f32, x, mean, rstd, w, b, M, D):
     it = LnItem()
     it.dy, it.x, it.mean, it.rstd, it.dgamma, it.dbeta = dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), grad_of(w).data_ptr(), grad_of(b).data_ptr()
     it.M, it.D, it.dy_f32 = M, D, int(dy_f32)
-    if _in_backward():
+    if _in_backward() and D % 4 == 0 and D <= 1024:
         q = _pending()
         q.ln.append(it)
         q.keep += [dy, x, mean, rstd]
@@ -1198,8 +1206,10 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 1), 2.0 * N * H * W * Cin * KH * KW * Cout)
         return dx
+    # algorithmic work of the backward-data product: one MAC per (output pixel, tap, Cin, Cout) -- for stride 2 three of four taps of the implicit GEMM
+    # over input pixels are structurally zero and are skipped by the parity-class kernel: they are not counted
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
-            res=dx_res, res_act=True)
+            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return dx
 
 
@@ -1261,6 +1271,7 @@ class ResNetBlockFn(torch.autograd.Function):
 
 
 STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels
+STEM3P = os.environ.get("AVEC_STEM3P", "1") != "0"                    # ... with the max pool inside the convolution kernel and the pre-pool tensor recomputed in backward (stem3p.hip)
 
 
 class VideoStemFn(torch.autograd.Function):
@@ -1279,6 +1290,23 @@ class VideoStemFn(torch.autograd.Function):
         st = BNState(C, v)
         K, Kp = sh.Tm * sh.C, sh.Cp
         y = empty((M, C), rt.act_dtype(), v)
+        if (STEM3P and STEM3D_DIRECT and rt.compute_dtype() == "bf16" and C == 64 and K == 245 and lib.raw("avec_stem3p_supported")(B, T, H, W)
+                and lib.raw("avec_stem3d_supported")(B, T, H, W)):
+            # round 3 (stem3p.hip): the max pool runs on the raw conv output inside the convolution kernel (BatchNorm + ReLU is monotone per channel); the
+            # 793 MB pre-pool tensor never reaches memory, the backward pass recomputes it
+            w8 = torch.zeros((C, 36, 8), dtype=sh.fwd.dtype, device=v.device)         # (kd,kh) rows: zero slot, then the 7 taps
+            w8[:, :35, 1:] = sh.fwd.view(C, Kp)[:, :K].view(C, 35, 7)
+            vb = v.to(torch.bfloat16)
+            PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+            zp = torch.empty((B * T, PH, PW, C), dtype=torch.bfloat16, device=v.device)
+            idx = torch.empty((B * T, PH, PW, C), dtype=torch.uint8, device=v.device)
+            lib.stem3p_fwd(vb.data_ptr(), w8.data_ptr(), _p(conv.bias), bn.weight.data_ptr(), zp.data_ptr(), idx.data_ptr(), st.stats.data_ptr() if training else None,
+                           B, T, H, W, rt.stream())
+            cp = bn_finalize(bn, st, M, training)
+            out = torch.empty_like(zp)
+            lib.bn_apply_fwd(rt.dt(), zp.data_ptr(), st.ss.data_ptr(), None, ACT_RELU, out.data_ptr(), B * T * PH * PW, C, rt.stream())
+            ctx.saved = (v, None, idx, st, cp, conv, bn, ("p", vb, w8, zp, PH, PW), B, T, OH, OW, C, M, K, training, None)
+            return out
         if STEM3D_DIRECT and rt.compute_dtype() == "bf16" and C == 64 and K == 245 and lib.raw("avec_stem3d_supported")(B, T, H, W):
             # direct kernels (stem3d.hip): the input band is staged in LDS, no im2col matrix in HBM
             w8 = torch.zeros((C, 36, 8), dtype=sh.fwd.dtype, device=v.device)         # (kd,kh) rows of 7 taps + a zero slot (stem3d.hip)
@@ -1305,6 +1333,22 @@ class VideoStemFn(torch.autograd.Function):
         v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training, ymax = ctx.saved
         assert training, "VideoStem backward is implemented for training-mode BatchNorm"
         dpool = dpool.to(rt.act_dtype()).contiguous()
+        if isinstance(r, tuple):                                # stem3p: ReLU mask + BatchNorm-backward sums over the pooled tensor, then dz from the RECOMPUTED conv output
+            _, vb, w8, zp, PH, PW = r
+            H, W = v.shape[2], v.shape[3]
+            dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
+            lib.stem3p_reduce(dpool.data_ptr(), zp.data_ptr(), st.ss.data_ptr(), dstats.data_ptr(), B * T, PH, PW, rt.stream())      # (dpool is masked in place)
+            gw, gb = grad_of(bn.weight), grad_of(bn.bias)
+            dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
+            if synced:
+                gw = gb = None
+            dy = empty((M, C), rt.act_dtype(), v)
+            lib.stem3p_dz(vb.data_ptr(), w8.data_ptr(), _p(conv.bias), dpool.data_ptr(), idx.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M),
+                          dy.data_ptr(), _p(gw), _p(gb), B, T, H, W, rt.stream())
+            lib.stem3d_wgrad(v.data_ptr(), dy.data_ptr(), grad_of(conv.weight).data_ptr(), B, T, H, W, rt.stream())
+            if conv.bias is not None:
+                grad_of(conv.bias)
+            return None, None, None, None, None
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
         args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
         if ymax is not None:

@@ -13,6 +13,7 @@ from .lib import lib
 MAX_WORLD = 8
 MAXN = 2056          # granules per slot: vectors of up to 2*1024 + 1 floats (BatchNorm widths <= 1024)
 SITES = 256          # distinct exchange sites (a BatchNorm layer uses two: forward statistics, backward sums)
+TIMEOUT_MS = int(float(os.environ.get("AVEC_PEER_TIMEOUT_S", "600")) * 1000)      # device-side spin limit of one exchange
 
 
 class PeerExchange:
@@ -25,7 +26,9 @@ class PeerExchange:
         self.site_granules = 2 * world * MAXN                     # two parity pages of world slots
         self._own, self._opened, self.bases, self.sites = None, [], [], {}
         self.epochs = self.err = None
-        self.timeout_ms = 30000
+        # a late rank (dataloader stall, checkpoint I/O, an uneven last batch) must not poison the step: wait as long as a collective would
+        # (RCCL's default is minutes); the Adam launch is additionally guarded by `err` (optimizers.Adam._launch)
+        self.timeout_ms = TIMEOUT_MS
 
     def allocate(self):
         """-> the 64-byte IPC handle of this rank's exchange buffer"""
@@ -66,7 +69,7 @@ class PeerExchange:
     def check(self):
         """host-side: raise if a peer ever failed to arrive (synchronises)"""
         if int(self.err.item()) != 0:
-            raise RuntimeError("avec_amd.peer: a SyncBatchNorm peer exchange timed out (a rank did not arrive within %d s)" % (self.timeout_ms // 1000))
+            raise RuntimeError("avec_amd.peer: a SyncBatchNorm peer exchange timed out (a rank did not arrive within %d s); the optimizer steps since then were skipped" % (self.timeout_ms // 1000))
 
     def close(self):
         for p in self._opened:
@@ -131,7 +134,7 @@ def setup(device, group=None):
             dist.all_reduce(ref, group=group)
             torch.cuda.synchronize(device)
             good = good and torch.equal(got.cpu(), ref.cpu()) and int(px.err.item()) == 0
-    px.timeout_ms = 30000
+    px.timeout_ms = TIMEOUT_MS
     if not _agree(good, device, group):
         print("[avec_amd.peer] rank %d: peer exchange self-test failed; SyncBatchNorm statistics go through torch.distributed" % rank, flush=True)
         px.close()

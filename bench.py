@@ -112,6 +112,19 @@ def pmc_traffic(family):
     return round(tot / n) if n else None
 
 
+def pmc_traffic_kernel(kernel):
+    """HBM bytes per launch (fetch + write) of ONE kernel instance from the newest committed rocprofv3 --pmc summary; None when absent"""
+    path = pmc_summary_path()
+    if not kernel or path is None:
+        return None
+    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace("__hip_bfloat16", "bf16")
+    want = norm(kernel)
+    for name, v in json.load(open(path))["kernels"].items():
+        if norm(name).split("(")[0] == want:
+            return round(v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0))
+    return None
+
+
 def spawn_ranks(n):
     """Re-run this command under torch.distributed.run with `n` ranks on this node (free rendezvous port on 127.0.0.1); rank 0 prints the JSON line."""
     import socket
@@ -223,9 +236,12 @@ def main():
         from avec_amd import runtime as rt
         rt.set_branch_streams(False)
         ops.KERNEL_TIMER.reset(enabled=(rank == 0))
-        for _ in range(min(args.steps, 3)):
+        timed_steps = min(args.steps, 3)
+        te0 = time.perf_counter()
+        for _ in range(timed_steps):
             model.train_step(inputs, targets, precision=precision)
         barrier()
+        eager_ms = 1000 * (time.perf_counter() - te0) / timed_steps      # eager, single-stream, event-instrumented step: an upper bound of the eager fallback's cost
         ops.KERNEL_TIMER.enabled = False
         rt.set_branch_streams(os.environ.get("AVEC_BRANCH_STREAMS", "1") != "0")
     if world > 1:
@@ -241,9 +257,9 @@ def main():
         utt = world * args.batch * args.steps
         value = utt / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        roof = ops.KERNEL_TIMER.summary(peak)
+        roof = ops.KERNEL_TIMER.summary(peak, steps=timed_steps) if not args.no_kernel_timing else None
         if roof is not None and args.dtype == "bf16" and args.batch == 32:
-            roof["traffic"] = pmc_traffic(roof["kernel"])
+            roof["traffic"] = pmc_traffic_kernel(roof["kernel"])
             roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/%s)" % os.path.basename(pmc_summary_path() or "none")
         out = {
             "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",
@@ -252,7 +268,8 @@ def main():
             "config": {"workload": "AV EffConfInterCTC (LRS23/AV) training step: fwd + 6 CTC losses + bwd + grad all-reduce + Adam; "
                                    "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),
-                       "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5)},
+                       "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5),
+                       "eager_instrumented_ms_per_step": (round(eager_ms, 2) if not args.no_kernel_timing else None)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -38,6 +38,8 @@ extern "C" {
 
 int avec_version(void);
 const char* avec_last_error(void);
+/* the kernel instance chosen by the last GEMM-family entry point called on this thread ("gemm_nt_glds_kernel<bf16,64,64,0,4,0,128>" ...): measurement aid, bench.py's roofline rows */
+const char* avec_last_kernel(void);
 /* Optional scratch for the two-pass column reductions (LayerNorm / BatchNorm / depthwise-conv parameter-gradient sums): a 256-byte aligned
  * device buffer (>= 64 KB; 32 MB serves every shape of the AV model) registered for the current device.  Without it those kernels fall back
  * to one float atomic per column per workgroup.  The buffer must stay alive and must not be used by two streams at once.
@@ -264,6 +266,20 @@ int avec_stem_im2col(int dtype, const float* video, void* A, long long clips, in
 int avec_stem3d_supported(long long clips, int T, int H, int W);
 int avec_stem3d_fwd(const float* video, const void* w_shadow, int ldw, const float* bias, void* y, float* stats, long long clips, int T, int H, int W, hipStream_t stream);
 int avec_stem3d_wgrad(const float* video, const void* dy, float* dw, long long clips, int T, int H, int W, hipStream_t stream);
+/* Round 3: the same stem WITHOUT the pre-pool activation in memory (avec_amd/csrc/stem3p.hip).  BatchNorm + ReLU is monotone per channel, so the max pool is taken on the raw
+ * conv output (max for gamma >= 0, min for gamma < 0) inside the convolution kernel:
+ *   avec_stem3p_fwd   : video_bf16 [clips][T][H][W] (W % 8 == 0), w_shadow bf16 [64][36][8] (slot 0 of every (kd,kh) row and row 35 zero, slots 1..7 = kw 0..6), gamma = the
+ *                       BatchNorm weight -> zp act [clips*T][PH][PW][64] (raw conv output of each window's winner), idx u8 (window slot kh*3+kw), stats fp32 [2*64] += (sum, sumsq) of z
+ *                       (then avec_bn_finalize + avec_bn_apply_fwd(zp, ReLU) give the pooled activation);
+ *   avec_stem3p_reduce: dpool <- dpool * [scale*zp+shift > 0] in place, dstats [2*64] += (sum d, sum d * xhat) over the pooled tensor;
+ *   avec_stem3p_dz    : recomputes z and writes dz [clips*T*OH*OW][64] = gamma*rstd*(route(dpool) - mean(dy) - xhat*mean(dy*xhat)) (the operand of avec_stem3d_wgrad); dgamma/dbeta += dstats. */
+int avec_stem3p_supported(long long clips, int T, int H, int W);
+int avec_stem3p_fwd(const void* video_bf16, const void* w_shadow, const float* bias, const float* gamma, void* zp, unsigned char* idx, float* stats,
+                    long long clips, int T, int H, int W, hipStream_t stream);
+int avec_stem3p_reduce(void* dpool, const void* zp, const float* ss, float* dstats, long long frames, int PH, int PW, hipStream_t stream);
+int avec_stem3p_dz(const void* video_bf16, const void* w_shadow, const float* bias, const void* dpool_masked, const unsigned char* idx, const float* ss,
+                   const float* gamma, const float* dstats, const float* count_ptr, float count, void* dz, float* dgamma, float* dbeta,
+                   long long clips, int T, int H, int W, hipStream_t stream);
 /* ymax (optional, act, pooled shape): the conv output under each window's winning tap -- lets avec_stem_pool_bwd_reduce_pooled compute the BatchNorm-backward sums from
  * pooled-size tensors instead of the full-resolution conv output */
 int avec_stem_pool_fwd(int dtype, const void* y, const float* ss, void* out, unsigned char* idx, void* ymax, long long frames, int H, int W, int C, hipStream_t stream);
@@ -318,6 +334,10 @@ int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStre
 /* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */
 int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, int zero_grad, long long n, hipStream_t stream);
+/* the same with a device-side guard: *skip_flag != 0 (the SyncBatchNorm peer exchange's error flag: a rank did not arrive and the sums of this step are NaN)
+ * leaves parameters and moments untouched and only clears the gradient arena -- the step is skipped instead of poisoning the model state */
+int avec_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
+                           float weight_decay, float grad_scale, int zero_grad, long long n, const int* skip_flag, hipStream_t stream);
 /* Compute-dtype copies of the GEMM weights (master fp32 [A][Tm][C]): fwd = same order, bwd = [C][Tm][A].  table entry = 10 x int64: src_off, fwd_off|-1,
  * bwd_off|-1, A, Tm, C, first_block, n_blocks = Tm*ceil(A/32)*ceil(C/32) (one workgroup per 32x32 tile and tap), C_pad (row stride of the fwd
  * shadow when Tm==1), bwd row pitch (0: Tm*A; larger when several weights share one [C][G*A] backward matrix, e.g. Q|K|V) */

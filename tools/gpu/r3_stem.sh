@@ -1,0 +1,6 @@
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "visual_stem" > gpurun_out/r3_stem_test.log 2>&1
+tail -15 gpurun_out/r3_stem_test.log
+timeout 300 python tools/bench_stem.py > gpurun_out/r3_stem_bench.log 2>&1
+tail -6 gpurun_out/r3_stem_bench.log
