@@ -1271,6 +1271,7 @@ class ResNetBlockFn(torch.autograd.Function):
 
 
 STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels
+STEM3P_FUSED_WGRAD = os.environ.get("AVEC_STEM3P_FUSED", "1") != "0"  # ... and the weight gradient computed from the recomputed tiles in the same kernel (no dz tensor)
 STEM3P = os.environ.get("AVEC_STEM3P", "1") != "0"                    # ... with the max pool inside the convolution kernel and the pre-pool tensor recomputed in backward (stem3p.hip)
 
 
@@ -1342,10 +1343,15 @@ class VideoStemFn(torch.autograd.Function):
             dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
             if synced:
                 gw = gb = None
-            dy = empty((M, C), rt.act_dtype(), v)
-            lib.stem3p_dz(vb.data_ptr(), w8.data_ptr(), _p(conv.bias), dpool.data_ptr(), idx.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M),
-                          dy.data_ptr(), _p(gw), _p(gb), B, T, H, W, rt.stream())
-            lib.stem3d_wgrad(v.data_ptr(), dy.data_ptr(), grad_of(conv.weight).data_ptr(), B, T, H, W, rt.stream())
+            if STEM3P_FUSED_WGRAD and lib.raw("avec_stem3p_wgrad_supported")(B, T, H, W):
+                # recompute + routing + weight gradient in ONE kernel: neither z nor dz exist in memory
+                lib.stem3p_wgrad(vb.data_ptr(), w8.data_ptr(), _p(conv.bias), dpool.data_ptr(), idx.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M),
+                                 grad_of(conv.weight).data_ptr(), _p(gw), _p(gb), B, T, H, W, rt.stream())
+            else:
+                dy = empty((M, C), rt.act_dtype(), v)
+                lib.stem3p_dz(vb.data_ptr(), w8.data_ptr(), _p(conv.bias), dpool.data_ptr(), idx.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M),
+                              dy.data_ptr(), _p(gw), _p(gb), B, T, H, W, rt.stream())
+                lib.stem3d_wgrad(v.data_ptr(), dy.data_ptr(), grad_of(conv.weight).data_ptr(), B, T, H, W, rt.stream())
             if conv.bias is not None:
                 grad_of(conv.bias)
             return None, None, None, None, None

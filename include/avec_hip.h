@@ -277,6 +277,11 @@ int avec_stem3p_supported(long long clips, int T, int H, int W);
 int avec_stem3p_fwd(const void* video_bf16, const void* w_shadow, const float* bias, const float* gamma, void* zp, unsigned char* idx, float* stats,
                     long long clips, int T, int H, int W, hipStream_t stream);
 int avec_stem3p_reduce(void* dpool, const void* zp, const float* ss, float* dstats, long long frames, int PH, int PW, hipStream_t stream);
+/* fused: dw fp32 [64][245] += the stem's weight gradient straight from the pooled gradients (z recomputed per tile, dz formed in LDS, never written) */
+int avec_stem3p_wgrad_supported(long long clips, int T, int H, int W);
+int avec_stem3p_wgrad(const void* video_bf16, const void* w_shadow, const float* bias, const void* dpool_masked, const unsigned char* idx, const float* ss,
+                      const float* gamma, const float* dstats, const float* count_ptr, float count, float* dw, float* dgamma, float* dbeta,
+                      long long clips, int T, int H, int W, hipStream_t stream);
 int avec_stem3p_dz(const void* video_bf16, const void* w_shadow, const float* bias, const void* dpool_masked, const unsigned char* idx, const float* ss,
                    const float* gamma, const float* dstats, const float* count_ptr, float count, void* dz, float* dgamma, float* dbeta,
                    long long clips, int T, int H, int W, hipStream_t stream);

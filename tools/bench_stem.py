@@ -22,6 +22,7 @@ def main():
     conv, bn = stem.layers[0][0], stem.layers[0][1]
     wout = None
     for name, p3 in (("stem3p", True), ("stem3d", False), ("stem3p", True), ("stem3d", False)):
+        ops.STEM3P_FUSED_WGRAD = os.environ.get("AVEC_STEM3P_FUSED", "1") != "0"
         ops.STEM3P = p3
         ts = []
         for it in range(6):
