@@ -577,6 +577,15 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
         for (int j = 0; j < NT; ++j) { if (AVEC_ABL & 4) { fb[q][j].w[0] = fb[q][j].w[1] = fb[q][j].w[2] = fb[q][j].w[3] = kt + j; } else fb[q][j] = *(const chunk16*)(Bs + offb[j] + ((((k0 + q) * 2 + gsel) ^ swb[j]) << 4)); }
       }
       asm volatile("" ::: "memory");            // keeps the reads above the MFMAs (the scheduler otherwise sinks each pair next to its consumer)
+      // ... and makes every fragment opaque HERE: a register-only consumer (the MFMA) may be hoisted above a memory fence, which left one LDS round trip
+      // per K-substep in the 64x64 kernel (read, wait, MFMA, read, wait, MFMA); with the values pinned the waits become one counted ladder per group
+#pragma unroll
+      for (int q = 0; q < KG; ++q) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q][i].w[0]), "+v"(fa[q][i].w[1]), "+v"(fa[q][i].w[2]), "+v"(fa[q][i].w[3]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[q][j].w[0]), "+v"(fb[q][j].w[1]), "+v"(fb[q][j].w[2]), "+v"(fb[q][j].w[3]));
+      }
 #pragma unroll
       for (int q = 0; q < KG; ++q)
 #pragma unroll
