@@ -136,6 +136,7 @@ struct Epi {
   const void* dact_z; long long ldz; int dact;   // multiply by act'(z) (1 swish, 2 relu)
   float* colsum;                   // += column sums of v (bias gradient)
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
+  const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;      // BatchNorm-backward fusion (avec_hip.h): v = alpha*acc + res; mask; stats += (v, v*y)
 };
 
 struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
@@ -241,6 +242,32 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
       if (row >= g.M || col >= g.N) continue;
       float v[4];
       { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      if (v4 && e.bnb_y) {
+        // BatchNorm-backward fusion: the product is the gradient of a BatchNorm (+ ReLU) output: add the residual gradient first, apply the ReLU mask, accumulate
+        // (sum d, sum d*y) per column and store the masked gradient
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (v[c] + bias4[c]) * e.alpha;
+        if (e.res) {
+          float r4[4];
+          if (e.res_act) ld4<T>((const T*)e.res + row * e.ldres + col, r4); else ld4<float>((const float*)e.res + row * e.ldres + col, r4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+        float y4[4]; ld4<T>((const T*)e.bnb_y + row * e.ldby + col, y4);
+        if (e.bnb_mask) {
+          float sc[4], sh[4]; ld4<float>(e.bnb_ss + col, sc); ld4<float>(e.bnb_ss + g.N + col, sh);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = (y4[c] * sc[c] + sh[c]) > 0.f ? v[c] : 0.f;
+        } else if (e.dact == 2) {
+          float z[4]; ld4<T>((const T*)e.dact_z + row * e.ldz + col, z);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = z[c] > 0.f ? v[c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * y4[c]; }
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+        continue;
+      }
       if (v4) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] += bias4[c];
@@ -1375,6 +1402,9 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
   e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
+  e.bnb_y = ep->bnb_y; e.ldby = ep->ldby; e.bnb_ss = ep->bnb_ss; e.bnb_mask = ep->bnb_mask;
+  AVEC_CHECK_ARG(!e.bnb_y || (e.stats && N % 4 == 0 && !(e.ldo & 3) && !(e.ldby & 3) && !(e.ldres & 3) && !(e.ldz & 3) && !(e.ldpre & 3) && (!e.bnb_mask || e.bnb_ss) && (e.bnb_mask || e.dact == 2 || e.dact == 0)),
+                 "gemm_nt: the BatchNorm-backward fusion needs stats, N %% 4 == 0 and row strides that are multiples of 4");
   AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt: dropout without rng state");
   int r = 1;
   if (dtype == AVEC_BF16 && !a_f32 && a_mode != AVEC_ROWS_PLAIN) r = launch_conv_shift(g, a_mode, stream);      // 3x3 / stride 1: shifted-window kernel

@@ -414,6 +414,19 @@ extern "C" int avec_bn_finalize(const float* stats, int n_replicas, const float*
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ stats, int nrep, const float* __restrict__ ss, float* __restrict__ dstats, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, sy = 0.f;
+  for (int r = 0; r < nrep; ++r) { s1 += stats[(long long)r * 2 * C + c]; sy += stats[(long long)r * 2 * C + C + c]; }
+  dstats[c] = s1; dstats[C + c] = ss[3 * C + c] * (sy - ss[2 * C + c] * s1);
+}
+extern "C" int avec_bn_bwd_finalize(const float* stats, int n_replicas, const float* ss, float* dstats, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(stats && ss && dstats && C > 0 && n_replicas > 0, "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, n_replicas, ss, dstats, C);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // out = act(y*scale + shift (+ residual))
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,

@@ -29,7 +29,8 @@ class Epilogue(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("rng", ctypes.c_void_p), ("rng_stream", ctypes.c_uint),
                 ("res", ctypes.c_void_p), ("ldres", ctypes.c_longlong), ("alpha", ctypes.c_float), ("res_act", ctypes.c_int),
                 ("dact_z", ctypes.c_void_p), ("ldz", ctypes.c_longlong), ("dact", ctypes.c_int),
-                ("colsum", ctypes.c_void_p), ("stats", ctypes.c_void_p)]
+                ("colsum", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+                ("bnb_y", ctypes.c_void_p), ("ldby", ctypes.c_longlong), ("bnb_ss", ctypes.c_void_p), ("bnb_mask", ctypes.c_int)]
 
 
 class Attn(ctypes.Structure):

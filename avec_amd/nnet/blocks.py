@@ -27,8 +27,9 @@ class ResNetBlock(nn.Module):
         else:
             self.residual = nn.Identity()
 
-    def forward_nhwc(self, x):
-        return ops.ResNetBlockFn.apply(x, self.layers[0].weight, self, self.training)
+    def forward_nhwc(self, x, chain=False):
+        """chain: the output feeds ONLY the next ResNetBlock (lets that block's backward fold this block's BatchNorm-backward reduction into its epilogue)"""
+        return ops.ResNetBlockFn.apply(x, self.layers[0].weight, self, self.training, chain)
 
     def forward(self, x):
         """logical NCHW in / out (reference interface)"""

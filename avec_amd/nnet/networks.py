@@ -30,8 +30,8 @@ class ResNet(nn.Module):
                                   layers.Linear(dim_blocks[-1], dim_output, weight_init="he_normal", bias_init="zeros")) if include_head else nn.Identity()
 
     def forward_nhwc(self, x):
-        for blk in self.blocks:
-            x = blk.forward_nhwc(x)
+        for i, blk in enumerate(self.blocks):
+            x = blk.forward_nhwc(x, chain=i + 1 < len(self.blocks))       # every block but the last hands its output to the next block only
         if isinstance(self.head, nn.Identity):
             return x
         x = ops.AvgPoolFn.apply(x)

@@ -146,7 +146,7 @@ def gemm_nt_fp8(A, ent, out, M, N, K, *, bias=None, act=ACT_NONE, out_pre=None, 
 
 def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
             drop_p=0.0, sid=0, res=None, res_act=False, alpha=1.0, dact_z=None, dact=0, colsum=None, stats=None, out_f32=False,
-            ldo=None, ldres=None, dtype=None, flops=None):
+            ldo=None, ldres=None, dtype=None, flops=None, bnb=None):
     ep = Epilogue()
     ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
     if out_pre is not None:
@@ -161,6 +161,12 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     if dact_z is not None:
         ep.dact_z, ep.ldz, ep.dact = dact_z.data_ptr(), N, dact
     ep.colsum, ep.stats = _p(colsum), _p(stats)
+    if bnb is not None:       # BatchNorm-backward fusion (avec_hip.h): (y, ss | None, mask tensor | None, replicated stats)
+        ep.bnb_y, ep.ldby, ep.stats = bnb.y.data_ptr(), N, bnb.stats.data_ptr()
+        if bnb.mask_z is not None:
+            ep.dact_z, ep.ldz, ep.dact, ep.bnb_mask = bnb.mask_z.data_ptr(), N, 2, 0
+        else:
+            ep.bnb_ss, ep.bnb_mask = bnb.ss.data_ptr(), 1
     if rows is None:
         rows = rows_plain(K)
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
@@ -825,11 +831,16 @@ def bn_finalize(bn, st, count, training):
     return cptr
 
 
-def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
+def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False, pre=None):
+    """pre: a completed BnbFuse -- `dout` is already masked and its (sum d, sum d*y) sit in pre.stats: no reduction pass, the apply pass reads d and y only"""
     C = st.C
     adt = rt.act_dtype()
     dstats = rt.zeros_scratch(2 * C, dout.device)
-    lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
+    if pre is not None:
+        lib.bn_bwd_finalize(pre.stats.data_ptr(), BNState.NREP, st.ss.data_ptr(), dstats.data_ptr(), C, rt.stream())
+        act, out, want_dres = ACT_NONE, None, False
+    else:
+        lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
     gw, gb = grad_of(bn.weight), grad_of(bn.bias)
     dstats, synced = _add_local_affine_grads(dstats, gw, gb, C, (id(bn), "b"))
     if synced:
@@ -838,7 +849,7 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False):
     dres = empty((M, C), adt, dout) if want_dres else None
     lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count), act,
                      dy.data_ptr(), _p(dres), _p(gw), _p(gb), M, C, rt.stream())
-    return dy, dres
+    return dy, (dout if pre is not None else dres)
 
 
 def _add_local_affine_grads(dstats, gw, gb, C, key):
@@ -1180,7 +1191,22 @@ def _slab_conv(H, W, Cin, Cout, KH, KW, stride):
     return SLAB_CONV and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_conv3x3_c64_supported")(H, W, Cin, Cout, KH, KW, stride))
 
 
-def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None):
+class BnbFuse:
+    """request to fold a BatchNorm(+ReLU) backward reduction into the epilogue of the product that computes its output gradient:
+    y = the BatchNorm input, mask_z = saved post-ReLU activation (mask z > 0) or None (mask from scale*y + shift > 0 with `ss`), stats = replicated [sum d | sum d*y]"""
+    __slots__ = ("y", "ss", "mask_z", "stats", "done")
+
+    def __init__(self, y, ss, mask_z, C):
+        self.y, self.ss, self.mask_z, self.done = y, ss, mask_z, False
+        self.stats = rt.zeros_scratch(BNState.NREP * 2 * C, y.device)
+
+
+# BatchNorm-backward reductions inside the backward-data epilogues (ResNet stages 2-4).  Correct (tests/test_gpu_round3.py) but SLOWER in the step (25.32 vs 25.07 ms, same box):
+# the extra y / mask tile loads sit on the critical path of each workgroup's epilogue while the stand-alone reductions run at 0.5 of the HBM peak.  Opt-in.
+BNB_FUSE = os.environ.get("AVEC_BNB_FUSE", "0") == "1"
+
+
+def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None):
     Cout, KH, KW = weight.shape[0], weight.shape[2], weight.shape[3]
     pad = (KH - 1) // 2
     M = N * OH * OW
@@ -1208,16 +1234,24 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
         return dx
     # algorithmic work of the backward-data product: one MAC per (output pixel, tap, Cin, Cout) -- for stride 2 three of four taps of the implicit GEMM
     # over input pixels are structurally zero and are skipped by the parity-class kernel: they are not counted
+    fuse = bnb if (bnb is not None and BNB_FUSE and rt.act_dtype() == torch.bfloat16 and Cin % 4 == 0) else None
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
-            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, bnb=fuse)
+    if fuse is not None:
+        fuse.done = True
     return dx
 
 
 class ResNetBlockFn(torch.autograd.Function):
     """x: act NHWC [N,H,W,Cin] -> act NHWC [N,OH,OW,Cout]"""
 
+    # BatchNorm-backward fusion across blocks: a block whose output feeds ONLY the next block (chain=True, set by nnet.ResNet) registers (y2, out, ss2) under its
+    # output's address; the next block's backward folds the mask + (sum d, sum d*y2) reduction of that BatchNorm into the epilogue of the product that computes its
+    # input gradient and leaves the completed request under the gradient's address for the producer block's backward
+    _CHAIN, _READY = {}, {}
+
     @staticmethod
-    def forward(ctx, x, _anchor, blk, training):
+    def forward(ctx, x, _anchor, blk, training, chain=False):
         rt.require_gpu(x)
         N, H, W, Cin = x.shape
         conv1, bn1, conv2, bn2 = blk.layers[0], blk.layers[1], blk.layers[3], blk.layers[4]
@@ -1247,6 +1281,11 @@ class ResNetBlockFn(torch.autograd.Function):
         out = empty((Mo, Cout), adt, x)
         lib.bn_apply_fwd(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), ACT_RELU, out.data_ptr(), Mo, Cout, rt.stream())
         ctx.saved = (x, y1, a1, y2, yr, out, st1, st2, str_, c1, c2, cr, blk, training, N, H, W, Cin, Cout, OH, OW, stride, has_proj)
+        ctx.chain = bool(chain and training and BNB_FUSE and rt.act_dtype() == torch.bfloat16)
+        if ctx.chain:
+            if len(ResNetBlockFn._CHAIN) > 64:
+                ResNetBlockFn._CHAIN.clear()
+            ResNetBlockFn._CHAIN[out.data_ptr()] = (y2, out, st2, Cout)
         return out.view(N, OH, OW, Cout)
 
     @staticmethod
@@ -1256,18 +1295,29 @@ class ResNetBlockFn(torch.autograd.Function):
         Mo = N * OH * OW
         dout = dout.reshape(Mo, Cout).to(rt.act_dtype()).contiguous()
         assert training, "ResNetBlock backward is implemented for training-mode BatchNorm"
-        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True)
-        da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW)
-        dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, None, ACT_RELU, Mo)      # no residual before this ReLU: the mask is recomputed from y1 (one tensor less to read)
+        ResNetBlockFn._CHAIN.pop(out.data_ptr(), None)
+        pre2 = ResNetBlockFn._READY.pop(dout.data_ptr(), None) if ctx.chain else None      # the consumer block already masked dout and reduced it against y2
+        if pre2 is not None and pre2.y is not y2:
+            raise RuntimeError("ResNetBlock backward: a fused BatchNorm-backward request does not belong to this block (the block output has another consumer?)")
+        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True, pre=pre2)
+        f1 = BnbFuse(y1, st1.ss, None, Cout)        # BatchNorm 1 + ReLU: the mask comes from the pre-activation itself
+        da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW, bnb=f1)
+        dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, None, ACT_RELU, Mo, pre=f1 if f1.done else None)      # no residual before this ReLU: the mask is recomputed from y1 (one tensor less to read)
         need_dx = ctx.needs_input_grad[0]
+        prev = ResNetBlockFn._CHAIN.get(x.data_ptr()) if need_dx else None
+        fx = BnbFuse(prev[0], prev[2].ss, prev[1], prev[3]) if prev is not None else None
         if has_proj:
             convr, bnr = blk.residual[0], blk.residual[1]
             dyr, _ = bn_backward(bnr, str_, cr, Mo, dres, yr, None, ACT_NONE, Mo)
             dx = conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx)
-            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx)
+            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx, bnb=fx)
         else:
-            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres)
-        return (dx.view(N, H, W, Cin) if dx is not None else None), None, None, None
+            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres, bnb=fx)
+        if fx is not None and fx.done:
+            if len(ResNetBlockFn._READY) > 64:
+                ResNetBlockFn._READY.clear()
+            ResNetBlockFn._READY[dx.data_ptr()] = fx
+        return (dx.view(N, H, W, Cin) if dx is not None else None), None, None, None, None
 
 
 STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels

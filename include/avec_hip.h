@@ -69,6 +69,11 @@ typedef struct avec_epilogue {
   const void* dact_z; long long ldz; int dact; /* backward: v *= act'(z) */
   float* colsum;                               /* += per-column sum of v  (bias gradients) */
   float* stats;                                /* += [N] sum, [N] sum of squares (BatchNorm batch statistics) */
+  /* BatchNorm-BACKWARD fusion (round 3; nnet/normalizations.py:90-170): this product IS the gradient d of a BatchNorm(+ReLU) output whose input was `bnb_y`.
+   * With bnb_y set the epilogue order is  v = alpha * acc + res;  v *= mask;  stats += (sum v | sum v * y);  out = v   -- the ReLU mask comes from the saved
+   * activation `dact_z` (dact = 2: v where z > 0) or, with bnb_mask = 1, from the pre-activation itself (scale * y + shift > 0, bnb_ss = [scale | shift | ...]).
+   * avec_bn_bwd_finalize turns the replicated (sum d, sum d*y) into (sum d, sum d*xhat); avec_bn_bwd_apply(act = 0) then needs d and y only. */
+  const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;
 } avec_epilogue_t;
 
 /* C[m][n] = epi(sum_k A[m][k] W[n][k]).  Replaces aten::addmm/mm of layers.Linear.forward (nnet/layers.py:64-76),
@@ -189,6 +194,8 @@ int avec_bn_collapse(const float* stats, int n_replicas, float count, float* out
 int avec_bn_affine_grads(const float* dstats, float* dgamma, float* dbeta, int C, hipStream_t stream);
 int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t stream);
+/* dstats[c] = sum over the n_replicas copies of stats[c], dstats[C + c] = rstd[c] * (sum of stats[C + c] - mean[c] * dstats[c]):  (sum d, sum d*y) -> (sum d, sum d*xhat) */
+int avec_bn_bwd_finalize(const float* stats, int n_replicas, const float* ss, float* dstats, int C, hipStream_t stream);
 int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t stream);
 int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t stream);
 int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
