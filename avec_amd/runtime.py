@@ -519,9 +519,18 @@ class ParamArena:
         self._early, self._early_armed = [], False
 
 
-def all_reduce_flat(flat, bucket_bytes=64 << 20):
+GRAD_ALLREDUCE_BF16 = os.environ.get("AVEC_GRAD_ALLREDUCE_BF16", "0") == "1"      # opt-in: bf16 payload for the flat gradient all-reduce: half the bytes on
+# every xGMI link; each rank's gradient is rounded to bf16 once before the sum (the reference all-reduces fp32 gradients: default off)
+
+
+def all_reduce_flat(flat, bucket_bytes=64 << 20, bf16_payload=None):
     """Sum a flat buffer over all ranks in contiguous slices of `bucket_bytes` (asynchronous, then waited in order)."""
     import torch.distributed as dist
+    if (GRAD_ALLREDUCE_BF16 if bf16_payload is None else bf16_payload) and flat.dtype == torch.float32:
+        wire = flat.to(torch.bfloat16)
+        all_reduce_flat(wire, bucket_bytes, bf16_payload=False)
+        flat.copy_(wire)
+        return flat
     n = flat.numel()
     step = max(bucket_bytes // flat.element_size(), 1)
     works = [dist.all_reduce(flat[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=True) for s in range(0, n, step)]

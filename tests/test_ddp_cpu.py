@@ -24,6 +24,14 @@ def _worker(rank, world, port, out):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     rt.all_reduce_flat(g, bucket_bytes=4 * 333)
     ok1 = torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
+    # 1b. opt-in bf16 payload (AVEC_GRAD_ALLREDUCE_BF16): each rank's values are rounded to bf16 once, the sum is exact for these small integers / within bf16 otherwise
+    gb = torch.arange(64, dtype=torch.float32) * (rank + 1)
+    rt.all_reduce_flat(gb, bucket_bytes=2 * 21, bf16_payload=True)
+    ok1 = ok1 and torch.equal(gb, torch.arange(64, dtype=torch.float32) * 3)
+    gr = torch.randn(5000, generator=torch.Generator().manual_seed(3 + rank))
+    ref = torch.randn(5000, generator=torch.Generator().manual_seed(3)) + torch.randn(5000, generator=torch.Generator().manual_seed(4))
+    rt.all_reduce_flat(gr, bf16_payload=True)
+    ok1 = ok1 and gr.dtype == torch.float32 and float((gr - ref).norm() / ref.norm()) < 1e-2
     # 2. SyncBatchNorm statistics: replicated partial sums + local counts -> global mean / var
     C, nrep = 4, 64
     torch.manual_seed(rank)

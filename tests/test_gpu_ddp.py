@@ -11,13 +11,43 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _transports():
+    """two ranks sharing the test box's single GPU over gloo -- and, on any box that has two devices, the real thing: one rank per GPU over RCCL (nccl backend),
+    cross-device IPC mapping of the SyncBatchNorm exchange buffers and peer stores over xGMI"""
+    t = [pytest.param(("gloo", True), id="gloo, one shared GPU")]
+    t.append(pytest.param(("nccl", False), id="rccl, one GPU per rank",
+                          marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")))
+    return t
+
+
+def _oracle_full_batch():
+    """the CPU oracle (pinned to the reference, tests/golden/check_oracle_fullsize.py) on the FULL batch of tools/ddp_equiv.py: loss and gradients the two ranks
+    together must reproduce (SyncBatchNorm statistics over both shards, gradients averaged over ranks = gradient of the batch-mean loss)"""
+    import nnet
+    from oracle import avec_oracle as O
+    torch.manual_seed(0)
+    model = nnet.AudioVisualEfficientConformerInterCTC()
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in model.state_dict().items()}
+    B = 4
+    g = torch.Generator().manual_seed(5)
+    video, audio = torch.randn(B, 20, 88, 88, 1, generator=g), 0.1 * torch.randn(B, 12160, generator=g)
+    vlen, alen = torch.tensor([20, 17, 20, 11]), torch.tensor([12160, 10000, 12160, 7000])
+    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor([4, 3, 4, 2])
+    out = O.av_forward(sd, video, vlen, audio, alen, train=True, stats_out={})
+    loss = O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)["loss"]
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize("transport", _transports())
 @pytest.mark.parametrize("peer_exchange", ["1", "0"], ids=["peer-write SyncBN exchange", "torch.distributed SyncBN exchange"])
-def test_two_rank_step_equals_single_process(tmp_path, peer_exchange):
+def test_two_rank_step_equals_single_process(tmp_path, peer_exchange, transport):
+    backend, share = transport
     single, ddp = str(tmp_path / "single.pt"), str(tmp_path / "ddp.pt")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AVEC_PEER_SYNCBN=peer_exchange)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AVEC_PEER_SYNCBN=peer_exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", single], check=True, env=env, timeout=600)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", "gloo", "--share-gpu"],
+                    "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", backend] + (["--share-gpu"] if share else []),
                    check=True, env=env, timeout=900)
     a, b = torch.load(single), torch.load(ddp)
     assert b["peer"] == (peer_exchange == "1")      # the statistics really travelled the way this case names (IPC peer writes work between two processes on one GPU)
@@ -38,6 +68,23 @@ def test_two_rank_step_equals_single_process(tmp_path, peer_exchange):
     assert (rest_num / rest_den) ** 0.5 < 2e-3, (rest_num / rest_den) ** 0.5
     assert (fe_num / fe_den) ** 0.5 < 6e-2, (fe_num / fe_den) ** 0.5
     assert torch.allclose(a["running_mean"], b["running_mean"], atol=1e-5) and torch.allclose(a["running_var"], b["running_var"], rtol=1e-4, atol=1e-6)
+    if peer_exchange == "1" and share:
+        # ... and against the ORACLE on the full batch (not only HIP vs HIP): the two ranks' averaged gradient is the gradient of the batch-mean loss with
+        # BatchNorm statistics over the whole batch.  Parameters stored in another physical order (conv weights are channels-last in the arena) are compared by norm.
+        o_loss, o_grad = _oracle_full_batch()
+        assert abs(float(b["loss"]) - o_loss) < 1e-3 * abs(o_loss), (float(b["loss"]), o_loss)
+        num = den = 0.0
+        n_cmp = 0
+        for k, (o, n) in b["names"].items():
+            if k not in o_grad or "front_end" in k:
+                continue
+            gb, go = b["grad"][o:o + n].double(), o_grad[k].double().reshape(-1)
+            if o_grad[k].dim() <= 2:
+                num += float((gb - go).pow(2).sum()); den += float(go.pow(2).sum())
+            else:
+                num += (float(gb.norm()) - float(go.norm())) ** 2; den += float(go.norm()) ** 2
+            n_cmp += 1
+        assert n_cmp > 400 and (num / den) ** 0.5 < 5e-3, (n_cmp, (num / den) ** 0.5)
 
 
 def test_peer_exchange_stress_and_graph(tmp_path):
@@ -47,14 +94,16 @@ def test_peer_exchange_stress_and_graph(tmp_path):
     assert r.returncode == 0 and r.stdout.count("PEER STRESS OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def test_graphed_two_rank_step_equals_eager_two_rank_step(tmp_path):
+@pytest.mark.parametrize("transport", _transports())
+def test_graphed_two_rank_step_equals_eager_two_rank_step(tmp_path, transport):
     """data-parallel step captured into a hipGraph (forward + backward with peer-write SyncBatchNorm exchanges inside; all-reduce + Adam after the replay) against
     the eager data-parallel train_step: same parameters after three steps"""
     outs = {}
     for mode in ("eager", "graph"):
         outs[mode] = str(tmp_path / (mode + ".pt"))
         subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                        os.path.join(ROOT, "tools", "ddp_graph_equiv.py"), "--out", outs[mode], "--mode", mode], check=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=900)
+                        os.path.join(ROOT, "tools", "ddp_graph_equiv.py"), "--out", outs[mode], "--mode", mode, "--backend", transport[0]], check=True,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900)
     a, b = torch.load(outs["eager"]), torch.load(outs["graph"])
     assert a["peer"] and b["peer"] and b["graphed"] and not a["graphed"]
     # Adam's first moment is linear in the three steps' gradients: it must agree up to fp32 summation order (the parameters themselves move by ~lr * sign(g) in the first

@@ -16,7 +16,7 @@ def main():
     dev = torch.device("cuda", 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     if world > 1:
-        torch.distributed.init_process_group(backend=args.backend, init_method="env://")
+        torch.distributed.init_process_group(backend=args.backend, init_method="env://", **({"device_id": dev} if args.backend == "nccl" else {}))
     import avec_amd, nnet
     avec_amd.set_compute_dtype("f32")
     torch.manual_seed(0)

@@ -12,11 +12,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--mode", default="eager")
+    ap.add_argument("--backend", default="gloo", help="gloo: both ranks on cuda:0; nccl (= RCCL): one GPU per rank")
     args = ap.parse_args()
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", 0 if args.backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    torch.distributed.init_process_group(backend="gloo", init_method="env://")
+    if args.backend == "nccl":
+        torch.distributed.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+    else:
+        torch.distributed.init_process_group(backend="gloo", init_method="env://")
     import avec_amd
     import nnet
     from avec_amd import peer
@@ -47,7 +51,8 @@ def main():
         for _ in range(3):
             losses, _, _ = model.train_step(inputs, targets, precision=torch.bfloat16)
     torch.cuda.synchronize()
-    loss = losses["loss"].detach().float().clone().cpu()
+    loss = losses["loss"].detach().float().clone()
+    loss = loss if args.backend == "nccl" else loss.cpu()
     torch.distributed.all_reduce(loss)
     if peer.active() is not None:
         peer.active().check()
