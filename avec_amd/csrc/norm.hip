@@ -414,6 +414,14 @@ extern "C" int avec_bn_finalize(const float* stats, int n_replicas, const float*
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+// measurement aid: one lane writes the 100 MHz wall clock into slot `i` of a device array (tools/step_stamps.py: where a graph-replayed step spends its time, per stream, without a profiler)
+__global__ void stamp_kernel(unsigned long long* out, int i) { if (threadIdx.x == 0) out[i] = wall_clock64(); }
+extern "C" int avec_stamp(unsigned long long* out, int slot, hipStream_t st) {
+  AVEC_CHECK_ARG(out && slot >= 0, "stamp: bad arguments");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, out, slot);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ stats, int nrep, const float* __restrict__ ss, float* __restrict__ dstats, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;

@@ -244,7 +244,9 @@ class Model(Module):
         def body():
             rt.reset_zero_pool(self.device)
             losses, _, _, _ = self.forward_model(static_in, static_tg, compute_metrics=False)
+            ops.stamp("loss_done:f")
             losses["loss"].backward()
+            ops.stamp("bwd_done:b")
             rt.advance_rng(self.device)
             if not dist_mode:
                 self.optimizer.launch_step()

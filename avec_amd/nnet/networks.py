@@ -171,6 +171,7 @@ class VisualEfficientConformerEncoder(nn.Module):
         stem = self.front_end[0].layers[0]
         bn = stem[1]
         frames = ops.VideoStemFn.apply(x.reshape(B, T, H, W), stem[0].weight, stem[0], bn, bn.training and not bn.frozen)     # (B*T, H/4, W/4, 64) act, channels-last
+        frames = ops.mark(frames, "v_stem")
         feats = self.front_end[3].forward_nhwc(frames)                                                          # (B*T, 256) fp32
         return feats.view(B, T, -1)
 
@@ -226,10 +227,14 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
                     audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
                 video, video_len, v_inter = self.video_encoder(video, video_len)
             else:
-                feats = self.video_encoder.forward_front(video)
+                ops.stamp("step_start:f")
+                feats = ops.mark(self.video_encoder.forward_front(video), "v_front")
                 with torch.cuda.stream(side):
+                    ops.stamp("a_start:f")
                     audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
+                    audio = ops.mark(audio, "a_enc")
                 video, video_len, v_inter = self.video_encoder.forward_back(feats, video_len)
+                video = ops.mark(video, "v_back")
             main.wait_stream(side)
             for t in [audio, audio_len] + [u for v in a_inter.values() for u in (v if isinstance(v, (list, tuple)) else [v])]:
                 if torch.is_tensor(t) and t.is_cuda:
@@ -244,8 +249,9 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             arena._audio_range = r_a
             if r_f is not None and r_h is not None and r_h[1] >= r_f[0]:
                 audio, video = rt.grad_boundary(audio, arena, r_f[0], r_h[1]), rt.grad_boundary(video, arena, r_f[0], r_h[1])
-        x = self.fusion_module(audio, video)
+        x = ops.mark(self.fusion_module(audio, video), "fusion")
         x, lengths, inter = self.audio_visual_encoder(x, audio_len)
+        x = ops.mark(x, "av_enc")
         inter.update(v_inter)
         inter.update(a_inter)
         if not isinstance(self.head, nn.Identity):

@@ -79,6 +79,40 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- step stamps (measurement aid, AVEC_STAMPS=1): wall-clock marks written by one-wave kernels at named points of the forward and backward passes, on whatever stream the
+# point runs on -- they replay with the captured graph, so tools/step_stamps.py sees the real overlap of the two branch streams without a profiler ----
+STAMPS = {"on": os.environ.get("AVEC_STAMPS", "0") == "1", "buf": None, "names": []}
+
+
+def stamp(name):
+    if not STAMPS["on"]:
+        return
+    if STAMPS["buf"] is None:
+        STAMPS["buf"] = torch.zeros(256, dtype=torch.int64, device="cuda")
+    if name not in STAMPS["names"]:
+        STAMPS["names"].append(name)
+    lib.stamp(STAMPS["buf"].data_ptr(), STAMPS["names"].index(name), rt.stream())
+
+
+class StampFn(torch.autograd.Function):
+    """identity; stamps `name:f` when the forward pass gets here and `name:b` when the gradient comes back"""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        stamp(name + ":f")
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        stamp(ctx.name + ":b")
+        return g, None
+
+
+def mark(x, name):
+    return StampFn.apply(x, name) if (STAMPS["on"] and torch.is_tensor(x) and x.requires_grad) else (stamp(name + ":f") or x)
+
+
 def grad_of(p):
     """fp32 gradient buffer of a parameter (same physical layout), created on first use."""
     if p.grad is None:
@@ -1404,6 +1438,7 @@ class VideoStemFn(torch.autograd.Function):
                 lib.stem3d_wgrad(v.data_ptr(), dy.data_ptr(), grad_of(conv.weight).data_ptr(), B, T, H, W, rt.stream())
             if conv.bias is not None:
                 grad_of(conv.bias)
+            stamp("v_stem_end:b")
             return None, None, None, None, None
         dstats = torch.zeros(2 * C, dtype=torch.float32, device=v.device)
         args = (dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cp, float(M))
@@ -1487,6 +1522,7 @@ class AudioStemFn(torch.autograd.Function):
             base = base[:5] + (dstats.data_ptr(),) + base[6:]
         lib.audio_stem_bwd(rt.dt(), *base, 1, grad_of(conv.weight).data_ptr(), None if conv.bias is None else grad_of(conv.bias).data_ptr(),
                            _p(gw), _p(gb), B, NM, F, C, rt.stream())
+        stamp("a_stem_end:b")
         arena = rt.arena_of(bn)
         if arena is not None and getattr(arena, "_early_armed", False) and getattr(arena, "_audio_range", None):
             lo, hi = arena._audio_range                       # the stem is the first op of the audio encoder: its backward is the last one of that branch

@@ -195,6 +195,8 @@ int avec_bn_affine_grads(const float* dstats, float* dgamma, float* dbeta, int C
 int avec_bn_finalize(const float* stats, int n_replicas, const float* count_ptr, float count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, float* ss, int C, int training, hipStream_t stream);
 /* dstats[c] = sum over the n_replicas copies of stats[c], dstats[C + c] = rstd[c] * (sum of stats[C + c] - mean[c] * dstats[c]):  (sum d, sum d*y) -> (sum d, sum d*xhat) */
+/* measurement aid: out[slot] = 100 MHz wall clock, written by a one-wave kernel on `stream` (graph-capturable) */
+int avec_stamp(unsigned long long* out, int slot, hipStream_t stream);
 int avec_bn_bwd_finalize(const float* stats, int n_replicas, const float* ss, float* dstats, int C, hipStream_t stream);
 int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t stream);
 int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t stream);
