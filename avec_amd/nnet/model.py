@@ -260,10 +260,11 @@ class Model(Module):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        warm = None
         with torch.cuda.stream(side):
             for _ in range(warmup):             # warm-up on a side stream: lazy kernel attributes, caches, allocator
                 self.optimizer.prepare_step()
-                body()
+                warm = body()
                 finish()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -290,7 +291,55 @@ class Model(Module):
         if dist_mode:
             self.arena.arm_early_all_reduce(os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0")      # later eager train_steps keep their overlapped exchange
         step.graph = graph
+        step.warm_losses = {k: v.detach().clone() for k, v in warm.items()} if warm is not None else None
         return step
+
+    # -- hipGraph replay for ragged training batches: one captured step per batch SHAPE --------------------------------------------------------------------
+    @staticmethod
+    def pad_av_batch(inputs, targets, bucket_frames):
+        """zero-pad an audio-visual batch [video (B,Tv,H,W,C), video_len, audio (B,Ta), audio_len], (labels (B,L), label_len) to the next multiple of
+        `bucket_frames` video frames (audio to the longest clip with that many frames: 640 * Tv' - 1 samples, labels to a multiple of 8): the true lengths stay, so
+        attention masks and CTC are unchanged; like the reference's own padding to the batch maximum (nnet/collate_fn.py:143-146) the zero frames do enter the
+        BatchNorm batch statistics -- a coarser bucket is a (slightly) different batch composition, which is why bucketing is opt-in."""
+        video, vlen, audio, alen = inputs
+        labels, llen = targets
+        Tv = video.shape[1]
+        Tvp = (Tv + bucket_frames - 1) // bucket_frames * bucket_frames
+        Tap = 640 * Tvp - 1
+        if Tvp > Tv:
+            video = torch.nn.functional.pad(video, (0, 0, 0, 0, 0, 0, 0, Tvp - Tv))
+        if Tap > audio.shape[1]:
+            audio = torch.nn.functional.pad(audio, (0, Tap - audio.shape[1]))
+        Lp = (labels.shape[1] + 7) // 8 * 8
+        if Lp > labels.shape[1]:
+            labels = torch.nn.functional.pad(labels, (0, Lp - labels.shape[1]))
+        return [video, vlen, audio, alen], (labels, llen)
+
+    def graphed_train_step(self, inputs, targets, precision=torch.bfloat16, cache_size=8, bucket_frames=None):
+        """train_step through a cache of captured steps keyed by the batch shape (LRU, `cache_size` graphs: each holds its own activation pool).  Ragged LRS batches
+        (nnet/collate_fn.py pads to the batch maximum) repeat a small set of shapes once they are bucketed (`bucket_frames`, see pad_av_batch) or come from a
+        length-bucketed sampler.  Falls back to train_step when a step cannot be captured as is (scheduled loss weights, gradient clipping, data parallel without the
+        peer exchange)."""
+        from .schedulers import ConstantScheduler
+        from .. import peer
+        lw = self.compiled_loss_weights
+        const_w = isinstance(lw, ConstantScheduler) or (isinstance(lw, dict) and all(isinstance(v, ConstantScheduler) for v in lw.values())) \
+            or (isinstance(lw, list) and all(isinstance(v, ConstantScheduler) for v in lw))
+        if not const_w or self.grad_max_norm is not None or (self.is_distributed and peer.active() is None):
+            return self.train_step(inputs, targets, precision=precision)[0]
+        if bucket_frames and len(inputs) == 4 and inputs[0].dim() == 5 and isinstance(targets, (tuple, list)) and len(targets) == 2:
+            inputs, targets = self.pad_av_batch(inputs, targets, bucket_frames)
+        key = tuple((tuple(t.shape), str(t.dtype)) for t in list(inputs) + list(targets)) + (str(precision),)
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        step = cache.pop(key, None)
+        if step is None:
+            while len(cache) >= cache_size:
+                cache.pop(next(iter(cache)))                 # least recently used (dict order = recency)
+            step = self.make_graphed_train_step(inputs, targets, precision=precision, warmup=1)      # (the warm-up pass is a real optimisation step on this batch)
+            cache[key] = step
+            return step.warm_losses
+        cache[key] = step
+        return step(inputs, targets)
 
     def eval_step(self, inputs, targets, verbose=0):
         with torch.no_grad():
@@ -318,7 +367,9 @@ class Model(Module):
     def fit(self, dataset_train, epochs, dataset_eval=None, eval_steps=None, verbose_eval=0, initial_epoch=0, callback_path=None, steps_per_epoch=None,
             precision=torch.float32, accumulated_steps=1, eval_period_step=None, eval_period_epoch=1, saving_period_epoch=1, log_figure_period_step=None,
             log_figure_period_epoch=1, step_log_period=100, eval_training=True, grad_init_scale=65536.0, detect_anomaly=False, recompute_metrics=False,
-            wandb_logging=False, verbose_progress_bar=1, keep_last_k=None):
+            wandb_logging=False, verbose_progress_bar=1, keep_last_k=None, use_graphs=False, graph_bucket_frames=None, graph_cache_size=8):
+        """use_graphs: replay captured steps per batch shape (graphed_train_step) instead of eager launches; graph_bucket_frames: additionally zero-pad AV batches to
+        multiples of that many video frames so that few shapes occur (opt-in: changes the padding the BatchNorm statistics see)."""
         if callback_path is not None and self.rank == 0:
             os.makedirs(callback_path, exist_ok=True)
         for epoch in range(initial_epoch, epochs):
@@ -330,7 +381,10 @@ class Model(Module):
             for step, batch in enumerate(dataset_train):
                 inputs = self.transfer_to_device(batch["inputs"])
                 targets = self.transfer_to_device(batch["targets"])
-                losses, _, acc_step = self.train_step(inputs, targets, precision, None, accumulated_steps, acc_step, eval_training)
+                if use_graphs and accumulated_steps == 1 and self.device.type == "cuda":
+                    losses = self.graphed_train_step(inputs, targets, precision=precision, cache_size=graph_cache_size, bucket_frames=graph_bucket_frames)
+                else:
+                    losses, _, acc_step = self.train_step(inputs, targets, precision, None, accumulated_steps, acc_step, eval_training)
                 n += 1
                 if self.is_distributed and step % step_log_period == 0:
                     from .. import peer

@@ -41,3 +41,58 @@ def test_resnet_bn_backward_fusion_matches_unfused():
     assert len(res[True][2]) == len(res[False][2]) and len(res[True][2]) > 40
     for n in res[True][2]:
         assert rel_err(res[True][2][n], res[False][2][n]) < 3e-2, n
+
+
+def _small_av_batch(B, secs, seed):
+    g = torch.Generator().manual_seed(seed)
+    alen = torch.tensor([int(16000 * s) for s in secs])
+    vlen = alen // 640 + 1
+    Ta, Tv = int(alen.max()), int(vlen.max())
+    audio, video = torch.zeros(B, Ta), torch.zeros(B, Tv, 88, 88, 1)
+    for b in range(B):
+        audio[b, :alen[b]] = 0.1 * torch.randn(int(alen[b]), generator=g)
+        video[b, :vlen[b]] = torch.randn(int(vlen[b]), 88, 88, 1, generator=g)
+    labels = torch.randint(1, 256, (B, 3), generator=g)
+    return [video.to(dev()), vlen.to(dev()), audio.to(dev()), alen.to(dev())], (labels.to(dev()), torch.full((B,), 3).to(dev()))
+
+
+def test_graphed_train_step_cache_on_ragged_batches():
+    """Model.graphed_train_step: one captured step per batch shape (two shapes alternate, six optimisation steps) follows the eager train_step --
+    same step counter, same losses up to summation order -- and the bucketed variant pads to the bucket without touching the lengths."""
+    import avec_amd
+    import nnet
+    batches = [_small_av_batch(2, (0.9, 0.7), 1), _small_av_batch(2, (1.2, 1.1), 2)]
+    out = {}
+    try:
+        avec_amd.set_compute_dtype("f32")
+        for mode in ("eager", "graphs"):
+            avec_amd.manual_seed(7)
+            torch.manual_seed(0)
+            model = nnet.AudioVisualEfficientConformerInterCTC()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+                if hasattr(m, "drop_rate"):
+                    m.drop_rate = 0.0
+            model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
+            model = model.to(dev()).train()
+            model.encoder.audio_encoder.spec_augment.eval()
+            losses = []
+            for i in range(6):
+                inp, tgt = batches[i % 2]
+                if mode == "eager":
+                    l = model.train_step(inp, tgt, precision=torch.float32)[0]
+                else:
+                    l = model.graphed_train_step(inp, tgt, precision=torch.float32)
+                losses.append(float(l["loss"].detach()))
+            torch.cuda.synchronize()
+            out[mode] = (losses, int(model.model_step), len(model.__dict__.get("_graph_cache", {})))
+    finally:
+        avec_amd.set_compute_dtype("f32")
+    assert out["eager"][1] == out["graphs"][1] == 6
+    assert out["graphs"][2] == 2 and out["eager"][2] == 0
+    for a, b in zip(out["eager"][0], out["graphs"][0]):
+        assert abs(a - b) < 2e-2 * abs(a), (out["eager"][0], out["graphs"][0])
+    assert out["eager"][0][-1] < out["eager"][0][0]                    # (it trains)
+    inp, tgt = nnet.Model.pad_av_batch(*batches[0], bucket_frames=25)
+    assert inp[0].shape[1] == 25 and inp[2].shape[1] == 640 * 25 - 1 and tgt[0].shape[1] == 8 and torch.equal(inp[1], batches[0][0][1]) and torch.equal(inp[3], batches[0][0][3])

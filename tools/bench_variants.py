@@ -44,16 +44,25 @@ def av_batch(B, dur, g, device):
     return [video.to(device), vlen.to(device), audio.to(device), alen.to(device)], (labels.to(device), llen.to(device)), eff, B
 
 
+GRAPHS = {"on": False, "bucket": None}
+
+
 def run(name, model, batches, steps, warmup, precision):
     import avec_amd
+    if GRAPHS["on"]:
+        one = lambda inp, tgt: model.graphed_train_step(inp, tgt, precision=precision, bucket_frames=GRAPHS["bucket"])
+        warmup = max(warmup, len(batches))              # every shape captured before the timed region
+        name += "+graphs" + ("(bucket %d)" % GRAPHS["bucket"] if GRAPHS["bucket"] else "")
+    else:
+        one = lambda inp, tgt: model.train_step(inp, tgt, precision=precision)[0]
     for i in range(warmup):
         inp, tgt = batches[i % len(batches)][:2]
-        last = model.train_step(inp, tgt, precision=precision)[0]
+        last = one(inp, tgt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         inp, tgt = batches[i % len(batches)][:2]
-        last = model.train_step(inp, tgt, precision=precision)[0]
+        last = one(inp, tgt)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     loss = float(last["loss"].detach())
@@ -68,7 +77,10 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graphs", action="store_true", help="replay captured steps per batch shape (Model.graphed_train_step) instead of eager launches")
+    ap.add_argument("--bucket", type=int, default=None, help="with --graphs: zero-pad AV batches to multiples of this many video frames")
     args = ap.parse_args()
+    GRAPHS["on"], GRAPHS["bucket"] = args.graphs, args.bucket
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     import avec_amd

@@ -28,3 +28,9 @@ python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $O/r03_pmc_traffic.json > $O/p
 fi
 head -45 $O/r03_kernel_stats.csv | cut -c1-150
 tail -30 $O/timeline.txt
+if [ "${1:-all}" = "all" ]; then
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo\|OMP_NUM\|^\*\*\*\*\|^$" | tail -40 > $O/tests_all.log
+tail -5 $O/tests_all.log
+AVEC_STAMPS=1 timeout 600 python tools/step_stamps.py 2>&1 | grep -v amdgpu > $O/r03_step_stamps.txt
+fi

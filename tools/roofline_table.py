@@ -9,7 +9,7 @@ stats, traffic, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 tr = json.load(open(traffic))["kernels"]
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("Per-kernel view of one AV training step (B = 32, bf16, one MI355X): time from `rocprofv3 --kernel-trace --stats`, HBM bytes from the two `--pmc` passes\n(FETCH_SIZE doubled for gfx950, WRITE_SIZE as reported) -- see profiles/README.md.  The GEMM family's MFMA-side figures are in `r02_bench_line.json`.\n")
+print("Per-kernel view of one AV training step (B = 32, bf16, one MI355X): time from `rocprofv3 --kernel-trace --stats`, HBM bytes from the two `--pmc` passes\n(FETCH_SIZE doubled for gfx950, WRITE_SIZE as reported) -- see profiles/README.md.  The GEMM family's MFMA-side figures are in the bench line of the same round (`rNN_bench_line.json`: `roofline.rows`).\n")
 print("| kernel | launches / step | avg us | ms / step | HBM fetch MB / launch | HBM write MB / launch | HBM GB/s | frac of 8 TB/s |")
 print("|---|---|---|---|---|---|---|---|")
 for r in [r for r in rows if not r["Name"].startswith("__amd_rocclr")][:40]:      # (buffer copies of model initialisation are not part of a step)
