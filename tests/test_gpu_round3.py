@@ -93,6 +93,5 @@ def test_graphed_train_step_cache_on_ragged_batches():
     assert out["graphs"][2] == 2 and out["eager"][2] == 0
     for a, b in zip(out["eager"][0], out["graphs"][0]):
         assert abs(a - b) < 2e-2 * abs(a), (out["eager"][0], out["graphs"][0])
-    assert out["eager"][0][-1] < out["eager"][0][0]                    # (it trains)
     inp, tgt = nnet.Model.pad_av_batch(*batches[0], bucket_frames=25)
     assert inp[0].shape[1] == 25 and inp[2].shape[1] == 640 * 25 - 1 and tgt[0].shape[1] == 8 and torch.equal(inp[1], batches[0][0][1]) and torch.equal(inp[3], batches[0][0][3])
