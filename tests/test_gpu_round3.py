@@ -95,3 +95,38 @@ def test_graphed_train_step_cache_on_ragged_batches():
         assert abs(a - b) < 2e-2 * abs(a), (out["eager"][0], out["graphs"][0])
     inp, tgt = nnet.Model.pad_av_batch(*batches[0], bucket_frames=25)
     assert inp[0].shape[1] == 25 and inp[2].shape[1] == 640 * 25 - 1 and tgt[0].shape[1] == 8 and torch.equal(inp[1], batches[0][0][1]) and torch.equal(inp[3], batches[0][0][3])
+
+
+def test_inplace_weight_edits_reach_train_step_and_eval_step_and_fp8_amax_resets():
+    """Advisor findings of round 2: (1) the stale-shadow check must run on the paths that call forward() directly (train_step / eval_step / evaluate / fit), not only on
+    model(x); (2) with fp8 operands the activation amax slots are per-pass ("current scaling"): a quiet batch after a loud one must not inherit the loud maximum."""
+    import avec_amd
+    from avec_amd import fp8
+    from tests.test_gpu_round2 import _ao_batch, _ao_model
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        model = _ao_model().eval()
+        inputs, targets = _ao_batch()
+        l0 = float(model.eval_step(inputs, targets)[0]["loss"])
+        with torch.no_grad():
+            model.encoder.head.weight.mul_(0.0)               # in-place edit after .to('cuda'): the logits become the bias alone
+            model.encoder.head.bias.mul_(0.0)
+        l1 = float(model.eval_step(inputs, targets)[0]["loss"])
+        assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)         # eval_step saw the edit (uniform logits: a different CTC loss)
+        model.train()
+        l2 = float(model.train_step(inputs, targets, precision=torch.bfloat16)[0]["loss"].detach())
+        assert abs(l2 - l1) < 5e-2 * abs(l1), (l1, l2)         # train_step too (same uniform logits; BatchNorm batch statistics change nothing after a zeroed head)
+        # fp8: amax slots of the activations are zeroed at the start of every pass
+        fp8.enable(True)
+        m2 = _ao_model()
+        m2.train_step(inputs, targets, precision=torch.bfloat16)
+        st = fp8.state_of(m2.arena)
+        used = st.amax[st.n:] > 0
+        st.amax[st.n:].fill_(1e30)                              # a stale "all-time maximum": the next pass must start from zero again
+        m2.train_step(inputs, targets, precision=torch.bfloat16)
+        torch.cuda.synchronize()
+        a2 = st.amax[st.n:]
+        assert used.any() and (a2[used] < 1e29).all() and (a2[used] > 0).all()
+    finally:
+        fp8.enable(False)
+        avec_amd.set_compute_dtype("f32")
