@@ -54,9 +54,14 @@ class Conv1d(nn.Conv1d):
                 rt.register_weight(self.weight, out_channels, 1, in_channels)
 
     def forward(self, x):
-        if self.depthwise or self.kernel_size[0] != 1 or self.mask is not None:
-            raise RuntimeError("standalone Conv1d(k=%d, groups=%d) is not part of the HIP hot path; the depthwise conv runs fused inside "
-                               "ConvolutionModule" % (self.kernel_size[0], self.groups))
+        if self.depthwise and self.mask is None:            # on the hot path it runs fused inside ConvolutionModule; alone: the same kernels with the GLU gate pinned to 1
+            from .functions import DepthwiseConv1dFn
+            if not self.channels_last:
+                x = x.transpose(1, 2)
+            y = DepthwiseConv1dFn.apply(x, self.weight, self)
+            return y if self.channels_last else y.transpose(1, 2)
+        if self.kernel_size[0] != 1 or self.mask is not None:
+            raise RuntimeError("Conv1d(k=%d, groups=%d) on the HIP path: pointwise (k = 1) or depthwise (groups == channels)" % (self.kernel_size[0], self.groups))
         if not self.channels_last:
             x = x.transpose(1, 2)
         if self.stride[0] > 1:
@@ -105,7 +110,8 @@ class Conv3d(nn.Conv3d):
             rt.register_weight(self.weight, out_channels, 1, kk, need_bwd=False, c_pad=(kk + 7) // 8 * 8)
 
     def forward(self, x):
-        raise RuntimeError("standalone Conv3d is not part of the HIP hot path; the (5,7,7) stem runs fused in VisualEfficientConformerEncoder.front_end")
+        from .functions import conv3d_module_forward
+        return conv3d_module_forward(self, x)
 
 
 class MaxPool3d(nn.MaxPool3d):
@@ -117,7 +123,8 @@ class MaxPool3d(nn.MaxPool3d):
         self.channels_last = channels_last
 
     def forward(self, x):
-        raise RuntimeError("standalone MaxPool3d is not part of the HIP hot path (fused into the visual stem)")
+        from .functions import maxpool3d_module_forward
+        return maxpool3d_module_forward(self, x)
 
 
 class AvgPool1d(nn.AvgPool1d):
@@ -126,7 +133,8 @@ class AvgPool1d(nn.AvgPool1d):
         self.channels_last = channels_last
 
     def forward(self, x):
-        raise RuntimeError("standalone AvgPool1d is not part of the HIP hot path (fused into patch attention)")
+        from .functions import avgpool1d_module_forward
+        return avgpool1d_module_forward(self, x)
 
 
 class Upsample(nn.Upsample):
@@ -135,7 +143,8 @@ class Upsample(nn.Upsample):
         self.channels_last = channels_last
 
     def forward(self, x):
-        raise RuntimeError("standalone Upsample is not part of the HIP hot path (fused into patch attention)")
+        from .functions import upsample_module_forward
+        return upsample_module_forward(self, x)
 
 
 class Dropout(nn.Dropout):
@@ -211,7 +220,8 @@ class GlobalAvgPool2d(nn.Module):
         self.dim, self.keepdim = dim, keepdim
 
     def forward(self, x, mask=None):
-        raise RuntimeError("standalone GlobalAvgPool2d is not part of the HIP hot path (fused into the ResNet head)")
+        from .functions import global_avgpool2d_module_forward
+        return global_avgpool2d_module_forward(self, x, mask)
 
 
 layer_dict = {

@@ -50,7 +50,14 @@ class ConvNeuralNetwork(nn.Module):
             nn.Dropout(drop_rate) if drop_rate > 0 else nn.Identity()) for i in range(len(dims))])
 
     def forward(self, x, x_len=None):
-        raise RuntimeError("ConvNeuralNetwork stems run fused inside Audio/VisualEfficientConformerEncoder (HIP front-end kernels)")
+        """nnet/modules.py:115-130: conv -> norm -> activation -> dropout per layer (+ residual); every layer halves the lengths (the reference hard-codes 2).
+        On the hot path the two stems run as fused sequences (ops.AudioStemFn / ops.VideoStemFn, called by the encoders); called on its own the stack runs layer by
+        layer through the stand-alone layer forwards (same kernels, more launches)."""
+        for layer in self.layers:
+            x = x + layer(x) if self.residual else layer(x)
+            if x_len is not None:
+                x_len = torch.div(x_len - 1, 2, rounding_mode="floor") + 1
+        return x if x_len is None else (x, x_len)
 
 
 class FeedForwardModule(nn.Module):

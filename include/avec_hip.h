@@ -211,6 +211,14 @@ int avec_to_f32_rows(int dtype, const void* src, long long ld_src, float* dst, l
  * 3 GLU over the last axis (x [rows][2C] -> out [rows][C]).  backward != 0: out = d(loss)/dx from dy (GLU: out is [rows][2C]). */
 int avec_act_f32(int act, const float* x, const float* dy, float* out, long long rows, int C, int backward, hipStream_t stream);
 int avec_dropout_f32(const float* x, float* y, float p, const unsigned long long* rng, unsigned rng_stream, long long n, hipStream_t stream);
+/* Stand-alone layers (avec_amd/csrc/standalone.hip): layers.MaxPool3d with a (1, KH, KW) window on a channels-last tensor [frames][H][W][C] (nnet/layers.py:839-915: zero
+ * padding pad0 / pad1 before / behind each spatial axis, then a valid max pool; idx = winner slot kh*KW + kw, 255 = the zero padding), and layers.Upsample(mode="nearest")
+ * on rows [B][T][D] -> [B][T*P][D] (nnet/layers.py:1013-1043; backward != 0: the P-row sums).  On the hot path both run fused (stem3p.hip, patch attention). */
+int avec_maxpool_hw_fwd(int dtype, const void* x, void* out, unsigned char* idx, long long frames, int H, int W, int C, int KH, int KW, int SH, int SW,
+                        int pad0_h, int pad0_w, int pad1_h, int pad1_w, hipStream_t stream);
+int avec_maxpool_hw_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, long long frames, int H, int W, int C, int KH, int KW, int SH, int SW,
+                        int pad0_h, int pad0_w, int pad1_h, int pad1_w, hipStream_t stream);
+int avec_upsample_rows(int dtype, const void* src, void* dst, long long B, int T, int D, int P, int backward, hipStream_t stream);
 /* patch attention pooling (layers.AvgPool1d / Upsample, nnet/attentions.py:342-346,365-380) */
 int avec_patch_pool_fwd(int dtype, const void* x, void* y, int B, int T, int D, int P, hipStream_t stream);
 int avec_patch_pool_bwd(int dtype, const void* dy, void* dx, int B, int T, int D, int P, hipStream_t stream);
