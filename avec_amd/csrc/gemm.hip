@@ -1511,7 +1511,8 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   g.split = 1; g.nb_inner = nb_inner;
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
-  if (dtype == AVEC_BF16 && strides) for (int i = 0; i < 4; ++i) AVEC_CHECK_ARG(strides[i] % 2 == 0, "gemm_tn: bf16 batch strides must be even");
+  // P batches stay dword aligned; Q batches may start on any element (heads of odd width, d = 45: the plain-load kernels issue unaligned dword loads, which gfx950 serves)
+  if (dtype == AVEC_BF16 && strides) for (int i = 0; i < 2; ++i) AVEC_CHECK_ARG(strides[i] % 2 == 0, "gemm_tn: bf16 batch strides of P must be even");
   const int nbatch = nb_outer * nb_inner;
   // few output tiles AND a short reduction (conformer weight gradients): 64x64 tiles fill the chip with less atomic traffic; long reductions
   // (conv weight gradients, M ~ 1e5..1e6) amortise the atomics and prefer the more efficient 128x128 tile

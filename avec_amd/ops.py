@@ -129,6 +129,7 @@ def empty(shape, dtype, ref):
     return torch.empty(shape, dtype=dtype, device=ref.device)
 
 
+ATTN_ODD_VALU = os.environ.get("AVEC_ATTN_ODD_VALU", "0") == "1"             # A/B: odd head widths take the VALU column pass of the attention backward (round 2)
 TNG_ALIGNED_ONLY = os.environ.get("AVEC_TNG_ALIGNED_ONLY", "0") == "1"       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
 
 
@@ -695,7 +696,7 @@ class AttentionModuleFn(torch.autograd.Function):
         Tld, Rld = (Tp + 7) // 8 * 8, (2 * Tp - 1 + 7) // 8 * 8
         scratch = empty((2, B * H, Tp, Tld), adt, dy)                # P and dS of every (batch, head), row stride padded to 8
         a.pbuf, a.dsbuf, a.ldt = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * esz, Tld
-        use_mfma = d % 2 == 0                                        # head column offsets must stay dword aligned in bf16 (d = 45 heads take the VALU column pass)
+        use_mfma = d % 2 == 0 or not ATTN_ODD_VALU                   # odd head widths (d = 45): the batched products read their Q operand from odd element offsets (unaligned dword loads)
         if use_mfma:
             dsrel = torch.zeros((H, B * Tp, Rld), dtype=adt, device=dy.device)
             a.dsrel, a.ldr = dsrel.data_ptr(), Rld

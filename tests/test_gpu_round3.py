@@ -130,3 +130,37 @@ def test_inplace_weight_edits_reach_train_step_and_eval_step_and_fp8_amax_resets
     finally:
         fp8.enable(False)
         avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("B,H,T,d", [(2, 4, 200, 45), (3, 4, 67, 45), (2, 2, 50, 33)])
+def test_batched_tn_products_on_odd_head_offsets(B, H, T, d):
+    """dK = dS^T Q per (batch, head) with heads of odd width (d = 45, audio stage 0): the Q operand and the stored result start on odd bf16 element offsets.
+    avec_gemm_tn_batched_store / avec_gemm_tn_batched against a float64 einsum on the same bf16-rounded operands."""
+    import ctypes
+    import avec_amd
+    from avec_amd import ops, runtime as rt
+    g = torch.Generator().manual_seed(21)
+    D, Tld = H * d, (T + 7) // 8 * 8
+    ds = torch.zeros(B * H, T, Tld)
+    ds[..., :T] = torch.randn(B * H, T, T, generator=g)
+    ds = ds.bfloat16().to(dev())
+    qkv = torch.randn(B * T, 3 * D, generator=g).bfloat16().to(dev())
+    try:
+        avec_amd.set_compute_dtype("bf16")
+        out = torch.zeros(B * T, 3 * D, dtype=torch.bfloat16, device=dev())
+        L6 = ctypes.c_longlong * 6
+        ops.lib.gemm_tn_batched_store(rt.dt(), ds.data_ptr(), Tld, qkv.data_ptr(), 3 * D, out.data_ptr() + D * 2, 3 * D, T, T, d, B, H,
+                                      L6(H * T * Tld, T * Tld, T * 3 * D, d, T * 3 * D, d), rt.stream())
+        acc = torch.zeros(T, D, dtype=torch.float32, device=dev())                   # dE-style: summed over the batch into fp32, per head
+        ops.lib.gemm_tn_batched(rt.dt(), ds.data_ptr(), Tld, qkv.data_ptr(), 3 * D, acc.data_ptr(), D, T, T, d, B, H,
+                                L6(H * T * Tld, T * Tld, T * 3 * D, d, 0, d), rt.stream())
+        torch.cuda.synchronize()
+    finally:
+        avec_amd.set_compute_dtype("f32")
+    q = qkv[:, :D].double().cpu().view(B, T, H, d)
+    s = ds[..., :T].double().cpu().view(B, H, T, T)
+    ref = torch.einsum("bhij,bihc->bjhc", s, q)                                      # [B][T(j)][H][d]
+    got = out[:, D:2 * D].double().cpu().view(B, T, H, d)
+    assert rel_err(got, ref) < 1e-2
+    assert out[:, :D].abs().max() == 0 and out[:, 2 * D:].abs().max() == 0          # nothing written outside the K third
+    assert rel_err(acc.double().cpu().view(T, H, d), ref.sum(0)) < 1e-3
