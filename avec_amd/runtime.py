@@ -294,8 +294,8 @@ def register_weight(param, A, Tm, C, need_bwd=True, c_pad=None):
 
 
 def _shadow_blocks(sh):
-    """workgroups of avec_shadow_refresh for one weight: one per 32 x 32 (A x C) tile and tap"""
-    return sh.Tm * ((sh.A + 31) // 32) * ((sh.C + 31) // 32)
+    """workgroups of avec_shadow_refresh for one weight: one per 64 x 64 (A x C) tile and tap"""
+    return sh.Tm * ((sh.A + 63) // 64) * ((sh.C + 63) // 64)
 
 
 def _refresh_single(param, sh):

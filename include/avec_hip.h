@@ -361,9 +361,12 @@ int avec_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
 int avec_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* state_dev, float beta1, float beta2, float eps,
                            float weight_decay, float grad_scale, int zero_grad, long long n, const int* skip_flag, hipStream_t stream);
 /* Compute-dtype copies of the GEMM weights (master fp32 [A][Tm][C]): fwd = same order, bwd = [C][Tm][A].  table entry = 10 x int64: src_off, fwd_off|-1,
- * bwd_off|-1, A, Tm, C, first_block, n_blocks = Tm*ceil(A/32)*ceil(C/32) (one workgroup per 32x32 tile and tap), C_pad (row stride of the fwd
+ * bwd_off|-1, A, Tm, C, first_block, n_blocks = Tm*ceil(A/64)*ceil(C/64) (one workgroup per 64x64 tile and tap), C_pad (row stride of the fwd
  * shadow when Tm==1), bwd row pitch (0: Tm*A; larger when several weights share one [C][G*A] backward matrix, e.g. Q|K|V) */
 int avec_shadow_refresh(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long total_blocks, hipStream_t stream);
+/* partial refresh: `table_dev` points at the first of `n_entries` consecutive entries, whose blocks are [first_block, first_block + n_blocks) of the full table
+ * (the weights of one sub-network right after ITS optimizer launch, while the rest of the backward pass is still running) */
+int avec_shadow_refresh_range(int dtype, const float* master, void* shadow, const long long* table_dev, int n_entries, long long first_block, long long n_blocks, hipStream_t stream);
 
 #ifdef __cplusplus
 }
