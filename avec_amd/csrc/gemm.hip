@@ -641,7 +641,17 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ u32x4 lds_read128(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128o(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory"); return v; }
+// LDS-DMA of 16 B per lane, scalar base + per-lane 32-bit byte offset (no VALU on the issue path), LDS destination (wave-uniform) through M0
+__device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
+}
 
+// Round 3: the loop's address arithmetic is out of the VALU -- the A fragments of a step share ONE address (rows 32 apart keep the swizzle: immediates), the B
+// fragment addresses are loop constants plus the ring slot, the DMA sources are a scalar base + a per-lane 32-bit offset fixed at entry (120 -> ~50 VALU
+// instructions per K-step; at ~4 issue cycles per wave64 VALU instruction they cost as much as the step's 16 MFMAs).  Rows outside the tensor are clamped
+// instead of redirected to a zero page: every tap that could read them is masked (it lies outside its image), and tile rows / columns beyond M / N are never stored.
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   typedef bf16 T;
@@ -652,48 +662,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   constexpr int BTILE = BN * RB, AWIN = WROWS * RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Bring = smem; char* const Awin = smem + STAGES * BTILE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
   const int Wd = g.a.W, H = g.a.H, C = g.a.C, halo = Wd + 1;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  // DMA descriptors: window row wr = i*64 + tid/4 holds source pixel m0 - halo + wr; physical slot tid%4 carries logical chunk slot ^ swz(row)
-  int aoff[NA], boff[NCB];
+  // DMA plan: window row wr = i*64 + tid/4 holds source pixel m0 - halo + wr (clamped into the tensor); physical slot tid%4 carries logical chunk slot ^ swz(row)
+  unsigned aoff[NA], boff[NCB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int wr = i * 64 + (tid >> 2); const long long p = m0 - halo + wr;
-    aoff[i] = (p >= 0 && p < g.M && wr < BM + 2 * halo) ? (int)(p * C) + (((tid & 3) ^ glds_swz<RB>(wr)) * 8) : -1;
+    const int wr = i * 64 + (tid >> 2); long long p = m0 - halo + wr;
+    p = p < 0 ? 0 : (p >= g.M ? g.M - 1 : p);
+    aoff[i] = (unsigned)((p * C + (((tid & 3) ^ glds_swz<RB>(wr)) * 8)) * 2);
   }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
-    const int row = i * 64 + (tid >> 2);
-    boff[i] = (n0 + row < g.N) ? (int)((long long)(n0 + row) * g.ldw) + (((tid & 3) ^ glds_swz<RB>(row)) * 8) : -1;
+    const int row = i * 64 + (tid >> 2); const int n = n0 + row < g.N ? n0 + row : g.N - 1;
+    boff[i] = (unsigned)(((long long)n * g.ldw + (((tid & 3) ^ glds_swz<RB>(row)) * 8)) * 2);
   }
+  const unsigned bring0 = (unsigned)(uintptr_t)(lptr_t)Bring, awin0 = (unsigned)(uintptr_t)(lptr_t)Awin;
+  const unsigned wslot = (unsigned)wave * 1024u;
   auto issueA = [&](int cc, int buf) {
     if (AVEC_ABL & (2 | 64)) return;
+    const char* base = (const char*)g.a.ptr + (long long)cc * (KE * 2);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const void* src = aoff[i] >= 0 ? (const void*)((const T*)g.a.ptr + (aoff[i] + cc * KE)) : (const void*)avec_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Awin + buf * AWIN + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < NA; ++i) glds16_sv(aoff[i], base, awin0 + (unsigned)buf * AWIN + i * 4096 + wslot);
   };
   auto issueB = [&](int koff, int buf) {
     if (AVEC_ABL & (2 | 128)) return;
+    const char* base = (const char*)g.W + (long long)koff * 2;
 #pragma unroll
-    for (int i = 0; i < NCB; ++i) {
-      const void* src = boff[i] >= 0 ? (const void*)((const T*)g.W + (boff[i] + koff)) : (const void*)avec_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bring + buf * BTILE + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < NCB; ++i) glds16_sv(boff[i], base, bring0 + (unsigned)buf * BTILE + i * 4096 + wslot);
   };
 
   // fragment rows and the taps each of them may use
-  int arow[MT]; unsigned amask[MT];
+  unsigned amask[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int r = wm * (BM / 2) + i * 32 + (lane & 31);
-    arow[i] = r + halo;
     const long long p = m0 + r;
     unsigned mk = 0u;
     if (p < g.M) {
@@ -708,10 +715,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
     }
     amask[i] = mk;
   }
-  int offb[NT], swb[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { const int row = wn * (BN / 2) + j * 32 + (lane & 31); offb[j] = row * RB; swb[j] = glds_swz<RB>(row); }
+  const int arow0 = wm * (BM / 2) + (lane & 31) + halo;        // window row of this lane's first fragment row; fragment i: + 32 i (same swizzle: (w >> 2) & 3)
   const int gsel = lane >> 5;
+  unsigned bq[2];                                             // B fragment address inside a ring slot, K-substep q; fragment j: + 2048 j
+  { const int row = wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bq[q] = (unsigned)(row * RB + (((q * 2 + gsel) ^ glds_swz<RB>(row)) << 4)); }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -722,7 +731,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int NC = C / KE, KT = NC * 9;
-  const unsigned bring0 = (unsigned)(uintptr_t)(lptr_t)Bring, awin0 = (unsigned)(uintptr_t)(lptr_t)Awin;
 #define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
   // issue order: A(0), B(0), B(1); then in iteration ks (after its barrier): [A(cc+1) when t == 0], B(ks+2)
   issueA(0, 0);
@@ -730,6 +738,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   issueB(C, 1);                                   // step 1 = (chunk 0, tap 1): K offset 1 * C
   int cc = 0, t = 0;                              // chunk / tap of step ks
   int i_cc = 0, i_t = 2;                          // chunk / tap of the next B tile to issue (step ks + 2)
+  int slot = 0, islot = 2;                        // ring slot of step ks / of the tile issued in it
+  int sh = (MODE == MODE_CONV_FWD ? 1 : -1) * (-Wd - 1), kw = 0;      // pixel shift of tap t
   bool a_prev = false;                            // an A window was issued in the previous iteration (it is newer than B(ks))
   for (int ks = 0; ks < KT; ++ks) {
     const bool last = ks == KT - 1;
@@ -738,23 +748,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
     else AVEC_WAIT_VM(NCB);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const int kh = t / 3, kw = t - kh * 3;
-    const int sh = (MODE == MODE_CONV_FWD ? 1 : -1) * ((kh - 1) * Wd + (kw - 1));
-    const unsigned Ac = awin0 + (cc & 1) * AWIN, Bs = bring0 + (ks % STAGES) * BTILE;
+    const unsigned Ac = awin0 + (unsigned)(cc & 1) * AWIN, Bs = bring0 + (unsigned)slot * BTILE;
     // all fragment reads of the step are requested at once (inline asm: in-order returns, counted waits); the first MFMA group
     // waits only for its own K-substep while the second one's reads are still in flight
     u32x4 fa[2][MT], fb[2][NT];
+    const int w0 = arow0 + sh;
+    const unsigned abase = Ac + (unsigned)w0 * RB, asw = (unsigned)(w0 >> 2) & 3u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) { const int w = arow[i] + sh; fa[q][i] = lds_read128(Ac + w * RB + (((q * 2 + gsel) ^ glds_swz<RB>(w)) << 4)); }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[q][j] = lds_read128(Bs + offb[j] + (((q * 2 + gsel) ^ swb[j]) << 4));
+      const unsigned aa = abase + ((((unsigned)(q * 2 + gsel)) ^ asw) << 4), bb = Bs + bq[q];
+      fa[q][0] = lds_read128o<0>(aa); fa[q][1] = lds_read128o<2048>(aa);
+      if (MT > 2) { fa[q][2 % MT] = lds_read128o<4096>(aa); fa[q][3 % MT] = lds_read128o<6144>(aa); }
+      fb[q][0] = lds_read128o<0>(bb);
+      if (NT > 1) fb[q][1 % NT] = lds_read128o<2048>(bb);
     }
     // the DMA of the tiles two steps ahead goes out while the fragment reads are in flight
     a_prev = false;
     if (t == 0 && cc + 1 < NC) { issueA(cc + 1, (cc + 1) & 1); a_prev = true; }
-    if (ks + 2 < KT) { issueB(i_t * C + i_cc * KE, (ks + 2) % STAGES); if (++i_t == 9) { i_t = 0; ++i_cc; } }
+    if (ks + 2 < KT) { issueB(i_t * C + i_cc * KE, islot); if (++i_t == 9) { i_t = 0; ++i_cc; } if (++islot == STAGES) islot = 0; }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -774,7 +785,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       }
       __builtin_amdgcn_sched_barrier(0);          // (keeps this group's MFMAs above the next group's wait)
     }
-    if (++t == 9) { t = 0; ++cc; }
+    if (++slot == STAGES) slot = 0;
+    // next tap: (kh, kw) row-major; its pixel shift moves by 1, or by W - 2 at the end of a tap row
+    if (++t == 9) { t = 0; ++cc; kw = 0; sh = (MODE == MODE_CONV_FWD ? 1 : -1) * (-Wd - 1); }
+    else if (++kw == 3) { kw = 0; sh += (MODE == MODE_CONV_FWD ? 1 : -1) * (Wd - 2); }
+    else sh += (MODE == MODE_CONV_FWD ? 1 : -1);
   }
 #undef AVEC_WAIT_VM
   __syncthreads();
