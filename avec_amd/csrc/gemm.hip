@@ -642,16 +642,32 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 256) ? 1 : 2) void gemm_nt_gl
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ u32x4 lds_read128(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
 template <int OFF> __device__ __forceinline__ u32x4 lds_read128o(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory"); return v; }
-// LDS-DMA of 16 B per lane, scalar base + per-lane 32-bit byte offset (no VALU on the issue path), LDS destination (wave-uniform) through M0
-__device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsigned lds_dst_uniform) {
+// LDS-DMA of N x 16 B per lane as one group: scalar base + per-lane 32-bit byte offsets (no VALU on the issue path); LDS destinations lds0 + 4096 i (wave-uniform)
+// go through M0, saved and restored once per group
+#define AVEC_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+#define AVEC_GLDS_NEXT(k) "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #k ", %2\n\t"
+#define AVEC_GLDS_TAIL "s_mov_b32 m0, %0"
+template <int N> __device__ __forceinline__ void glds16_group(const unsigned (&v)[N], const void* sbase, unsigned lds0) {
+  static_assert(N == 1 || N == 2 || N == 3 || N == 5, "group size");
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
+  if constexpr (N == 1) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0) : "memory", "scc");
+  if constexpr (N == 2) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]) : "memory", "scc");
+  if constexpr (N == 3) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+  if constexpr (N == 5) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_NEXT(6) AVEC_GLDS_NEXT(7) AVEC_GLDS_TAIL
+                                     : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory", "scc");
 }
+#undef AVEC_GLDS_HEAD
+#undef AVEC_GLDS_NEXT
+#undef AVEC_GLDS_TAIL
+template <int V> struct IntC { static constexpr int value = V; };
 
-// Round 3: the loop's address arithmetic is out of the VALU -- the A fragments of a step share ONE address (rows 32 apart keep the swizzle: immediates), the B
-// fragment addresses are loop constants plus the ring slot, the DMA sources are a scalar base + a per-lane 32-bit offset fixed at entry (120 -> ~50 VALU
-// instructions per K-step; at ~4 issue cycles per wave64 VALU instruction they cost as much as the step's 16 MFMAs).  Rows outside the tensor are clamped
-// instead of redirected to a zero page: every tap that could read them is masked (it lies outside its image), and tile rows / columns beyond M / N are never stored.
+// Round 3: the loop is bound by instruction ISSUE, not by a data path.  Ablation (512-channel stage, 147 us): without MFMA, LDS-DMA and fragment reads the loop
+// skeleton alone -- ~190 instructions per K-step (address arithmetic, tap bookkeeping, M0 traffic, ring-slot modulo, branches) -- took 72 us, the MFMAs alone
+// need 63, and the two ADD: a wave issues one instruction per 4-cycle slot whatever its type, and two waves per SIMD do not hide each other's scalar and vector
+// bookkeeping under the MFMAs.  So the nine taps of a channel chunk are unrolled (two chunks per trip for the window parity): tap, ring slot, window buffer and
+// fragment offsets are compile-time, every ds_read_b128 takes one of 18 + 2 precomputed addresses plus an immediate, the DMA sources are a scalar base + a
+// per-lane 32-bit offset fixed at entry, one M0 save / restore per DMA group.  Rows outside the tensor are clamped instead of redirected to a zero page: every tap
+// that could read them is masked (it lies outside its image), and tile rows / columns beyond M / N are never stored.
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   typedef bf16 T;
@@ -660,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   constexpr int WROWS = BM + 64;                              // window rows: BM + 2 * halo, halo = W + 1 <= 32
   constexpr int MT = BM / 64, NT = BN / 64;
   constexpr int BTILE = BN * RB, AWIN = WROWS * RB;
+  constexpr int SGN = MODE == MODE_CONV_FWD ? 1 : -1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Bring = smem; char* const Awin = smem + STAGES * BTILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -683,18 +700,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   }
   const unsigned bring0 = (unsigned)(uintptr_t)(lptr_t)Bring, awin0 = (unsigned)(uintptr_t)(lptr_t)Awin;
   const unsigned wslot = (unsigned)wave * 1024u;
-  auto issueA = [&](int cc, int buf) {
-    if (AVEC_ABL & (2 | 64)) return;
-    const char* base = (const char*)g.a.ptr + (long long)cc * (KE * 2);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) glds16_sv(aoff[i], base, awin0 + (unsigned)buf * AWIN + i * 4096 + wslot);
-  };
-  auto issueB = [&](int koff, int buf) {
-    if (AVEC_ABL & (2 | 128)) return;
-    const char* base = (const char*)g.W + (long long)koff * 2;
-#pragma unroll
-    for (int i = 0; i < NCB; ++i) glds16_sv(boff[i], base, bring0 + (unsigned)buf * BTILE + i * 4096 + wslot);
-  };
+  const int C2 = C * 2;                                       // bytes between the B tiles of consecutive taps
 
   // fragment rows and the taps each of them may use
   unsigned amask[MT];
@@ -709,18 +715,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int yy = MODE == MODE_CONV_FWD ? y + kh - 1 : y - kh + 1, xx = MODE == MODE_CONV_FWD ? x + kw - 1 : x - kw + 1;
+          const int yy = y + SGN * (kh - 1), xx = x + SGN * (kw - 1);
           if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) mk |= 1u << (kh * 3 + kw);
         }
     }
     amask[i] = mk;
   }
-  const int arow0 = wm * (BM / 2) + (lane & 31) + halo;        // window row of this lane's first fragment row; fragment i: + 32 i (same swizzle: (w >> 2) & 3)
+  // LDS addresses of the fragment reads: A per (tap, K-substep) -- fragment i adds 2048 i, the second window buffer AWIN (rows 32 apart keep the swizzle
+  // (w >> 2) & 3); B per K-substep -- fragment j adds 2048 j, the ring slot BTILE * slot
   const int gsel = lane >> 5;
-  unsigned bq[2];                                             // B fragment address inside a ring slot, K-substep q; fragment j: + 2048 j
-  { const int row = wn * (BN / 2) + (lane & 31);
+  unsigned aad[9][2], bad[2];
+  { const int arow0 = wm * (BM / 2) + (lane & 31) + halo;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) bq[q] = (unsigned)(row * RB + (((q * 2 + gsel) ^ glds_swz<RB>(row)) << 4)); }
+    for (int t = 0; t < 9; ++t) {
+      const int w0 = arow0 + SGN * ((t / 3 - 1) * Wd + (t % 3 - 1));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) aad[t][q] = awin0 + (unsigned)w0 * RB + ((((unsigned)(q * 2 + gsel)) ^ ((unsigned)(w0 >> 2) & 3u)) << 4);
+    }
+    const int row = wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bad[q] = bring0 + (unsigned)(row * RB + (((q * 2 + gsel) ^ glds_swz<RB>(row)) << 4)); }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -730,42 +744,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int NC = C / KE, KT = NC * 9;
+  const int NC = C / KE;
+  const char* const Ab = (const char*)g.a.ptr; const char* const Wb = (const char*)g.W;
 #define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-  // issue order: A(0), B(0), B(1); then in iteration ks (after its barrier): [A(cc+1) when t == 0], B(ks+2)
-  issueA(0, 0);
-  issueB(0, 0);
-  issueB(C, 1);                                   // step 1 = (chunk 0, tap 1): K offset 1 * C
-  int cc = 0, t = 0;                              // chunk / tap of step ks
-  int i_cc = 0, i_t = 2;                          // chunk / tap of the next B tile to issue (step ks + 2)
-  int slot = 0, islot = 2;                        // ring slot of step ks / of the tile issued in it
-  int sh = (MODE == MODE_CONV_FWD ? 1 : -1) * (-Wd - 1), kw = 0;      // pixel shift of tap t
-  bool a_prev = false;                            // an A window was issued in the previous iteration (it is newer than B(ks))
-  for (int ks = 0; ks < KT; ++ks) {
-    const bool last = ks == KT - 1;
-    if (last) AVEC_WAIT_VM(0);
-    else if (a_prev) AVEC_WAIT_VM(NCB + NA);
+  // issue order: A(0), B(0), B(1); then in step ks (after its barrier): [A(cc+1) when t == 0], B(ks+2)
+  if (!(AVEC_ABL & (2 | 64))) glds16_group<NA>(aoff, Ab, awin0 + wslot);
+  if (!(AVEC_ABL & (2 | 128))) { glds16_group<NCB>(boff, Wb, bring0 + wslot); glds16_group<NCB>(boff, Wb + C2, bring0 + BTILE + wslot); }
+
+  // one K-step: tap TAP of chunk cc, whose window sits in buffer PAR
+  auto step = [&](auto tapc, auto parc, const int cc) {
+    constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value;
+    const bool last_chunk = cc + 1 >= NC;
+    if (TAP == 8) { if (last_chunk) AVEC_WAIT_VM(0); else AVEC_WAIT_VM(NCB); }
+    else if (TAP == 1) { if (last_chunk) AVEC_WAIT_VM(NCB); else AVEC_WAIT_VM(NCB + NA); }       // the window of the next chunk went out in the previous step (newer than B(ks))
     else AVEC_WAIT_VM(NCB);
-    __builtin_amdgcn_s_barrier();
+    if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const unsigned Ac = awin0 + (unsigned)(cc & 1) * AWIN, Bs = bring0 + (unsigned)slot * BTILE;
     // all fragment reads of the step are requested at once (inline asm: in-order returns, counted waits); the first MFMA group
     // waits only for its own K-substep while the second one's reads are still in flight
     u32x4 fa[2][MT], fb[2][NT];
-    const int w0 = arow0 + sh;
-    const unsigned abase = Ac + (unsigned)w0 * RB, asw = (unsigned)(w0 >> 2) & 3u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const unsigned aa = abase + ((((unsigned)(q * 2 + gsel)) ^ asw) << 4), bb = Bs + bq[q];
-      fa[q][0] = lds_read128o<0>(aa); fa[q][1] = lds_read128o<2048>(aa);
-      if (MT > 2) { fa[q][2 % MT] = lds_read128o<4096>(aa); fa[q][3 % MT] = lds_read128o<6144>(aa); }
-      fb[q][0] = lds_read128o<0>(bb);
-      if (NT > 1) fb[q][1 % NT] = lds_read128o<2048>(bb);
+      if (AVEC_ABL & 4) { for (int i = 0; i < MT; ++i) fa[q][i] = u32x4{(unsigned)cc, 1u, 2u, 3u}; for (int j = 0; j < NT; ++j) fb[q][j] = u32x4{(unsigned)cc, 5u, 6u, 7u}; continue; }
+      fa[q][0] = lds_read128o<PAR * AWIN>(aad[TAP][q]); fa[q][1] = lds_read128o<PAR * AWIN + 2048>(aad[TAP][q]);
+      if (MT > 2) { fa[q][2 % MT] = lds_read128o<PAR * AWIN + 4096>(aad[TAP][q]); fa[q][3 % MT] = lds_read128o<PAR * AWIN + 6144>(aad[TAP][q]); }
+      fb[q][0] = lds_read128o<(TAP % 3) * BTILE>(bad[q]);
+      if (NT > 1) fb[q][1 % NT] = lds_read128o<(TAP % 3) * BTILE + 2048>(bad[q]);
     }
     // the DMA of the tiles two steps ahead goes out while the fragment reads are in flight
-    a_prev = false;
-    if (t == 0 && cc + 1 < NC) { issueA(cc + 1, (cc + 1) & 1); a_prev = true; }
-    if (ks + 2 < KT) { issueB(i_t * C + i_cc * KE, islot); if (++i_t == 9) { i_t = 0; ++i_cc; } if (++islot == STAGES) islot = 0; }
+    if (TAP == 0 && !last_chunk && !(AVEC_ABL & (2 | 64))) glds16_group<NA>(aoff, Ab + (long long)(cc + 1) * (KE * 2), awin0 + (PAR ^ 1) * AWIN + wslot);
+    if ((TAP < 7 || !last_chunk) && !(AVEC_ABL & (2 | 128)))
+      glds16_group<NCB>(boff, Wb + (long long)((TAP + 2) % 9) * C2 + (long long)(cc + (TAP >= 7 ? 1 : 0)) * (KE * 2), bring0 + ((TAP + 2) % 3) * BTILE + wslot);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[q][j]));
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const bool ok = (amask[i] >> t) & 1u;
+        const bool ok = amask[i] & (1u << TAP);
         const u32x4 z = {0u, 0u, 0u, 0u};
         const u32x4 a = ok ? fa[q][i] : z;
 #pragma unroll
@@ -785,11 +794,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       }
       __builtin_amdgcn_sched_barrier(0);          // (keeps this group's MFMAs above the next group's wait)
     }
-    if (++slot == STAGES) slot = 0;
-    // next tap: (kh, kw) row-major; its pixel shift moves by 1, or by W - 2 at the end of a tap row
-    if (++t == 9) { t = 0; ++cc; kw = 0; sh = (MODE == MODE_CONV_FWD ? 1 : -1) * (-Wd - 1); }
-    else if (++kw == 3) { kw = 0; sh += (MODE == MODE_CONV_FWD ? 1 : -1) * (Wd - 2); }
-    else sh += (MODE == MODE_CONV_FWD ? 1 : -1);
+  };
+  auto chunk = [&](auto parc, const int cc) {
+    step(IntC<0>{}, parc, cc); step(IntC<1>{}, parc, cc); step(IntC<2>{}, parc, cc); step(IntC<3>{}, parc, cc); step(IntC<4>{}, parc, cc);
+    step(IntC<5>{}, parc, cc); step(IntC<6>{}, parc, cc); step(IntC<7>{}, parc, cc); step(IntC<8>{}, parc, cc);
+  };
+#pragma unroll 1
+  for (int cc = 0; cc < NC; cc += 2) {
+    chunk(IntC<0>{}, cc);
+    if (cc + 1 < NC) chunk(IntC<1>{}, cc + 1);
   }
 #undef AVEC_WAIT_VM
   __syncthreads();
