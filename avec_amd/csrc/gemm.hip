@@ -700,6 +700,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   }
   const unsigned bring0 = (unsigned)(uintptr_t)(lptr_t)Bring, awin0 = (unsigned)(uintptr_t)(lptr_t)Awin;
   const unsigned wslot = (unsigned)wave * 1024u;
+  const unsigned zaddr = (awin0 + 2 * AWIN + 255u) & ~255u;   // zero blocks (256 B each, 256-aligned) at zaddr + 2048 i behind the two windows
+  if (tid < 16 * MT) { *(uint4*)(smem + (zaddr - bring0) + (tid >> 4) * 2048 + (tid & 15) * 16) = make_uint4(0u, 0u, 0u, 0u); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   const int C2 = C * 2;                                       // bytes between the B tiles of consecutive taps
 
   // fragment rows and the taps each of them may use
@@ -766,8 +768,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (AVEC_ABL & 4) { for (int i = 0; i < MT; ++i) fa[q][i] = u32x4{(unsigned)cc, 1u, 2u, 3u}; for (int j = 0; j < NT; ++j) fb[q][j] = u32x4{(unsigned)cc, 5u, 6u, 7u}; continue; }
-      fa[q][0] = lds_read128o<PAR * AWIN>(aad[TAP][q]); fa[q][1] = lds_read128o<PAR * AWIN + 2048>(aad[TAP][q]);
-      if (MT > 2) { fa[q][2 % MT] = lds_read128o<PAR * AWIN + 4096>(aad[TAP][q]); fa[q][3 % MT] = lds_read128o<PAR * AWIN + 6144>(aad[TAP][q]); }
+      // rows whose tap lies outside the image read zeros instead of masking the operand (4 selects per fragment + the wait states behind them): four 256-byte zero
+      // blocks 2048 B apart behind the windows (fragment i adds 2048 i as an immediate), every lane at the bank group of its regular address (no extra conflicts).
+      // The centre tap is never masked.  (The pin keeps the 72 loop-invariant selected addresses from being hoisted into registers the kernel does not have.)
+      unsigned ar = aad[TAP][q] + (unsigned)(PAR * AWIN), az = (aad[TAP][q] & 0xF0u) | zaddr;
+      asm volatile("" : "+v"(az));
+#define AVEC_AADDR(i) ((TAP == 4 || (amask[i] & (1u << TAP))) ? ar : az)
+      fa[q][0] = lds_read128o<0>(AVEC_AADDR(0)); fa[q][1] = lds_read128o<2048>(AVEC_AADDR(1));
+      if (MT > 2) { fa[q][2 % MT] = lds_read128o<4096>(AVEC_AADDR(2 % MT)); fa[q][3 % MT] = lds_read128o<6144>(AVEC_AADDR(3 % MT)); }
+#undef AVEC_AADDR
       fb[q][0] = lds_read128o<(TAP % 3) * BTILE>(bad[q]);
       if (NT > 1) fb[q][1 % NT] = lds_read128o<(TAP % 3) * BTILE + 2048>(bad[q]);
     }
@@ -784,13 +793,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[q][j]));
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const bool ok = amask[i] & (1u << TAP);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        const u32x4 a = ok ? fa[q][i] : z;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          if (AVEC_ABL & 1) asm volatile("" :: "v"(a), "v"(fb[q][j])); else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
+          if (AVEC_ABL & 1) asm volatile("" :: "v"(fa[q][i]), "v"(fb[q][j])); else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);          // (keeps this group's MFMAs above the next group's wait)
     }
@@ -1360,7 +1366,7 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
   if (off || mode == MODE_PLAIN || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW || a.W > 31 || a.C % 32 != 0) return 1;
   if (!aligned16(a.ptr) || !aligned16(g_in.W) || g_in.ldw % 8 != 0 || g_in.M * a.C >= (1ll << 31) || (long long)g_in.N * g_in.ldw >= (1ll << 31) || g_in.N < 64) return 1;
   GemmArgs g = g_in; g.perm2 = 0;
-#define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
+#define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64 + 512 + (BM / 64 - 1) * 2048, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
     avec_note_kernel("conv3x3_shift_kernel<%d,%d,%d>", BM, BN, MODE); if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
   // 256-row tiles halve the weight-tile DMA per FLOP (measured 5-15 % on the 3200-image ResNet stages 2-3, slower once fewer than ~3 tiles per CU remain)
