@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
 
   const int NC = C / KE;
   const char* const Ab = (const char*)g.a.ptr; const char* const Wb = (const char*)g.W;
-#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define AVEC_WAIT_VM(n) do { if (!(AVEC_ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); } while (0)
   // issue order: A(0), B(0), B(1); then in step ks (after its barrier): [A(cc+1) when t == 0], B(ks+2)
   if (!(AVEC_ABL & (2 | 64))) glds16_group<NA>(aoff, Ab, awin0 + wslot);
   if (!(AVEC_ABL & (2 | 128))) { glds16_group<NCB>(boff, Wb, bring0 + wslot); glds16_group<NCB>(boff, Wb + C2, bring0 + BTILE + wslot); }
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
       glds16_group<NCB>(boff, Wb + (long long)((TAP + 2) % 9) * C2 + (long long)(cc + (TAP >= 7 ? 1 : 0)) * (KE * 2), bring0 + ((TAP + 2) % 3) * BTILE + wslot);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+      if (AVEC_ABL & 32) {} else            // (timing experiments only: the MFMAs then read whatever the registers hold)
       if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q][i]));
