@@ -648,11 +648,13 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read128o(unsigned lds_ad
 #define AVEC_GLDS_NEXT(k) "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #k ", %2\n\t"
 #define AVEC_GLDS_TAIL "s_mov_b32 m0, %0"
 template <int N> __device__ __forceinline__ void glds16_group(const unsigned (&v)[N], const void* sbase, unsigned lds0) {
-  static_assert(N == 1 || N == 2 || N == 3 || N == 5, "group size");
+  static_assert(N >= 1 && N <= 5, "group size");
   unsigned keep;
   if constexpr (N == 1) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0) : "memory", "scc");
   if constexpr (N == 2) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]) : "memory", "scc");
   if constexpr (N == 3) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+  if constexpr (N == 4) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_NEXT(6) AVEC_GLDS_TAIL
+                                     : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
   if constexpr (N == 5) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_NEXT(6) AVEC_GLDS_NEXT(7) AVEC_GLDS_TAIL
                                      : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory", "scc");
 }
@@ -816,6 +818,125 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Plain bf16 NT product with 64- or 128-row tiles x 64 columns: the conformer-sized products (a few hundred tiles, K = 256 .. 1440), which are bound by the
+// instructions the K loop issues, not by a data path -- 64 x 64 tiles run 4 MFMAs per wave and K-step; the general kernel above spends ~150 instructions per
+// step on them (bounds / tail / tap logic per DMA chunk, fragment addresses, ring-slot modulo).  Here the ring position is compile-time (steps unrolled by the
+// ring depth), every fragment read is one of eight precomputed addresses plus an immediate, the DMA sources are a scalar base + per-lane 32-bit offsets fixed at
+// entry; only the last, partial K tile takes per-lane selects (K % 8 == 0: a 16-byte chunk is inside K or not at all).  Rows beyond M / N are clamped (their
+// results are not stored).  Same LDS image, swizzle and epilogue as gemm_nt_glds_kernel<bf16, BM, 64, MODE_PLAIN, 4, false, 128>.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16_v64(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
+  typedef bf16 T;
+  constexpr int RB = 128, KE = 64, STAGES = 4;
+  constexpr int NCA = BM / 32, NCB = BN / 32, LPT = NCA + NCB;         // DMA passes (32 rows x 128 B) per tile
+  constexpr int MT = BM / 64, NT = BN / 64, KK = 4;                    // K-substeps of 16 per tile
+  constexpr int TILE = (BM + BN) * RB;
+  static_assert(NT == 1, "64-column tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem, wslot = (unsigned)wave * 1024u;
+  const int K = g.K, KT = (K + KE - 1) / KE, KF = K / KE;
+  // DMA plan: pass i, thread tid -> tile row tid/8 + 32 i, physical slot tid%8 carrying logical K-chunk (tid%8) ^ swz(row)
+  unsigned aoff[NCA], boff[NCB]; int kca, kcb[NCB];
+  kca = 0;
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) {
+    const int row = (tid >> 3) + i * 32; const long long m = m0 + row < g.M ? m0 + row : g.M - 1;
+    const int kc = (tid & 7) ^ glds_swz<RB>(row);
+    aoff[i] = (unsigned)((row_info<MODE_PLAIN>(g.a, m, g.M).base + kc * 8) * 2);
+    if (i == 0) kca = kc;                                            // (rows 32 apart share the swizzle)
+  }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int row = (tid >> 3) + i * 32; const int n = n0 + row < g.N ? n0 + row : g.N - 1;
+    kcb[i] = (tid & 7) ^ glds_swz<RB>(row);
+    boff[i] = (unsigned)(((long long)n * g.ldw + kcb[i] * 8) * 2);
+  }
+  const char* const Ab = (const char*)g.a.ptr; const char* const Wb = (const char*)g.W;
+  auto issue = [&](const int kt, auto stagec) {
+    constexpr int S = decltype(stagec)::value;
+    if (AVEC_ABL & 2) return;
+    const unsigned la = lds0 + S * TILE + wslot, lb = la + BM * RB;
+    if (kt < KF) { glds16_group<NCA>(aoff, Ab + (long long)kt * (KE * 2), la); glds16_group<NCB>(boff, Wb + (long long)kt * (KE * 2), lb); }
+    else {                                                           // the partial last tile: chunks at or beyond K come from the zero page
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) glds16_v64(kt * KE + kca * 8 < K ? (const void*)(Ab + aoff[i] + (long long)kt * (KE * 2)) : (const void*)avec_zero16, la + i * 4096);
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) glds16_v64(kt * KE + kcb[i] * 8 < K ? (const void*)(Wb + boff[i] + (long long)kt * (KE * 2)) : (const void*)avec_zero16, lb + i * 4096);
+    }
+  };
+  // fragment addresses inside a tile: K-substep q reads logical chunk 2 q + g of its row; A fragment i adds 4096 i (32 rows), the ring stage S * TILE
+  const int gsel = lane >> 5;
+  unsigned aad[2][KK], bad[2][KK];           // [ring stages 0-1 | 2-3]: the immediate offset field holds 16 bits
+  { const int ra = wm * (BM / 2) + (lane & 31), rb = wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      aad[0][q] = lds0 + (unsigned)(ra * RB + (((2 * q + gsel) ^ glds_swz<RB>(ra)) << 4));
+      bad[0][q] = lds0 + (unsigned)(BM * RB + rb * RB + (((2 * q + gsel) ^ glds_swz<RB>(rb)) << 4));
+      aad[1][q] = aad[0][q] + 2 * TILE; bad[1][q] = bad[0][q] + 2 * TILE;
+    } }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  issue(0, IntC<0>{});
+  if (KT > 1) issue(1, IntC<1>{});
+  if (KT > 2) issue(2, IntC<2>{});
+  auto step = [&](const int kt, auto stagec) {
+    constexpr int S = decltype(stagec)::value;
+    const int rem = KT - 1 - kt;                                     // tiles issued after kt: min(rem, 2) may still be in flight
+    if (rem >= 2) AVEC_WAIT_VM(2 * LPT); else if (rem == 1) AVEC_WAIT_VM(LPT); else AVEC_WAIT_VM(0);
+    if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 fa[KK][MT], fb[KK];
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if (AVEC_ABL & 4) { for (int i = 0; i < MT; ++i) fa[q][i] = u32x4{(unsigned)kt, 1u, 2u, 3u}; fb[q] = u32x4{(unsigned)kt, 5u, 6u, 7u}; continue; }
+      fa[q][0] = lds_read128o<(S & 1) * TILE>(aad[S >> 1][q]);
+      if (MT > 1) fa[q][1 % MT] = lds_read128o<(S & 1) * TILE + 4096>(aad[S >> 1][q]);
+      fb[q] = lds_read128o<(S & 1) * TILE>(bad[S >> 1][q]);
+    }
+    if (kt + 3 < KT) issue(kt + 3, IntC<(S + 3) % STAGES>{});        // into the slot everybody finished reading before this barrier
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * (MT + 1)) : "memory");
+      else if (q == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (MT + 1)) : "memory");
+      else if (q == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + 1) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q][i]));
+      asm volatile("" : "+v"(fb[q]));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        if (AVEC_ABL & 1) asm volatile("" :: "v"(fa[q][i]), "v"(fb[q])); else
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q]), acc[i][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt += STAGES) {
+    step(kt, IntC<0>{});
+    if (kt + 1 < KT) step(kt + 1, IntC<1>{});
+    if (kt + 2 < KT) step(kt + 2, IntC<2>{});
+    if (kt + 3 < KT) step(kt + 3, IntC<3>{});
+  }
+#undef AVEC_WAIT_VM
+  __syncthreads();                            // every wave is done with the ring before the epilogue reuses the LDS
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, 0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) NT product: A [M][K] and W [N][K] one byte per element, per-tensor scales, fp32 accumulate on
@@ -1324,6 +1445,18 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
   static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
+  static const bool no_lean = getenv("AVEC_NO_LEAN_NT") != nullptr;
+  if constexpr (sizeof(T) == 2 && BN == 64 && BM == 64) {       // (128 x 64 with the 4-stage ring leaves one workgroup per CU: slower than the general kernel's 2-stage ring)
+    // the lean plain kernel: whole 16-byte K-chunks, 32-bit byte offsets into both operands
+    const long long arows = g.a.step > 1 ? (g.M / (g.a.rows_out > 0 ? g.a.rows_out : 1) + 1) * (long long)g.a.rows_in : g.M;
+    if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && g.K % 8 == 0 && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K && !g.ktail &&
+        arows * g.a.ld * 2 < (1ll << 32) && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
+      const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
+      avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
+      if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
+      hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g); return 0;
+    }
+  }
   if ((a16 || plain_any) && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G2
 #undef G3
@@ -1401,7 +1534,10 @@ static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
     }
   }
   if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
-  if (((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
+  // plain bf16 products with whole 16-byte K-chunks: the lean 64 x 64 kernel beats the general 128 x 64 one up to the sizes the model has (3200 x 1024 x 256: 11.3 vs 11.8 us)
+  static const bool no_lean = getenv("AVEC_NO_LEAN_NT") != nullptr;
+  const bool lean = sizeof(T) == 2 && mode == MODE_PLAIN && !src_f32 && !no_lean && g.K % 8 == 0 && ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 4096;
+  if (!lean && ((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
   return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
 }
 
