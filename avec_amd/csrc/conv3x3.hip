@@ -255,6 +255,12 @@ __device__ __forceinline__ chunk16 c3_tr_read8(const char* p0, const char* p1) {
   const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
   chunk16 f; f.w[0] = ua.x; f.w[1] = ua.y; f.w[2] = ub.x; f.w[3] = ub.y; return f;
 }
+__device__ __forceinline__ void c3_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+typedef __attribute__((ext_vector_type(2))) unsigned c3_u32x2;
+__device__ __forceinline__ c3_u32x2 c3_lds_tr(unsigned lds_addr) { c3_u32x2 v; asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
 #define C3W_KROWS 512                       // reduction rows per image: H*(W+1) <= 512
 #define C3W_DBYTES (C3W_KROWS * 128)        // 65 536: dy image with the slab's row pitch
 
@@ -354,43 +360,58 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
 // image / element each 16-byte LDS slot receives) lives in LDS.  x is read C/64 times and dy C/128 times in total -- against once per column tile and
 // once per tap for the implicit-GEMM TN kernel (0.65 GB fetched per launch for 0.2 GB of tensors at C = 128).
 // ------------------------------------------------------------------------------------------------
-#define C3X_ROWS 352                        // x rows in LDS
-#define C3X_KROWS 288                       // dy rows in LDS
-struct C3WWArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W, C, KP, RS, IT; };   // KP: reduction rows per image (16-multiple), RS: x rows per image, IT: images per iteration
+#ifndef C3_ABL
+#define C3_ABL 0          // timing experiments: 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads
+#endif
+#define C3X_ROWS 352                        // x rows in LDS (two halves)
+#define C3X_KROWS 288                       // dy rows in LDS (two halves)
+#define C3X_XPL 6                           // DMA passes of one wave over a half: x (<= 176 rows x 16 chunks / 64 lanes / 8 waves), dy (<= 144 rows x 8 / 64 / 8)
+#define C3X_DPL 3
+struct C3WWArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W, C, KP, RS, IT; };   // KP: reduction rows per image (16-multiple), RS: x rows per image, IT: images per HALF
 
+// Round 3: (1) the LDS is a ring of two halves of IT images each: the LDS-DMA of the next half runs under the MFMAs of the current one (one barrier per half;
+// the first version loaded, waited, computed); (2) the DMA plan -- which image / element each 16-byte LDS slot receives -- is the same for every half and
+// lives in nine registers per lane instead of 32 KB of LDS read back before every DMA; (3) a step's 20 transposed reads go out together and the nine MFMAs
+// follow a counted wait ladder (before: every tap's reads sat next to their MFMA behind lgkmcnt(0), ~45 address additions per step).
 __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem; char* Ds = smem + C3X_ROWS * 256;
-  int* xplan = (int*)(Ds + C3X_KROWS * 128); int* dplan = xplan + C3X_ROWS * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W, C = a.C, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
   const int nci = C >> 7, kinds = (C >> 6) * nci, kind = blockIdx.x % kinds, cog = kind / nci, cig = kind - cog * nci;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // plan entry: (image inside the iteration) << 24 | element offset inside the image, or -1 = zero
-  for (int S = tid; S < C3X_ROWS * 16; S += 512) {
+  const unsigned xs0 = (unsigned)(uintptr_t)(lptr_t)Xs, ds0 = (unsigned)(uintptr_t)(lptr_t)Ds;
+  const int xhalf = a.IT * a.RS * 256, dhalf = a.IT * a.KP * 128;          // bytes of one half (multiples of 4096 / 2048: whole DMA passes)
+  const int xpasses = xhalf >> 10, dpasses = dhalf >> 10;                   // 1 KB = one DMA instruction of a wave
+  // plan entry: (image inside the half) * HW * C + element offset inside the image, or -1 = zero
+  int xpl[C3X_XPL], dpl[C3X_DPL];
+#pragma unroll
+  for (int k = 0; k < C3X_XPL; ++k) {
+    const int P = wave + 8 * k, S = P * 64 + lane;
     const int R = S >> 4, c = (S & 15) ^ (4 * (R & 3)), im = R / a.RS, row = R - im * a.RS;
     const int py = (row - 1) / PW, px = (row - 1) - py * PW;
-    const bool in = im < a.IT && row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
-    xplan[S] = in ? (im << 24) | (((py - 1) * W + px) * C + cig * 128 + c * 8) : -1;
+    const bool in = P < xpasses && row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
+    xpl[k] = in ? (im << 24) | (((py - 1) * W + px) * C + cig * 128 + c * 8) : -1;
   }
-  for (int S = tid; S < C3X_KROWS * 8; S += 512) {
+#pragma unroll
+  for (int k = 0; k < C3X_DPL; ++k) {
+    const int P = wave + 8 * k, S = P * 64 + lane;
     const int R = S >> 3, c = (S & 7) ^ (4 * ((R >> 1) & 1)), im = R / a.KP, row = R - im * a.KP;
     const int oy = row / PW, ox = row - oy * PW;
-    dplan[S] = (im < a.IT && oy < H && ox < W) ? (im << 24) | ((oy * W + ox) * C + cog * 64 + c * 8) : -1;
+    dpl[k] = (P < dpasses && oy < H && ox < W) ? (im << 24) | ((oy * W + ox) * C + cog * 64 + c * 8) : -1;
   }
   const int cot = wave & 1, ciq = wave >> 1;
   const int g4 = lane >> 4, t = lane & 15;
-  int offa[2], offb[9][2];
+  unsigned ada0[2], adb0[9][2];                                            // fragment addresses of step 0 of half 0
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int krow = 8 * (g4 >> 1) + 4 * h + (t >> 2);
     const int cbA = cot * 32 + 16 * (g4 & 1), cbB = ciq * 32 + 16 * (g4 & 1);
-    offa[h] = krow * 128 + ((((cbA >> 3) + ((t & 3) >> 1)) ^ (4 * ((krow >> 1) & 1))) << 4) + (t & 1) * 8;
+    ada0[h] = ds0 + krow * 128 + ((((cbA >> 3) + ((t & 3) >> 1)) ^ (4 * ((krow >> 1) & 1))) << 4) + (t & 1) * 8;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       const int rowd = krow + (j / 3) * PW + (j % 3);
-      offb[j][h] = rowd * 256 + ((((cbB >> 3) + ((t & 3) >> 1)) ^ (4 * (rowd & 3))) << 4) + (t & 1) * 8;
+      adb0[j][h] = xs0 + rowd * 256 + ((((cbB >> 3) + ((t & 3) >> 1)) ^ (4 * (rowd & 3))) << 4) + (t & 1) * 8;
     }
   }
   c3_f32x16 acc[9];
@@ -399,44 +420,65 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const long long ngroups = ((long long)a.N + a.IT - 1) / a.IT;
-  const int wgs = gridDim.x / kinds;           // workgroups per kind (the launch rounds the grid to a multiple of `kinds`)
+  const long long nhalves = ((long long)a.N + a.IT - 1) / a.IT;            // halves of IT images in the whole tensor
+  const int wgs = gridDim.x / kinds;            // workgroups per kind (the launch rounds the grid to a multiple of `kinds`)
   const int nsteps = a.KP >> 4;
-  for (long long p = blockIdx.x / kinds; p < ngroups; p += wgs) {
-    __syncthreads();                         // the plan is complete / every wave is done with the previous images
-    const long long img0 = p * a.IT;
-#pragma unroll 1
-    for (int P = wave; P < C3X_ROWS * 16 / 64; P += 8) {
-      const int e = xplan[P * 64 + lane];
-      const long long img = img0 + (e >> 24);
+  const int xjump = a.RS * 256 - (nsteps - 1) * 4096, djump = a.KP * 128 - (nsteps - 1) * 2048;      // last step of an image -> first step of the next one
+  // this workgroup's halves: q = blockIdx.x / kinds + k * wgs; the ring alternates between the two LDS halves
+  auto load_half = [&](long long q, int par) {
+    if (C3_ABL & 2) return;
+    const long long img0 = q * a.IT;
+#pragma unroll
+    for (int k = 0; k < C3X_XPL; ++k) {
+      if (wave + 8 * k >= xpasses) break;                                     // wave-uniform
+      const int e = xpl[k]; const long long img = img0 + (e >> 24);
       const void* src = (e >= 0 && img < a.N) ? (const void*)(a.x + img * HW * C + (e & 0xffffff)) : (const void*)c3_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + P * 1024), 16, 0, 0);
+      c3_glds16(src, xs0 + par * xhalf + (wave + 8 * k) * 1024);
     }
-#pragma unroll 1
-    for (int P = wave; P < C3X_KROWS * 8 / 64; P += 8) {
-      const int e = dplan[P * 64 + lane];
-      const long long img = img0 + (e >> 24);
+#pragma unroll
+    for (int k = 0; k < C3X_DPL; ++k) {
+      if (wave + 8 * k >= dpasses) break;
+      const int e = dpl[k]; const long long img = img0 + (e >> 24);
       const void* src = (e >= 0 && img < a.N) ? (const void*)(a.dy + img * HW * C + (e & 0xffffff)) : (const void*)c3_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + P * 1024), 16, 0, 0);
+      c3_glds16(src, ds0 + par * dhalf + (wave + 8 * k) * 1024);
     }
+  };
+  long long q = blockIdx.x / kinds;
+  int par = 0;
+  if (q < nhalves) load_half(q, 0);
+  for (; q < nhalves; q += wgs, par ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();                    // this half has landed for every wave / every wave is done with the other half
+    asm volatile("" ::: "memory");
+    if (q + wgs < nhalves) load_half(q + wgs, par ^ 1);
+    unsigned ada[2], adb[9][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { ada[h] = ada0[h] + par * dhalf;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) adb[j][h] = adb0[j][h] + par * xhalf; }
+    int s = 0;
 #pragma unroll 1
-    for (int im = 0; im < a.IT; ++im) {
-      const char* xb = Xs + im * a.RS * 256; const char* db = Ds + im * a.KP * 128;
-#pragma unroll 1
-      for (int s = 0; s < nsteps; ++s) {
-        const chunk16 fa = c3_tr_read8(db + offa[0] + s * 2048, db + offa[1] + s * 2048);
+    for (int u = a.IT * nsteps; u > 0; --u) {
+      c3_u32x2 ra[2], rb[9][2];
 #pragma unroll
-        for (int jb = 0; jb < 9; jb += 3) {          // three taps at a time: 12 fragment registers in flight instead of 36
-          chunk16 fb[3];
+      for (int h = 0; h < 2; ++h) ra[h] = (C3_ABL & 4) ? c3_u32x2{(unsigned)u, 1u} : c3_lds_tr(ada[h]);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) fb[j] = c3_tr_read8(xb + offb[jb + j][0] + s * 4096, xb + offb[jb + j][1] + s * 4096);
+      for (int j = 0; j < 9; ++j)
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
-            acc[jb + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[jb + j], 0, 0, 0);
-        }
-      }
+        for (int h = 0; h < 2; ++h) rb[j][h] = (C3_ABL & 4) ? c3_u32x2{(unsigned)u, 2u} : c3_lds_tr(adb[j][h]);
+      const bool wrap = ++s == nsteps; if (wrap) s = 0;
+      const int dx = wrap ? xjump : 4096, dd = wrap ? djump : 2048;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { ada[h] += dd;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) adb[j][h] += dx; }
+#define C3_STEP(j) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((j) == 0 ? 15 : 2 * (8 - (j))) : "memory"); if ((j) == 0) asm volatile("" : "+v"(ra[0]), "+v"(ra[1])); asm volatile("" : "+v"(rb[j][0]), "+v"(rb[j][1])); \
+        chunk16 fa, fb; fa.w[0] = ra[0].x; fa.w[1] = ra[0].y; fa.w[2] = ra[1].x; fa.w[3] = ra[1].y; fb.w[0] = rb[j][0].x; fb.w[1] = rb[j][0].y; fb.w[2] = rb[j][1].x; fb.w[3] = rb[j][1].y; \
+        if (C3_ABL & 1) asm volatile("" :: "v"(fa.w[0]), "v"(fa.w[1]), "v"(fa.w[2]), "v"(fa.w[3]), "v"(fb.w[0]), "v"(fb.w[1]), "v"(fb.w[2]), "v"(fb.w[3])); else \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb), acc[j], 0, 0, 0); } while (0)
+      C3_STEP(0); C3_STEP(1); C3_STEP(2); C3_STEP(3); C3_STEP(4); C3_STEP(5); C3_STEP(6); C3_STEP(7); C3_STEP(8);
+#undef C3_STEP
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -444,6 +486,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cog * 64 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cig * 128 + ciq * 32 + (lane & 31);
+      if (C3_ABL & 8) { if (acc[j][r] == 1234.5f) a.dw[(long long)co * 9 * C + j * C + ci] = acc[j][r]; } else
       atomicAdd(a.dw + (long long)co * 9 * C + j * C + ci, acc[j][r]);
     }
 }
@@ -451,8 +494,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
 static bool c3_wide_geometry(int H, int W, int C, int& KP, int& RS, int& IT) {
   const int PW = W + 1;
   KP = (H * PW + 15) / 16 * 16; RS = (KP + 2 * PW + 2 + 15) / 16 * 16;
-  if (C < 128 || C % 128 || C > 1024 || H < 1 || W < 2 || KP > C3X_KROWS || RS > C3X_ROWS || (H + 2) * PW + 1 > RS || H * W * C >= (1 << 24)) return false;
-  IT = C3X_ROWS / RS; if (C3X_KROWS / KP < IT) IT = C3X_KROWS / KP;
+  if (C < 128 || C % 128 || C > 1024 || H < 1 || W < 2 || 2 * KP > C3X_KROWS || 2 * RS > C3X_ROWS || (H + 2) * PW + 1 > RS || H * W * C >= (1 << 24)) return false;
+  IT = C3X_ROWS / 2 / RS; if (C3X_KROWS / 2 / KP < IT) IT = C3X_KROWS / 2 / KP;            // images per half of the LDS ring
   if (IT > 64) IT = 64;
   return IT >= 1;
 }
@@ -467,7 +510,7 @@ extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long
   C3WWArgs a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W; a.C = C;
   AVEC_CHECK_ARG(c3_wide_geometry(H, W, C, a.KP, a.RS, a.IT), "wgrad3x3_c128: %d channels, %dx%d images do not fit the slabs", C, H, W);
   static bool attr_set = false;
-  const size_t lds = (size_t)C3X_ROWS * 256 + C3X_KROWS * 128 + (C3X_ROWS * 16 + C3X_KROWS * 8) * 4;
+  const size_t lds = (size_t)C3X_ROWS * 256 + C3X_KROWS * 128;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { avec_set_error("wgrad3x3_c128: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
