@@ -373,12 +373,13 @@ struct C3WWArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W, C, KP, 
 // the first version loaded, waited, computed); (2) the DMA plan -- which image / element each 16-byte LDS slot receives -- is the same for every half and
 // lives in nine registers per lane instead of 32 KB of LDS read back before every DMA; (3) a step's 20 transposed reads go out together and the nine MFMAs
 // follow a counted wait ladder (before: every tap's reads sat next to their MFMA behind lgkmcnt(0), ~45 address additions per step).
-__global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
+// bid / nwg: this workgroup's index among the nwg workgroups that share the product (a launch of its own: blockIdx.x / gridDim.x)
+__device__ __forceinline__ void c3ww_body(const C3WWArgs& a, const int bid, const int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem; char* Ds = smem + C3X_ROWS * 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W, C = a.C, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
-  const int nci = C >> 7, kinds = (C >> 6) * nci, kind = blockIdx.x % kinds, cog = kind / nci, cig = kind - cog * nci;
+  const int nci = C >> 7, kinds = (C >> 6) * nci, kind = bid % kinds, cog = kind / nci, cig = kind - cog * nci;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const unsigned xs0 = (unsigned)(uintptr_t)(lptr_t)Xs, ds0 = (unsigned)(uintptr_t)(lptr_t)Ds;
   const int xhalf = a.IT * a.RS * 256, dhalf = a.IT * a.KP * 128;          // bytes of one half (multiples of 4096 / 2048: whole DMA passes)
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const long long nhalves = ((long long)a.N + a.IT - 1) / a.IT;            // halves of IT images in the whole tensor
-  const int wgs = gridDim.x / kinds;            // workgroups per kind (the launch rounds the grid to a multiple of `kinds`)
+  const int wgs = nwg / kinds;                  // workgroups per kind (the launch rounds the count to a multiple of `kinds`)
   const int nsteps = a.KP >> 4;
   const int xjump = a.RS * 256 - (nsteps - 1) * 4096, djump = a.KP * 128 - (nsteps - 1) * 2048;      // last step of an image -> first step of the next one
   // this workgroup's halves: q = blockIdx.x / kinds + k * wgs; the ring alternates between the two LDS halves
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
       c3_glds16(src, ds0 + par * dhalf + (wave + 8 * k) * 1024);
     }
   };
-  long long q = blockIdx.x / kinds;
+  long long q = bid / kinds;
   int par = 0;
   if (q < nhalves) load_half(q, 0);
   for (; q < nhalves; q += wgs, par ^= 1) {
@@ -491,6 +492,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) {
     }
 }
 
+__global__ __launch_bounds__(512) void wgrad3x3_wide_kernel(C3WWArgs a) { c3ww_body(a, (int)blockIdx.x, (int)gridDim.x); }
+// several layers' weight gradients as ONE grid (the final fp32 atomics are ~30 % of a launch of its own: 256 workgroups x 73 728 sums whatever the layer; grouped,
+// the 256 workgroups are shared out by work and the atomics are paid once for all the layers)
+struct C3WWGroup { C3WWArgs it[AVEC_WGRAD_GROUP_MAX]; int first[AVEC_WGRAD_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(512) void wgrad3x3_wide_grouped_kernel(C3WWGroup grp) {
+  int i = 0;
+  while (i + 1 < grp.n && (int)blockIdx.x >= grp.first[i + 1]) ++i;
+  c3ww_body(grp.it[i], (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i]);
+}
+
 static bool c3_wide_geometry(int H, int W, int C, int& KP, int& RS, int& IT) {
   const int PW = W + 1;
   KP = (H * PW + 15) / 16 * 16; RS = (KP + 2 * PW + 2 + 15) / 16 * 16;
@@ -521,6 +532,48 @@ extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long
   long long per_kind = 256 / kinds; if (per_kind < 1) per_kind = 1; if (per_kind > groups) per_kind = groups;
   avec_note_kernel("wgrad3x3_wide_kernel");
   hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3((unsigned)(per_kind * kinds)), dim3(512), lds, st, a);
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int avec_wgrad3x3_c128_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t st) {
+  AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_WGRAD_GROUP_MAX, "wgrad3x3_c128_grouped: 1..%d items", AVEC_WGRAD_GROUP_MAX);
+  C3WWGroup g; g.n = n;
+  long long cost[AVEC_WGRAD_GROUP_MAX]; int kinds[AVEC_WGRAD_GROUP_MAX], nwg[AVEC_WGRAD_GROUP_MAX], total = 0;
+  for (int i = 0; i < n; ++i) {
+    const avec_wgrad3x3_item_t& t = items[i];
+    AVEC_CHECK_ARG(t.x && t.dy && t.dw && t.images > 0, "wgrad3x3_c128_grouped: null buffer in item %d", i);
+    C3WWArgs& a = g.it[i]; a.x = (const bf16*)t.x; a.dy = (const bf16*)t.dy; a.dw = t.dw; a.N = (int)t.images; a.H = t.H; a.W = t.W; a.C = t.C;
+    AVEC_CHECK_ARG(c3_wide_geometry(t.H, t.W, t.C, a.KP, a.RS, a.IT), "wgrad3x3_c128_grouped: item %d: %d channels, %dx%d images do not fit the slabs", i, t.C, t.H, t.W);
+    kinds[i] = (t.C / 64) * (t.C / 128);
+    const long long halves = (t.images + a.IT - 1) / a.IT;
+    cost[i] = halves * (long long)(a.IT * (a.KP >> 4) + 2);              // steps of one kind's reduction (+ the per-half barrier / DMA issue)
+    nwg[i] = kinds[i]; total += kinds[i];
+  }
+  AVEC_CHECK_ARG(total <= 4096, "wgrad3x3_c128_grouped: too many tiles");
+  // one workgroup per CU (the slabs fill the LDS): hand the remaining workgroups to the item with the longest per-workgroup reduction, a whole set of kinds at a time
+  const int budget = 256;
+  for (;;) {
+    int best = -1; double worst = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const long long halves = (g.it[i].N + g.it[i].IT - 1) / g.it[i].IT;
+      if (total + kinds[i] > budget || nwg[i] / kinds[i] >= halves) continue;
+      const double load = (double)cost[i] / (double)(nwg[i] / kinds[i]);
+      if (load > worst) { worst = load; best = i; }
+    }
+    if (best < 0) break;
+    nwg[best] += kinds[best]; total += kinds[best];
+  }
+  g.first[0] = 0; for (int i = 0; i < n; ++i) g.first[i + 1] = g.first[i] + nwg[i];
+  static bool attr_set = false;
+  const size_t lds = (size_t)C3X_ROWS * 256 + C3X_KROWS * 128;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_wide_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { avec_set_error("wgrad3x3_c128_grouped: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  avec_note_kernel("wgrad3x3_wide_grouped_kernel");
+  hipLaunchKernelGGL(wgrad3x3_wide_grouped_kernel, dim3((unsigned)total), dim3(512), lds, st, g);
   AVEC_LAUNCH_CHECK();
   return 0;
 }

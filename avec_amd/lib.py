@@ -65,7 +65,13 @@ class Fp8Item(ctypes.Structure):
                 ("reserved", ctypes.c_int)]
 
 
-TN_GROUP_MAX, LN_GROUP_MAX = 32, 40
+class WgradItem(ctypes.Structure):
+    """avec_wgrad3x3_item_t"""
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("images", ctypes.c_longlong), ("C", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+TN_GROUP_MAX, LN_GROUP_MAX, WGRAD_GROUP_MAX = 32, 40, 16
 
 
 def _ctype(decl):

@@ -10,7 +10,8 @@ import torch
 
 from . import fp8
 from . import runtime as rt
-from .lib import ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnItem, lib
+from .lib import (ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, WGRAD_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnItem,
+                  WgradItem, lib)
 
 _byref = ctypes.byref
 
@@ -224,10 +225,11 @@ _DEFER = {"queues": {}, "task": -1}
 
 
 class _PendingGrads:
-    __slots__ = ("stream", "tn", "ln", "keep", "flops")
+    __slots__ = ("stream", "tn", "ln", "keep", "flops", "cw", "cw_flops")
 
     def __init__(self, stream):
         self.stream, self.tn, self.ln, self.keep, self.flops = stream, [], [], [], 0.0
+        self.cw, self.cw_flops = [], 0.0           # 3x3 weight gradients of the wide ResNet layers (avec_wgrad3x3_c128_grouped)
 
 
 def _in_backward():
@@ -243,7 +245,7 @@ def _pending():
     if _DEFER["task"] != task:                    # first queued item of this backward pass: flush whatever is left when the pass ends
         if _DEFER["task"] != -1:                  # the previous pass never reached its end-of-pass callback (it raised midway): its queued products
             for old in _DEFER["queues"].values():  # belong to another batch and must not be added to this step's gradients
-                old.tn, old.ln, old.keep, old.flops = [], [], [], 0.0
+                old.tn, old.ln, old.keep, old.flops, old.cw, old.cw_flops = [], [], [], 0.0, [], 0.0
         _DEFER["task"] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end)
     return q
@@ -268,7 +270,15 @@ def _launch_pending(q, part=None):
             chunk = q.ln[i:i + LN_GROUP_MAX]
             lib.layernorm_param_grads_grouped(rt.dt(), (LnItem * len(chunk))(*chunk), len(chunk), rt.stream())
         q.ln = []
-    if not q.tn and not q.ln:
+    if q.cw and part in (None, "cw"):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+        for i in range(0, len(q.cw), WGRAD_GROUP_MAX):
+            chunk = q.cw[i:i + WGRAD_GROUP_MAX]
+            lib.wgrad3x3_c128_grouped((WgradItem * len(chunk))(*chunk), len(chunk), rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 2), q.cw_flops)
+        q.cw, q.cw_flops = [], 0.0
+    if not q.tn and not q.ln and not q.cw:
         q.keep = []
 
 
@@ -1219,6 +1229,7 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
 
 SLAB_CONV = os.environ.get("AVEC_NO_SLAB_CONV") is None
 SLAB_WGRAD128 = os.environ.get("AVEC_NO_SLAB_WGRAD128") is None
+GROUP_WGRAD128 = os.environ.get("AVEC_GROUP_WGRAD128", "1") != "0"          # the wide layers' weight gradients as one grouped launch at the end of the backward pass
 
 
 def _slab_conv(H, W, Cin, Cout, KH, KW, stride):
@@ -1252,10 +1263,19 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     elif SLAB_CONV and SLAB_WGRAD128 and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_wgrad3x3_c128_supported")(H, W, Cin, Cout, KH, KW, stride)):
-        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-        lib.wgrad3x3_c128(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, Cin, H, W, rt.stream())
-        if ev is not None:
-            KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
+        if GROUP_WGRAD128 and _in_backward():
+            # queued: one grouped launch for all the wide layers when the backward pass is through (the final atomics of a launch of its own are ~30 % of it)
+            it = WgradItem()
+            it.x, it.dy, it.dw, it.images, it.C, it.H, it.W = x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, Cin, H, W
+            q = _pending()
+            q.cw.append(it)
+            q.keep += [x, dy]
+            q.cw_flops += 2.0 * M * Cout * KH * KW * Cin
+        else:
+            ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+            lib.wgrad3x3_c128(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, Cin, H, W, rt.stream())
+            if ev is not None:
+                KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     else:
         gemm_tn(dy, x, grad_of(weight), M, Cout, KH * KW * Cin, q_rows=rows_conv(H, W, Cin, KH, KW, stride, pad, OH, OW), q_mode=ROWS_CONV_FWD, side=True)
     if not need_dx:

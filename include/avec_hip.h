@@ -324,6 +324,12 @@ int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long long images
  * dw fp32 [C][9][C] (row stride 9C) += ...; supported when the per-image slabs fit (H (W+1) <= 288 rows of reduction, see csrc/conv3x3.hip) */
 int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride);
 int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int C, int H, int W, hipStream_t stream);
+/* the same for up to AVEC_WGRAD_GROUP_MAX layers in ONE launch: the 256 workgroups are shared out by work, and the final fp32 atomics (256 x 73 728 sums per launch,
+ * ~30 % of a single layer's launch) are paid once for all of them.  A binding queues (x, dy, dw) of the 3x3 stride-1 layers during the backward pass (the operands must stay
+ * alive and unmodified) and submits them when the ResNet's backward is through. */
+#define AVEC_WGRAD_GROUP_MAX 16
+typedef struct { const void* x; const void* dy; float* dw; long long images; int C, H, W, reserved; } avec_wgrad3x3_item_t;
+int avec_wgrad3x3_c128_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t stream);
 
 /* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
 /* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,
