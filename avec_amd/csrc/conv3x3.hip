@@ -266,10 +266,11 @@ __device__ __forceinline__ c3_u32x2 c3_lds_tr(unsigned lds_addr) { c3_u32x2 v; a
 
 struct C3WArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W; };
 
-__global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
+// bid / nwg: this workgroup's index among the nwg workgroups that share the product
+__device__ __forceinline__ void c3w_body(const C3WArgs& a, const int bid, const int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem; char* Ds = smem + C3_SBYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -311,33 +312,43 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  for (long long n = blockIdx.x; n < a.N; n += gridDim.x) {
+  const unsigned xs0 = (unsigned)(uintptr_t)(lptr_t)Xs, ds0 = (unsigned)(uintptr_t)(lptr_t)Ds;
+  for (long long n = bid; n < a.N; n += nwg) {
     __syncthreads();                         // every wave is done with the previous image
     const bf16* xi = a.x + n * HW * 64; const bf16* di = a.dy + n * HW * 64;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const void* src = xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 9; ++i) c3_glds16(xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16, xs0 + (wave + 8 * i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const void* src = doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ds + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 8; ++i) c3_glds16(doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16, ds0 + (wave + 8 * i) * 1024);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll 2
-    for (int s = 0; s < C3W_KROWS / 16; ++s) {
-      const int so = s * 2048;
-      const chunk16 fa = c3_tr_read8(Ds + offa[0] + so, Ds + offa[1] + so);
-      chunk16 fb[5];
+    // a step's 10 / 12 transposed reads go out together; the MFMAs follow a counted wait ladder (see wgrad3x3_wide_kernel)
+    unsigned ada[2], adb[5][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = c3_tr_read8(Xs + offb[j][0] + so, Xs + offb[j][1] + so);
-      if (five) fb[4] = c3_tr_read8(Xs + offb[4][0] + so, Xs + offb[4][1] + so);
+    for (int h = 0; h < 2; ++h) { ada[h] = ds0 + offa[h];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) adb[j][h] = xs0 + offb[j][h]; }
+#pragma unroll 1
+    for (int s = 0; s < C3W_KROWS / 16; ++s) {
+      c3_u32x2 ra[2], rb[5][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ra[h] = c3_lds_tr(ada[h]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[j], 0, 0, 0);
-      if (five) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[4]), acc[4], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rb[j][h] = c3_lds_tr(adb[j][h]);
+      if (five) { rb[4][0] = c3_lds_tr(adb[4][0]); rb[4][1] = c3_lds_tr(adb[4][1]); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { ada[h] += 2048;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) adb[j][h] += 2048; }
+#define C3_STEP(j, CNT) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory"); if ((j) == 0) asm volatile("" : "+v"(ra[0]), "+v"(ra[1])); asm volatile("" : "+v"(rb[j][0]), "+v"(rb[j][1])); \
+        chunk16 fa, fb; fa.w[0] = ra[0].x; fa.w[1] = ra[0].y; fa.w[2] = ra[1].x; fa.w[3] = ra[1].y; fb.w[0] = rb[j][0].x; fb.w[1] = rb[j][0].y; fb.w[2] = rb[j][1].x; fb.w[3] = rb[j][1].y; \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb), acc[j], 0, 0, 0); } while (0)
+      if (five) { C3_STEP(0, 8); C3_STEP(1, 6); C3_STEP(2, 4); C3_STEP(3, 2); C3_STEP(4, 0); }
+      else { C3_STEP(0, 6); C3_STEP(1, 4); C3_STEP(2, 2); C3_STEP(3, 0); }
+#undef C3_STEP
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -350,6 +361,14 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) {
       atomicAdd(a.dw + (long long)co * 576 + tap * 64 + ci, acc[j][r]);
     }
   }
+}
+__global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) { c3w_body(a, (int)blockIdx.x, (int)gridDim.x); }
+// several 64-channel layers' weight gradients as ONE grid: the workgroups are shared out evenly, the final atomics (256 x 36 864 sums per launch) are paid once
+struct C3WGroup { C3WArgs it[AVEC_WGRAD_GROUP_MAX]; int first[AVEC_WGRAD_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(512) void wgrad3x3_c64_grouped_kernel(C3WGroup grp) {
+  int i = 0;
+  while (i + 1 < grp.n && (int)blockIdx.x >= grp.first[i + 1]) ++i;
+  c3w_body(grp.it[i], (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,6 +551,37 @@ extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long
   long long per_kind = 256 / kinds; if (per_kind < 1) per_kind = 1; if (per_kind > groups) per_kind = groups;
   avec_note_kernel("wgrad3x3_wide_kernel");
   hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3((unsigned)(per_kind * kinds)), dim3(512), lds, st, a);
+  AVEC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int avec_wgrad3x3_c64_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t st) {
+  AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_WGRAD_GROUP_MAX, "wgrad3x3_c64_grouped: 1..%d items", AVEC_WGRAD_GROUP_MAX);
+  C3WGroup g; g.n = n;
+  long long total_images = 0;
+  for (int i = 0; i < n; ++i) {
+    const avec_wgrad3x3_item_t& t = items[i];
+    AVEC_CHECK_ARG(t.x && t.dy && t.dw && t.images > 0 && t.C == 64, "wgrad3x3_c64_grouped: bad item %d", i);
+    AVEC_CHECK_ARG(avec_conv3x3_c64_supported(t.H, t.W, 64, 64, 3, 3, 1) && t.H * (t.W + 1) <= C3W_KROWS, "wgrad3x3_c64_grouped: item %d: %dx%d images do not fit the slab", i, t.H, t.W);
+    C3WArgs& a = g.it[i]; a.x = (const bf16*)t.x; a.dy = (const bf16*)t.dy; a.dw = t.dw; a.N = (int)t.images; a.H = t.H; a.W = t.W;
+    total_images += t.images;
+  }
+  // one workgroup per CU (the two slabs fill the LDS): 256 workgroups shared out by image count, at least one per item
+  int used = 0; g.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    long long w = (256 * items[i].images + total_images / 2) / total_images; if (w < 1) w = 1; if (w > items[i].images) w = items[i].images;
+    if (used + w > 256 + n) w = 1;
+    used += (int)w; g.first[i + 1] = used;
+  }
+  static bool attr_set = false;
+  const size_t lds = C3_SBYTES + C3W_DBYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c64_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { avec_set_error("wgrad3x3_c64_grouped: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  avec_note_kernel("wgrad3x3_c64_grouped_kernel");
+  hipLaunchKernelGGL(wgrad3x3_c64_grouped_kernel, dim3((unsigned)used), dim3(512), lds, st, g);
   AVEC_LAUNCH_CHECK();
   return 0;
 }

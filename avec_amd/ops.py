@@ -225,11 +225,12 @@ _DEFER = {"queues": {}, "task": -1}
 
 
 class _PendingGrads:
-    __slots__ = ("stream", "tn", "ln", "keep", "flops", "cw", "cw_flops")
+    __slots__ = ("stream", "tn", "ln", "keep", "flops", "cw", "cw_flops", "cw64", "cw64_flops")
 
     def __init__(self, stream):
         self.stream, self.tn, self.ln, self.keep, self.flops = stream, [], [], [], 0.0
         self.cw, self.cw_flops = [], 0.0           # 3x3 weight gradients of the wide ResNet layers (avec_wgrad3x3_c128_grouped)
+        self.cw64, self.cw64_flops = [], 0.0       # ... of the 64-channel layers (avec_wgrad3x3_c64_grouped)
 
 
 def _in_backward():
@@ -245,7 +246,7 @@ def _pending():
     if _DEFER["task"] != task:                    # first queued item of this backward pass: flush whatever is left when the pass ends
         if _DEFER["task"] != -1:                  # the previous pass never reached its end-of-pass callback (it raised midway): its queued products
             for old in _DEFER["queues"].values():  # belong to another batch and must not be added to this step's gradients
-                old.tn, old.ln, old.keep, old.flops, old.cw, old.cw_flops = [], [], [], 0.0, [], 0.0
+                old.tn, old.ln, old.keep, old.flops, old.cw, old.cw_flops, old.cw64, old.cw64_flops = [], [], [], 0.0, [], 0.0, [], 0.0
         _DEFER["task"] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end)
     return q
@@ -278,7 +279,15 @@ def _launch_pending(q, part=None):
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 2), q.cw_flops)
         q.cw, q.cw_flops = [], 0.0
-    if not q.tn and not q.ln and not q.cw:
+    if q.cw64 and part in (None, "cw"):
+        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+        for i in range(0, len(q.cw64), WGRAD_GROUP_MAX):
+            chunk = q.cw64[i:i + WGRAD_GROUP_MAX]
+            lib.wgrad3x3_c64_grouped((WgradItem * len(chunk))(*chunk), len(chunk), rt.stream())
+        if ev is not None:
+            KERNEL_TIMER.stop(ev, (2, 2), q.cw64_flops)
+        q.cw64, q.cw64_flops = [], 0.0
+    if not q.tn and not q.ln and not q.cw and not q.cw64:
         q.keep = []
 
 
@@ -1258,10 +1267,18 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     M = N * OH * OW
     sh = rt.shadow(weight)
     if _slab_conv(H, W, Cin, Cout, KH, KW, stride) and H * (W + 1) <= 512:
-        ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-        lib.wgrad3x3_c64(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
-        if ev is not None:
-            KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
+        if GROUP_WGRAD128 and _in_backward():
+            it = WgradItem()
+            it.x, it.dy, it.dw, it.images, it.C, it.H, it.W = x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, Cin, H, W
+            q = _pending()
+            q.cw64.append(it)
+            q.keep += [x, dy]
+            q.cw64_flops += 2.0 * M * Cout * KH * KW * Cin
+        else:
+            ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+            lib.wgrad3x3_c64(x.data_ptr(), dy.data_ptr(), grad_of(weight).data_ptr(), N, H, W, rt.stream())
+            if ev is not None:
+                KERNEL_TIMER.stop(ev, (2, 2), 2.0 * M * Cout * KH * KW * Cin)
     elif SLAB_CONV and SLAB_WGRAD128 and rt.act_dtype() == torch.bfloat16 and bool(lib.raw("avec_wgrad3x3_c128_supported")(H, W, Cin, Cout, KH, KW, stride)):
         if GROUP_WGRAD128 and _in_backward():
             # queued: one grouped launch for all the wide layers when the backward pass is through (the final atomics of a launch of its own are ~30 % of it)

@@ -330,6 +330,7 @@ int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long image
 #define AVEC_WGRAD_GROUP_MAX 16
 typedef struct { const void* x; const void* dy; float* dw; long long images; int C, H, W, reserved; } avec_wgrad3x3_item_t;
 int avec_wgrad3x3_c128_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t stream);
+int avec_wgrad3x3_c64_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t stream);      /* the 64-channel layers (C = 64 in every item) */
 
 /* ---- video input pipeline (avec_amd/csrc/video_input.hip) ------------------ */
 /* Replaces, for a whole batch, the per-sample dataloader work of LRS.__getitem__ (nnet/datasets.py:187-196,348-356): uint8 -> float / 255, Grayscale,
