@@ -137,6 +137,7 @@ struct Epi {
   float* colsum;                   // += column sums of v (bias gradient)
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
   const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;      // BatchNorm-backward fusion (avec_hip.h): v = alpha*acc + res; mask; stats += (v, v*y)
+  int res_cls0;                    // parity-class order: `res` has one row per class-0 pixel (class-local index), none for the other classes
 };
 
 struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
@@ -234,6 +235,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
 #pragma unroll 1
     for (int lr = tid / TPR; lr < 64; lr += 256 / TPR) {
       long long row = m0 + pass * 64 + lr;
+      const long long rrow_cls = row;           // class-local row (res_cls0)
       if (g.perm2) {                            // m0 is class-local here: map to the pixel's row of the output
         if (row >= perm2_count(g.a, perm_cls, g.pImgs) || col >= g.N) continue;
         long long img; int ih, iw; perm2_pixel(g.a, perm_cls, row, img, ih, iw);
@@ -247,9 +249,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
         // (sum d, sum d*y) per column and store the masked gradient
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = (v[c] + bias4[c]) * e.alpha;
-        if (e.res) {
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) {
+          const long long rrow = e.res_cls0 ? rrow_cls : row;
           float r4[4];
-          if (e.res_act) ld4<T>((const T*)e.res + row * e.ldres + col, r4); else ld4<float>((const float*)e.res + row * e.ldres + col, r4);
+          if (e.res_act) ld4<T>((const T*)e.res + rrow * e.ldres + col, r4); else ld4<float>((const float*)e.res + rrow * e.ldres + col, r4);
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += r4[c];
         }
@@ -280,9 +283,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * v[c]; v[c] *= e.alpha; }
-        if (e.res) {
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) {
+          const long long rrow = e.res_cls0 ? rrow_cls : row;
           float r4[4];
-          if (e.res_act) ld4<T>((const T*)e.res + row * e.ldres + col, r4); else ld4<float>((const float*)e.res + row * e.ldres + col, r4);
+          if (e.res_act) ld4<T>((const T*)e.res + rrow * e.ldres + col, r4); else ld4<float>((const float*)e.res + rrow * e.ldres + col, r4);
           for (int c = 0; c < 4; ++c) v[c] += r4[c];
         }
 #if AVEC_ABL
@@ -304,7 +308,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
         }
         csum[c] += x; csq[c] += x * x;
         x *= e.alpha;
-        if (e.res) x += e.res_act ? ldf((const T*)e.res + row * e.ldres + col + c) : ((const float*)e.res)[row * e.ldres + col + c];
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) { const long long rrow = e.res_cls0 ? rrow_cls : row; x += e.res_act ? ldf((const T*)e.res + rrow * e.ldres + col + c) : ((const float*)e.res)[rrow * e.ldres + col + c]; }
         v[c] = x;
       }
       if (e.out_f32) { float* o = (float*)e.out + row * e.ldo + col; for (int c = 0; c < 4; ++c) if (col + c < g.N) o[c] = v[c]; }
@@ -1428,7 +1432,10 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   if (g.perm2 && mode == MODE_CONV_BWD && g.fast_conv && a16 && !f32src && use_glds_) {     // parity-class order: only the fast LDS-DMA kernel knows it
     g.pTs[0] = 0; for (int c = 0; c < 4; ++c) g.pTs[c + 1] = g.pTs[c] + (int)((perm2_count(g.a, c, g.pImgs) + BM - 1) / BM);
     grid.x = (unsigned)g.pTs[4];
-  } else g.perm2 = 0;
+  } else {
+    if (g.e.res_cls0) { avec_set_error("gemm_nt: res_cls0: this launch cannot run in parity-class order (alignment)"); return -1; }
+    g.perm2 = 0;
+  }
   constexpr int STG = (BM + BN) <= 128 ? 4 : 2;      // ring depth: deep for the small latency-bound tiles; the big tiles keep 3 workgroups per CU instead (measured)
   static const bool rb_env_set = getenv("AVEC_NT_RB") != nullptr;
   static const int rb_env = rb_env_set ? atoi(getenv("AVEC_NT_RB")) : 128;
@@ -1573,7 +1580,8 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
   e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
-  e.bnb_y = ep->bnb_y; e.ldby = ep->ldby; e.bnb_ss = ep->bnb_ss; e.bnb_mask = ep->bnb_mask;
+  e.bnb_y = ep->bnb_y; e.ldby = ep->ldby; e.bnb_ss = ep->bnb_ss; e.bnb_mask = ep->bnb_mask; e.res_cls0 = ep->res_cls0;
+  AVEC_CHECK_ARG(!e.res_cls0 || (g.perm2 && e.res), "gemm_nt: res_cls0 needs a bf16 stride-2 backward-data product that runs in parity-class order");
   AVEC_CHECK_ARG(!e.bnb_y || (e.stats && N % 4 == 0 && !(e.ldo & 3) && !(e.ldby & 3) && !(e.ldres & 3) && !(e.ldz & 3) && !(e.ldpre & 3) && (!e.bnb_mask || e.bnb_ss) && (e.bnb_mask || e.dact == 2 || e.dact == 0)),
                  "gemm_nt: the BatchNorm-backward fusion needs stats, N %% 4 == 0 and row strides that are multiples of 4");
   AVEC_CHECK_ARG(!(e.drop_p > 0.f) || e.rng, "gemm_nt: dropout without rng state");

@@ -30,7 +30,8 @@ class Epilogue(ctypes.Structure):
                 ("res", ctypes.c_void_p), ("ldres", ctypes.c_longlong), ("alpha", ctypes.c_float), ("res_act", ctypes.c_int),
                 ("dact_z", ctypes.c_void_p), ("ldz", ctypes.c_longlong), ("dact", ctypes.c_int),
                 ("colsum", ctypes.c_void_p), ("stats", ctypes.c_void_p),
-                ("bnb_y", ctypes.c_void_p), ("ldby", ctypes.c_longlong), ("bnb_ss", ctypes.c_void_p), ("bnb_mask", ctypes.c_int)]
+                ("bnb_y", ctypes.c_void_p), ("ldby", ctypes.c_longlong), ("bnb_ss", ctypes.c_void_p), ("bnb_mask", ctypes.c_int),
+                ("res_cls0", ctypes.c_int)]
 
 
 class Attn(ctypes.Structure):

@@ -182,7 +182,7 @@ def gemm_nt_fp8(A, ent, out, M, N, K, *, bias=None, act=ACT_NONE, out_pre=None, 
 
 def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
             drop_p=0.0, sid=0, res=None, res_act=False, alpha=1.0, dact_z=None, dact=0, colsum=None, stats=None, out_f32=False,
-            ldo=None, ldres=None, dtype=None, flops=None, bnb=None):
+            ldo=None, ldres=None, dtype=None, flops=None, bnb=None, res_cls0=False):
     ep = Epilogue()
     ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
     if out_pre is not None:
@@ -192,7 +192,7 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     if drop_p > 0.0:
         ep.drop_p, ep.rng, ep.rng_stream = drop_p, rt.rng_state(out.device).data_ptr(), sid
     if res is not None:
-        ep.res, ep.ldres, ep.res_act = res.data_ptr(), (N if ldres is None else ldres), int(res_act)
+        ep.res, ep.ldres, ep.res_act, ep.res_cls0 = res.data_ptr(), (N if ldres is None else ldres), int(res_act), int(res_cls0)
     ep.alpha = alpha
     if dact_z is not None:
         ep.dact_z, ep.ldz, ep.dact = dact_z.data_ptr(), N, dact
@@ -1238,6 +1238,7 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
 
 SLAB_CONV = os.environ.get("AVEC_NO_SLAB_CONV") is None
 SLAB_WGRAD128 = os.environ.get("AVEC_NO_SLAB_WGRAD128") is None
+SHORTCUT_SUBGRID = os.environ.get("AVEC_SHORTCUT_SUBGRID", "1") != "0"        # ResNet projection shortcuts: input gradient on the subsampled grid (res_cls0)
 GROUP_WGRAD128 = os.environ.get("AVEC_GROUP_WGRAD128", "1") != "0"          # the wide layers' weight gradients as one grouped launch at the end of the backward pass
 
 
@@ -1261,7 +1262,8 @@ class BnbFuse:
 BNB_FUSE = os.environ.get("AVEC_BNB_FUSE", "0") == "1"
 
 
-def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None):
+def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None, dx_res_cls0=False):
+    """dx_res_cls0: dx_res holds rows for the (even row, even column) input pixels only (stride-2 layers, bf16: include/avec_hip.h res_cls0)"""
     Cout, KH, KW = weight.shape[0], weight.shape[2], weight.shape[3]
     pad = (KH - 1) // 2
     M = N * OH * OW
@@ -1308,7 +1310,7 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     # over input pixels are structurally zero and are skipped by the parity-class kernel: they are not counted
     fuse = bnb if (bnb is not None and BNB_FUSE and rt.act_dtype() == torch.bfloat16 and Cin % 4 == 0) else None
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
-            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, bnb=fuse)
+            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, bnb=fuse, res_cls0=dx_res_cls0)
     if fuse is not None:
         fuse.done = True
     return dx
@@ -1381,8 +1383,18 @@ class ResNetBlockFn(torch.autograd.Function):
         if has_proj:
             convr, bnr = blk.residual[0], blk.residual[1]
             dyr, _ = bn_backward(bnr, str_, cr, Mo, dres, yr, None, ACT_NONE, Mo)
-            dx = conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx)
-            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx, bnb=fx)
+            kr = convr.weight.shape[2]
+            if (SHORTCUT_SUBGRID and need_dx and stride == 2 and kr == 1 and rt.act_dtype() == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0
+                    and conv1.weight.shape[2] == 3 and not _slab_conv(H, W, Cin, Cout, 3, 3, stride)):
+                # the 1x1 / stride-2 shortcut sends its gradient to the (even, even) input pixels only: a plain product on the subsampled grid, added by the 3x3
+                # layer's backward-data epilogue to its class-0 tiles -- instead of a full-size, three-quarters-zero tensor written and read back
+                conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=False)
+                dxs = empty((Mo, Cin), rt.act_dtype(), dyr)
+                gemm_nt(dyr, rt.shadow(convr.weight).bwd, dxs, Mo, Cin, Cout)
+                dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=dxs, bnb=fx, dx_res_cls0=True)
+            else:
+                dx = conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx)
+                dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx, bnb=fx)
         else:
             dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres, bnb=fx)
         if fx is not None and fx.done:

@@ -74,6 +74,10 @@ typedef struct avec_epilogue {
    * activation `dact_z` (dact = 2: v where z > 0) or, with bnb_mask = 1, from the pre-activation itself (scale * y + shift > 0, bnb_ss = [scale | shift | ...]).
    * avec_bn_bwd_finalize turns the replicated (sum d, sum d*y) into (sum d, sum d*xhat); avec_bn_bwd_apply(act = 0) then needs d and y only. */
   const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;
+  /* backward-data of a stride-2 convolution (bf16, parity-class order): `res` holds one row per pixel of class (even row, even column) only -- the gradient that a
+   * 1x1 / stride-2 shortcut convolution sends to the same input (nnet/blocks.py: ResNetBlock.residual), computed as a plain product on the subsampled grid --
+   * instead of a full-size, three-quarters-zero tensor.  Rejected (< 0) when the launch cannot run in parity-class order. */
+  int res_cls0;
 } avec_epilogue_t;
 
 /* C[m][n] = epi(sum_k A[m][k] W[n][k]).  Replaces aten::addmm/mm of layers.Linear.forward (nnet/layers.py:64-76),
