@@ -164,3 +164,68 @@ def test_batched_tn_products_on_odd_head_offsets(B, H, T, d):
     assert rel_err(got, ref) < 1e-2
     assert out[:, :D].abs().max() == 0 and out[:, 2 * D:].abs().max() == 0          # nothing written outside the K third
     assert rel_err(acc.double().cpu().view(T, H, d), ref.sum(0)) < 1e-3
+
+
+def _wgrad_ref(x, dy, N, C, H, W):
+    xp = torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    cols = torch.nn.functional.unfold(xp, 3).view(N, C, 9, H * W).permute(0, 3, 2, 1).reshape(N * H * W, 9 * C)
+    return dy.float().t() @ cols
+
+
+def test_grouped_wgrad3x3_launches_match_fp32_math():
+    """avec_wgrad3x3_c128_grouped / avec_wgrad3x3_c64_grouped: several layers of different geometry in one launch (workgroups shared out by work, image counts that do
+    not fill the last half of the LDS ring) add the same sums to their fp32 gradients as plain fp32 math on the bf16 operands"""
+    import avec_amd
+    from avec_amd import runtime as rt
+    from avec_amd.lib import WgradItem, lib
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d = dev()
+        torch.manual_seed(4)
+        for fn, geos in ((lib.wgrad3x3_c128_grouped, [(301, 128, 11, 11), (37, 256, 6, 6), (160, 512, 3, 3), (5, 128, 5, 7), (1, 256, 6, 6)]),
+                         (lib.wgrad3x3_c64_grouped, [(300, 64, 22, 22), (3, 64, 6, 6), (7, 64, 20, 22)])):
+            ts, items = [], []
+            for N, C, H, W in geos:
+                x = torch.randn(N, H, W, C, device=d).to(torch.bfloat16)
+                dy = torch.randn(N * H * W, C, device=d).to(torch.bfloat16)
+                dw = torch.full((C, 9 * C), 0.5, device=d)
+                it = WgradItem()
+                it.x, it.dy, it.dw, it.images, it.C, it.H, it.W = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, C, H, W
+                ts.append((x, dy, dw, N, C, H, W)); items.append(it)
+            fn((WgradItem * len(items))(*items), len(items), rt.stream())
+            torch.cuda.synchronize()
+            for x, dy, dw, N, C, H, W in ts:
+                assert rel_err(dw - 0.5, _wgrad_ref(x, dy, N, C, H, W)) < 1e-3, (N, C, H, W)
+    finally:
+        avec_amd.set_compute_dtype("f32")
+
+
+def test_resnet_shortcut_gradient_on_subsampled_grid_matches_full_size_path():
+    """bf16 ResNet-18 trunk: input / parameter gradients with the projection shortcuts' input gradient computed on the subsampled grid and added by the 3x3 stride-2
+    backward-data epilogue (avec_epilogue_t.res_cls0), and with the weight gradients queued for the grouped launches, against the round-2 paths (full-size shortcut
+    gradient tensor, one weight-gradient launch per layer)"""
+    import avec_amd
+    import nnet
+    from avec_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(12, 22, 22, 64, generator=g).to(dev())
+    res = {}
+    try:
+        avec_amd.set_compute_dtype("bf16")
+        for new in (True, False):
+            torch.manual_seed(13)
+            net = nnet.ResNet(dim_input=64, dim_output=256, model="ResNet18", include_stem=False, include_head=True).to(dev()).train()
+            ops.SHORTCUT_SUBGRID, ops.GROUP_WGRAD128 = new, new
+            xin = x.to(torch.bfloat16).requires_grad_(True)
+            y = net.forward_nhwc(xin)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev())
+            (y.float() * w).sum().backward()
+            torch.cuda.synchronize()
+            res[new] = (xin.grad.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.SHORTCUT_SUBGRID, ops.GROUP_WGRAD128 = True, True
+        avec_amd.set_compute_dtype("f32")
+    assert rel_err(res[True][0], res[False][0]) < 1e-2, "input gradient"
+    assert len(res[True][1]) == len(res[False][1]) and len(res[True][1]) > 40
+    for n in res[True][1]:
+        assert rel_err(res[True][1][n], res[False][1][n]) < 1e-2, n
