@@ -286,7 +286,9 @@ class Model(Module):
             self.optimizer.prepare_step()
             graph.replay()
             finish()
-            return static_losses
+            if not dist_mode:
+                self.arena.mark_dirty()             # host-side view of what the replay's closing Adam launch left behind: whatever runs next OUTSIDE the graph
+            return static_losses                    # (evaluation, an eager step) must refresh the weight shadows first -- the captured refresh sits at the START of a replay
 
         if dist_mode:
             self.arena.arm_early_all_reduce(os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0")      # later eager train_steps keep their overlapped exchange
