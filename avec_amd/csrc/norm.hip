@@ -151,10 +151,13 @@ extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma,
 
 // dx only (dgamma / dbeta are produced later by avec_layernorm_param_grads_grouped): one wave per row, every row in flight at once -- no serial walk over
 // rows, no column reduction on the dependent chain of the backward pass.
+// Optional second output (avec_layernorm_bwd_prep): prep = act(palpha * dropmask * dx) -- what the module in front of this one would compute from dx with a
+// grad_prep launch of its own at the start of ITS backward (out = res + alpha * Dropout(.): nnet/blocks.py:292-301).
+struct LnPrep { void* out; float alpha, p; const unsigned long long* rng; unsigned stream; int f32; };
 template <typename TG, int NG>
 __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
-                                                          const float* __restrict__ dres, long long M, int D) {
+                                                          const float* __restrict__ dres, long long M, int D, LnPrep pr) {
   const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float mu = mean[row], rs = rstd[row];
@@ -182,6 +185,12 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[i][e] += rs * (d[i][e] * gg[i][e] - s1 - v[i][e] * s2);
     st4<float>(dx + row * D + c, o[i]);
+    if (pr.out) {
+      float q[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = o[i][e] * (pr.alpha * drop_scale(pr.rng, pr.stream, (unsigned long long)row * D + c + e, pr.p));
+      if (pr.f32) st4<float>((float*)pr.out + row * D + c, q); else st4<bf16>((bf16*)pr.out + row * D + c, q);
+    }
   }
 }
 
@@ -236,13 +245,14 @@ extern "C" int avec_layernorm_param_grads_grouped(int dtype, const avec_ln_item_
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
-extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                  float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
+static int layernorm_bwd_impl(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, const LnPrep& pr, hipStream_t st) {
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && (!dgamma == !dbeta), "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
+  AVEC_CHECK_ARG(!pr.out || (!dgamma && (pr.p <= 0.f || pr.rng)), "layernorm_bwd_prep: the second output comes with the dx-only kernel (dgamma == NULL); dropout needs rng");
   if (!dgamma) {        // input gradient only (parameter gradients deferred to avec_layernorm_param_grads_grouped)
     const dim3 grid((unsigned)((M + 3) / 4)); const bool f32in = dy_f32 || dtype == AVEC_F32;
-#define AVEC_LN_ROWS(TG, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<TG, NG>), grid, dim3(256), 0, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, M, D)
+#define AVEC_LN_ROWS(TG, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<TG, NG>), grid, dim3(256), 0, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, M, D, pr)
     if (D <= 512) { if (f32in) AVEC_LN_ROWS(float, 2); else AVEC_LN_ROWS(bf16, 2); }
     else { if (f32in) AVEC_LN_ROWS(float, 6); else AVEC_LN_ROWS(bf16, 6); }
 #undef AVEC_LN_ROWS
@@ -260,6 +270,18 @@ extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const f
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[2] = {dgamma, dbeta}; return col_finalize(ws, 1, (unsigned)nb, 2, D, dst, D, st); }
   return 0;
+}
+extern "C" int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t st) {
+  LnPrep pr; pr.out = nullptr; pr.alpha = 1.f; pr.p = 0.f; pr.rng = nullptr; pr.stream = 0; pr.f32 = 0;
+  return layernorm_bwd_impl(dtype, dy, dy_f32, x, mean, rstd, gamma, dx, dres, dgamma, dbeta, M, D, pr, st);
+}
+extern "C" int avec_layernorm_bwd_prep(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                       float* dx, const float* dres, void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream,
+                                       long long M, int D, hipStream_t st) {
+  AVEC_CHECK_ARG(prep, "layernorm_bwd_prep: null prep buffer");
+  LnPrep pr; pr.out = prep; pr.alpha = prep_alpha; pr.p = prep_drop_p; pr.rng = rng; pr.stream = rng_stream; pr.f32 = dtype == AVEC_F32;
+  return layernorm_bwd_impl(dtype, dy, dy_f32, x, mean, rstd, gamma, dx, dres, nullptr, nullptr, M, D, pr, st);
 }
 
 // =============================================================================================

@@ -345,12 +345,53 @@ def layernorm_fwd(x, w, b, M, D, out_f32, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, dy_f32, x, mean, rstd, w, b, M, D, dres=None):
+# ---- the first launch of a module's backward, folded into the last launch of the module behind it -----------------------------------------------------
+# Every residual module computes  out = x + alpha * Dropout(f(LN(x)))  and starts its backward with  dacc = act(alpha * dropmask * dy)  (avec_grad_prep: ~100
+# launches per step).  dy is the dx that the NEXT module's LayerNorm backward wrote a moment ago -- so that kernel writes dacc as a second output
+# (avec_layernorm_bwd_prep).  Forward: a module tags its output tensor with (alpha, drop_p, rng stream); the consumer module remembers the tag of its input.
+# Backward: the consumer's LayerNorm backward produces the prepared gradient and leaves it under dx's address; the producer module takes it if the address, the
+# backward pass, the shape and its own (alpha, drop_p, stream) all match, and launches grad_prep otherwise (gradient accumulated from several consumers, ...).
+PREP_FUSE = os.environ.get("AVEC_PREP_FUSE", "1") != "0"
+_PREP_READY = {"task": -1, "m": {}}
+
+
+def _tag_prep(out, alpha, drop_p, sid):
+    if PREP_FUSE:
+        out._avec_prep = (float(alpha), float(drop_p), int(sid))
+    return out
+
+
+def _prep_request(x):
+    return getattr(x, "_avec_prep", None) if PREP_FUSE else None
+
+
+def _take_prep(dy, M, N, alpha, drop_p, sid):
+    if _PREP_READY["task"] != torch._C._current_graph_task_id():
+        return None
+    r = _PREP_READY["m"].pop(dy.data_ptr(), None)
+    if r is not None and r[1:] == (M, N, float(alpha), float(drop_p), int(sid)) and r[0].dtype == rt.act_dtype():
+        return r[0]
+    return None
+
+
+def layernorm_bwd(dy, dy_f32, x, mean, rstd, w, b, M, D, dres=None, prep=None):
+    """prep = (alpha, drop_p, rng stream) of the module whose output this LayerNorm normalised: also produce its prepared gradient (see above)"""
     dx = empty((M, D), torch.float32, x)
     gw, gb = grad_of(w), grad_of(b)
     if D <= 1024 and D % 4 == 0 and _in_backward():          # (the dx-only kernel and the grouped launch use 4-wide accesses) dx now (one wave per row); d(gamma), d(beta) with the other queued parameter gradients
-        lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
-                          None, None, M, D, rt.stream())
+        if prep is not None:
+            task = torch._C._current_graph_task_id()
+            if _PREP_READY["task"] != task:
+                _PREP_READY["task"], _PREP_READY["m"] = task, {}
+            pt = empty((M, D), rt.act_dtype(), x)
+            alpha, drop_p, sid = prep
+            rng = rt.rng_state(x.device).data_ptr() if drop_p > 0 else None
+            lib.layernorm_bwd_prep(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
+                                   pt.data_ptr(), alpha, drop_p, rng, sid, M, D, rt.stream())
+            _PREP_READY["m"][dx.data_ptr()] = (pt, M, D, alpha, drop_p, sid)
+        else:
+            lib.layernorm_bwd(rt.dt(), dy.data_ptr(), int(dy_f32), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dres),
+                              None, None, M, D, rt.stream())
         it = LnItem()
         it.dy, it.x, it.mean, it.rstd, it.dgamma, it.dbeta = dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gw.data_ptr(), gb.data_ptr()
         it.M, it.D, it.dy_f32 = M, D, int(dy_f32)
@@ -461,13 +502,13 @@ class LayerNormFn(torch.autograd.Function):
         x2 = _f32c(x.reshape(-1, shp[-1]))
         M, D = x2.shape
         y, mean, rstd = layernorm_fwd(x2, w, b, M, D, True, eps)
-        ctx.saved = (x2, mean, rstd, w, b, M, D, shp)
+        ctx.saved = (x2, mean, rstd, w, b, M, D, shp, _prep_request(x))
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, mean, rstd, w, b, M, D, shp = ctx.saved
-        dx = layernorm_bwd(_f32c(dy.reshape(M, D)), True, x2, mean, rstd, w, b, M, D)
+        x2, mean, rstd, w, b, M, D, shp, req = ctx.saved
+        dx = layernorm_bwd(_f32c(dy.reshape(M, D)), True, x2, mean, rstd, w, b, M, D, prep=req)
         return dx.view(shp), None, None, None
 
 
@@ -570,7 +611,8 @@ class FeedForwardFn(torch.autograd.Function):
             h1 = linear_fwd(h0, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z, drop_p=drop_p, sid=sid1)
             y = linear_fwd(h1, w2, b2, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid2, res=x2, alpha=alpha)
         ctx.saved = (x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp, fused)
-        return y.view(shp)
+        ctx.prep_req = _prep_request(x)
+        return y.view(shp) if fused else _tag_prep(y.view(shp), alpha, drop_p, sid2)
 
     @staticmethod
     def backward(ctx, dy):
@@ -591,12 +633,14 @@ class FeedForwardFn(torch.autograd.Function):
             linear_bwd_weight(dz, h0, w1, M, bias=b1)
             defer_ln_param_grads(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D)
             return (dx.view(shp),) + (None,) * 11
-        dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2)
+        dacc = _take_prep(dy, M, D, alpha, drop_p, sid2)
+        if dacc is None:
+            dacc = grad_prep(dy, M, D, alpha=alpha, drop_p=drop_p, sid=sid2)
         linear_bwd_weight(dacc, h1, w2, M, bias=b2)
         dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1)
         linear_bwd_weight(dz, h0, w1, M, bias=b1)
         dh0 = linear_bwd_input(dz, w1, M, out_f32=False)
-        dx = layernorm_bwd(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy)
+        dx = layernorm_bwd(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy, prep=ctx.prep_req)
         return (dx.view(shp),) + (None,) * 11
 
 
@@ -688,7 +732,8 @@ class AttentionModuleFn(torch.autograd.Function):
             y = linear_fwd(o, wo, bo, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid, res=res, alpha=1.0)
         ctx.saved = (x2, mean, rstd, h, hp, qkv, pe, e, o, lse, lens, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wp, bp,
                      H, patch, drop_p, sid, residual, B, T, Tp, D)
-        return y.view(B, T, D)
+        ctx.prep_req = _prep_request(x)
+        return _tag_prep(y.view(B, T, D), 1.0, drop_p, sid) if patch == 1 else y.view(B, T, D)
 
     @staticmethod
     def backward(ctx, dy):
@@ -701,7 +746,9 @@ class AttentionModuleFn(torch.autograd.Function):
             rng = rt.rng_state(dy.device).data_ptr() if drop_p > 0 else None
             lib.patch_unpool_bwd(rt.dt(), dy.data_ptr(), doo.data_ptr(), drop_p, rng, sid, B, T, D, patch, rt.stream())
         else:
-            doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid)
+            doo = _take_prep(dy, M, D, 1.0, drop_p, sid)
+            if doo is None:
+                doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid)
         linear_bwd_weight(doo, o, wo, Mp, bias=bo)
         do = linear_bwd_input(doo, wo, Mp, out_f32=False)
         dqkv = empty((Mp, 3 * D), adt, dy)
@@ -751,7 +798,7 @@ class AttentionModuleFn(torch.autograd.Function):
         else:
             dh = dhp
         if ln_w is not None:
-            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy if residual else None)
+            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy if residual else None, prep=ctx.prep_req)
         else:
             dx = dy.clone() if residual else torch.zeros_like(dy)
             lib.to_f32_rows(rt.dt(), dh.data_ptr(), D, dx.data_ptr(), D, M, D, 1, rt.stream())
@@ -955,7 +1002,8 @@ class ConvModuleFn(torch.autograd.Function):
             R = x2
         y = linear_fwd(a, pw2.weight, pw2.bias, Mo, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid, res=R, alpha=1.0)
         ctx.saved = (x2, mean, rstd, h, u, c, a, st, cptr, use_batch, mod, res_conv, drop_p, sid, B, T, To, D, Dp, K, stride)
-        return y.view(B, To, Dp)
+        ctx.prep_req = _prep_request(x)
+        return _tag_prep(y.view(B, To, Dp), 1.0, drop_p, sid)
 
     @staticmethod
     def backward(ctx, dy):
@@ -963,7 +1011,9 @@ class ConvModuleFn(torch.autograd.Function):
         ln, pw1, dw, bn, pw2 = mod.layers[0], mod.layers[1], mod.layers[3], mod.layers[4], mod.layers[6]
         M, Mo, adt = B * T, B * To, rt.act_dtype()
         dy = _f32c(dy.reshape(Mo, Dp))
-        dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid)
+        dacc = _take_prep(dy, Mo, Dp, 1.0, drop_p, sid)
+        if dacc is None:
+            dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid)
         linear_bwd_weight(dacc, a, pw2.weight, Mo, bias=pw2.bias)
         da = linear_bwd_input(dacc, pw2.weight, Mo, out_f32=False)
         if use_batch:
@@ -976,7 +1026,7 @@ class ConvModuleFn(torch.autograd.Function):
         linear_bwd_weight(du, h, pw1.weight, M, bias=pw1.bias)
         dh = linear_bwd_input(du, pw1.weight, M, out_f32=False)
         if res_conv is None:
-            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D, dres=dy)
+            dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D, dres=dy, prep=ctx.prep_req)
         else:
             rs = res_conv.stride[0]
             dx = layernorm_bwd(dh, False, x2, mean, rstd, ln.weight, ln.bias, M, D)

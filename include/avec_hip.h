@@ -176,6 +176,11 @@ int avec_layernorm_fwd(int dtype, const float* x, const float* gamma, const floa
                        float* mean, float* rstd, long long M, int D, float eps, hipStream_t stream);
 int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, hipStream_t stream);
+/* dx-only LayerNorm backward with a second output  prep = act(prep_alpha * dropmask(rng, rng_stream, prep_drop_p) * dx):  the gradient the module IN FRONT of this
+ * LayerNorm needs at the start of its own backward (out = res + alpha * Dropout(acc + bias), nnet/blocks.py:292-301; otherwise an avec_grad_prep launch per module) */
+int avec_layernorm_bwd_prep(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, const float* dres, void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream,
+                            long long M, int D, hipStream_t stream);
 /* avec_layernorm_bwd with dgamma == dbeta == NULL computes dx only (one wave per row); the parameter gradients of up to AVEC_LN_GROUP_MAX such layers are
  * then produced by ONE launch: dgamma_k[c] += sum_m dy_k[m][c] * xhat_k[m][c], dbeta_k[c] += sum_m dy_k[m][c]  (native_layer_norm_backward's weight / bias terms). */
 #define AVEC_LN_GROUP_MAX 40
