@@ -69,3 +69,5 @@ conv(3200, 11, 128, 128)
 conv(3200, 6, 256, 256)
 conv(3200, 3, 512, 512)
 conv(3200, 22, 64, 128, 2)
+conv(3200, 11, 128, 256, 2)
+conv(3200, 6, 256, 512, 2)
