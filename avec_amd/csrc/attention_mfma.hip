@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32x2_to_
 template <int PITCH, int NTHR>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, long long ld, int row0, int nrows, int limit, int d, int dpad) {
   const int CH = dpad >> 3;
-  const bool al4 = ((((size_t)src) | ((size_t)ld * 2)) & 3) == 0;
+  const bool al4 = true;      // (gfx950 serves dword loads at any 2-byte address: rows of odd heads -- d = 45, audio stage 0 -- take the 16-byte path too; round 2 fetched them element by element)
   for (int idx = threadIdx.x; idx < nrows * CH; idx += NTHR) {
     const int r = idx / CH, c = idx - r * CH; const int gr = row0 + r;
     chunk16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
@@ -166,13 +166,11 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&O)[CTMAX], float mul
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const bool pair = (d & 1) == 0 && (((size_t)op | ((size_t)ldo * 2)) & 3) == 0;
-  if (pair) {
-    const int dh = d >> 1;
-    for (int idx = lane; idx < nrow * dh; idx += 64) { const int r = idx / dh, c = (idx - r * dh) * 2; *(uint32_t*)(op + (long long)r * ldo + c) = *(const uint32_t*)(ost + r * OP + c); }
-  } else {
-    for (int idx = lane; idx < nrow * d; idx += 64) { const int r = idx / d, c = idx - r * d; op[(long long)r * ldo + c] = ost[r * OP + c]; }
-  }
+  // element pairs as (possibly unaligned) dword stores, the last element of an odd row on its own
+  typedef uint32_t __attribute__((aligned(2))) u32_u;
+  const int dh = d >> 1;
+  for (int idx = lane; idx < nrow * dh; idx += 64) { const int r = idx / dh, c = (idx - r * dh) * 2; *(u32_u*)(op + (long long)r * ldo + c) = *(const uint32_t*)(ost + r * OP + c); }
+  if (d & 1) for (int r = lane; r < nrow; r += 64) op[(long long)r * ldo + d - 1] = ost[r * OP + d - 1];
 }
 
 // ------------------------------------------------------------------------------------------------
