@@ -229,3 +229,60 @@ def test_resnet_shortcut_gradient_on_subsampled_grid_matches_full_size_path():
     assert len(res[True][1]) == len(res[False][1]) and len(res[True][1]) > 40
     for n in res[True][1]:
         assert rel_err(res[True][1][n], res[False][1][n]) < 1e-2, n
+
+
+def test_layernorm_bwd_prep_equals_separate_grad_prep():
+    """avec_layernorm_bwd_prep: dx is bit-identical to avec_layernorm_bwd's and the second output to grad_prep(dx) with the same (alpha, dropout stream) -- the
+    fusion that removes one launch per residual module from the backward pass"""
+    import avec_amd
+    from avec_amd import ops, runtime as rt
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d = dev()
+        g = torch.Generator().manual_seed(8)
+        M, D = 333, 360
+        dy = torch.randn(M, D, generator=g).bfloat16().to(d)
+        x = torch.randn(M, D, generator=g).to(d)
+        dres = torch.randn(M, D, generator=g).to(d)
+        w = torch.randn(D, generator=g).to(d)
+        mean, rstd = x.mean(1).contiguous(), (1.0 / (x.var(1, unbiased=False) + 1e-6).sqrt()).contiguous()
+        dx0, dx1 = torch.empty(M, D, device=d), torch.empty(M, D, device=d)
+        prep = torch.empty(M, D, dtype=torch.bfloat16, device=d)
+        rng = rt.rng_state(d)
+        ops.lib.layernorm_bwd(rt.dt(), dy.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx0.data_ptr(), dres.data_ptr(), None, None, M, D, rt.stream())
+        ops.lib.layernorm_bwd_prep(rt.dt(), dy.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(), dx1.data_ptr(), dres.data_ptr(),
+                                   prep.data_ptr(), 0.5, 0.1, rng.data_ptr(), 7, M, D, rt.stream())
+        ref = ops.grad_prep(dx0, M, D, alpha=0.5, drop_p=0.1, sid=7)
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1)
+        assert torch.equal(prep, ref)
+        assert float((ref == 0).float().mean()) > 0.05                     # the dropout mask is really in there
+    finally:
+        avec_amd.set_compute_dtype("f32")
+
+
+def test_shadow_refresh_range_equals_full_refresh():
+    """avec_shadow_refresh_range over two complementary runs of table entries reproduces avec_shadow_refresh (Linear, fused Q|K|V, Conv2d 3x3 and the stem Conv3d:
+    vector and element-wise paths of the 64 x 64 tile kernel)"""
+    import avec_amd
+    import nnet
+    from avec_amd import runtime as rt
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(3)
+        m = nnet.AudioVisualEfficientConformerInterCTC(vocab_size=64, v_interctc_blocks=[3], a_interctc_blocks=[8], f_interctc_blocks=[2]).to(dev())
+        arena = m.arena if hasattr(m, "arena") else rt.arena_of(m)
+        arena.dirty = True
+        arena.ensure_fresh()
+        torch.cuda.synchronize()
+        full = arena.shadow.clone()
+        arena.shadow.zero_()
+        rows = arena.table.cpu().tolist()
+        k = len(rows) // 3
+        for e0, e1 in ((0, k), (k, len(rows))):
+            nblocks = sum(r[7] for r in rows[e0:e1])
+            rt.lib.shadow_refresh_range(rt.dt(), arena.master.data_ptr(), arena.shadow.data_ptr(), arena.table.data_ptr() + e0 * 80, e1 - e0, rows[e0][6], nblocks, rt.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(arena.shadow, full)
+    finally:
+        avec_amd.set_compute_dtype("f32")
