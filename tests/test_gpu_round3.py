@@ -286,3 +286,38 @@ def test_shadow_refresh_range_equals_full_refresh():
         assert torch.equal(arena.shadow, full)
     finally:
         avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(333, 200, 360, "res"), (70, 64, 72, "plain"), (1000, 1440, 1440, "ffn1"), (800, 360, 1440, "res"), (129, 65, 8, "plain"), (64, 64, 64, "plain")])
+def test_lean_plain_product_matches_fp32_math(M, N, K, kind):
+    """gemm_nt_plain_kernel<64,64> (the conformer-sized products): ragged M / N (clamped rows, unstored columns), K that is not a multiple of the 64-wide K tile
+    (partial last tile from the zero page), every epilogue the conformer uses -- against fp32 math on the same bf16 operands"""
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import ACT_SWISH, lib
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d = dev()
+        g = torch.Generator().manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g).bfloat16().to(d)
+        W = (0.1 * torch.randn(N, K, generator=g)).bfloat16().to(d)
+        bias = torch.randn(N, generator=g).to(d)
+        res = torch.randn(M, N, generator=g).to(d)
+        ref = A.float() @ W.float().t() + bias
+        if kind == "ffn1":
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=d)
+            ops.gemm_nt(A, W, out, M, N, K, bias=bias, act=ACT_SWISH)
+            ref = ref * torch.sigmoid(ref)
+        elif kind == "res":
+            out = torch.empty(M, N, dtype=torch.float32, device=d)
+            ops.gemm_nt(A, W, out, M, N, K, bias=bias, res=res, alpha=0.5, out_f32=True)
+            ref = res + 0.5 * ref
+        else:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=d)
+            ops.gemm_nt(A, W, out, M, N, K, bias=bias)
+        name = lib.raw("avec_last_kernel")()
+        torch.cuda.synchronize()
+        assert b"gemm_nt_plain_kernel" in (name if isinstance(name, bytes) else name.encode()), name
+        assert rel_err(out.float().cpu(), ref.cpu()) < (1e-2 if out.dtype == torch.bfloat16 else 2e-3)
+    finally:
+        avec_amd.set_compute_dtype("f32")
