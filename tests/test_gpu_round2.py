@@ -587,7 +587,7 @@ from avec_amd import ops
 from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
 avec_amd.set_compute_dtype("bf16")
 d = torch.device("cuda:0"); out = {}
-for (Nimg, H, Cin, Cout, stride) in [(33, 11, 128, 128, 1), (33, 11, 128, 256, 2), (20, 22, 64, 128, 2)]:
+for (Nimg, H, Cin, Cout, stride) in [(33, 11, 128, 128, 1), (33, 11, 128, 256, 2), (20, 22, 64, 128, 2), (61, 6, 256, 256, 1), (70, 3, 512, 512, 1)]:
     g = torch.Generator().manual_seed(H + stride)
     x = torch.randn(Nimg, H, H, Cin, generator=g).bfloat16().to(d); OH = (H - 1) // stride + 1; M = Nimg * OH * OH
     W = (torch.randn(Cout, 9 * Cin, generator=g) / 30).bfloat16().to(d); Wb = (torch.randn(Cin, 9 * Cout, generator=g) / 30).bfloat16().to(d)
