@@ -361,8 +361,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_c64_grouped_kernel(C3WGroup grp)
 // Weight gradient of the wider 3x3 layers (ResNet stages 2..4: C = 128 / 256 / 512 channels, 11x11 / 6x6 / 3x3 images): same slab idea, the C x 9C fp32
 // result split over (C/64) x (C/128) kinds of workgroup -- 64 output channels x 128 input channels x 9 taps = 72 tiles of 32 x 32, nine per wave (one
 // (co tile, ci quarter) pair and all nine taps).  Several images per iteration: x slabs of RS rows x 256 B (this kind's 128 input channels) and dy images
-// of KP rows x 128 B (its 64 output channels), all with the row pitch W+1; 352 x-rows and 288 dy-rows of LDS hold 2..10 images.  The DMA plan (which
-// image / element each 16-byte LDS slot receives) lives in LDS.  x is read C/64 times and dy C/128 times in total -- against once per column tile and
+// of KP rows x 128 B (its 64 output channels), all with the row pitch W+1; 352 x-rows and 288 dy-rows of LDS hold 2..10 images (as two halves:
+// see the round-3 note below).  x is read C/64 times and dy C/128 times in total -- against once per column tile and
 // once per tap for the implicit-GEMM TN kernel (0.65 GB fetched per launch for 0.2 GB of tensors at C = 128).
 // ------------------------------------------------------------------------------------------------
 #ifndef C3_ABL
