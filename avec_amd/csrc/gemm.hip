@@ -943,6 +943,145 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (forward, or backward-data incl. the parity-class order of stride-2 layers) with the loop of gemm_nt_plain_kernel: 128-row tiles,
+// 64-byte LDS rows (32 channels per K-step, always inside one tap: C % 32 == 0), 3-stage ring unrolled so that the ring position is compile-time, fragment reads
+// from four precomputed addresses + immediates, the weight tiles by scalar-base DMA; only the gathered A chunks keep per-lane work (64-bit row pointer + the
+// tap's scalar offset, redirected to the zero page where the tap leaves the image).  The stride-2 and 1x1 layers of the ResNet (the general kernel spends ~110
+// instructions per K-step of 8 MFMAs on them).  Host-checked like the fast path of gemm_nt_glds_kernel (fast_conv); same LDS image, swizzle and epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_conv_lean_kernel(GemmArgs g) {
+  typedef bf16 T;
+  constexpr int BM = 128, RB = 64, KE = 32, STAGES = 3, CPR = 4;
+  constexpr int NCA = BM * CPR / 256, NCB = BN * CPR / 256, LPT = NCA + NCB;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int TILE = (BM + BN) * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr bool PERM = MODE == MODE_CONV_BWD;
+  const bool perm = PERM && g.perm2;
+  const int cls = perm ? ((int)blockIdx.x >= g.pTs[2] ? ((int)blockIdx.x >= g.pTs[3] ? 3 : 2) : ((int)blockIdx.x >= g.pTs[1] ? 1 : 0)) : 0;
+  const long long m0 = perm ? (long long)((int)blockIdx.x - g.pTs[cls]) * BM : (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  const long long pMc = perm ? perm2_count(g.a, cls, g.pImgs) : 0;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem, wslot = (unsigned)wave * 1024u;
+  const int IW = MODE == MODE_CONV_FWD ? g.a.W : g.a.OW;      // row pitch of the source image
+  const int sh = (MODE == MODE_CONV_BWD && g.a.stride == 2) ? 1 : 0;
+  // A plan: pass i, thread tid -> tile row tid/4 + 64 i, physical slot tid%4 carrying logical chunk (tid%4) ^ swz(row): 64-bit pointer of the row's origin + tap mask
+  const T* aptr[NCA]; unsigned rmask[NCA];
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) {
+    const int row = (tid >> 2) + i * 64;
+    RowInfo r;
+    if (perm) {
+      r.valid = m0 + row < pMc; r.base = 0; r.a = 0; r.b = 0;
+      if (r.valid) { long long img; int ih, iw; perm2_pixel(g.a, cls, m0 + row, img, ih, iw); r.base = img * (long long)g.a.OH * g.a.OW * g.a.C; r.a = ih + g.a.pad; r.b = iw + g.a.pad; }
+    } else r = row_info<MODE>(g.a, m0 + row, g.M);
+    const int ka = ((tid & 3) ^ glds_swz<RB>(row)) * 8;
+    aptr[i] = (const T*)g.a.ptr + (r.base + (long long)((r.a >> sh) * IW + (r.b >> sh)) * g.a.C + ka);
+    unsigned mk = 0u;
+    for (int kh = 0; kh < g.a.KH; ++kh)
+      for (int kw = 0; kw < g.a.KW; ++kw) {
+        bool ok;
+        if (MODE == MODE_CONV_FWD) { const int y = r.a + kh, x = r.b + kw; ok = y >= 0 && x >= 0 && y < g.a.H && x < g.a.W; }
+        else { const int ty = r.a - kh, tx = r.b - kw; ok = ty >= 0 && tx >= 0 && !((ty | tx) & sh) && (ty >> sh) < g.a.OH && (tx >> sh) < g.a.OW; }
+        mk |= ((ok && r.valid) ? 1u : 0u) << (kh * g.a.KW + kw);
+      }
+    rmask[i] = mk;
+  }
+  unsigned boff[NCB];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int row = (tid >> 2) + i * 64; const int n = n0 + row < g.N ? n0 + row : g.N - 1;
+    boff[i] = (unsigned)(((long long)n * g.ldw + (((tid & 3) ^ glds_swz<RB>(row)) * 8)) * 2);
+  }
+  const char* const Wb = (const char*)g.W;
+  // taps of this tile (parity classes reach a subset), K-steps
+  unsigned tapmask = 0xffffffffu; int KT = (g.K + KE - 1) / KE;
+  int f_tap = 0, f_kh = 0, f_kw = 0, f_c0 = 0;                 // running (tap, kh, kw, channel offset) of the next K-step to be issued
+  if (perm) {
+    tapmask = 0u; int ntap = 0;
+    for (int kh = 0; kh < g.a.KH; ++kh)
+      for (int kw = 0; kw < g.a.KW; ++kw)
+        if (!((((cls >> 1) + g.a.pad - kh) | ((cls & 1) + g.a.pad - kw)) & 1)) { tapmask |= 1u << (kh * g.a.KW + kw); ++ntap; }
+    KT = ntap * (g.a.C / KE);
+    while (f_tap < g.a.KH * g.a.KW && !((tapmask >> f_tap) & 1u)) { ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } }
+  }
+  auto issue = [&](auto stagec) {
+    constexpr int S = decltype(stagec)::value;
+    const unsigned la = lds0 + S * TILE + wslot, lb = la + BM * RB;
+    const long long tapoff = (long long)((MODE == MODE_CONV_FWD ? (f_kh * IW + f_kw) : -((f_kh >> sh) * IW + (f_kw >> sh))) * g.a.C + f_c0);
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const void* src = ((rmask[i] >> f_tap) & 1u) ? (const void*)(aptr[i] + tapoff) : (const void*)avec_zero16;
+      glds16_v64(src, la + i * 4096);
+    }
+    glds16_group<NCB>(boff, Wb + (long long)(f_tap * g.a.C + f_c0) * 2, lb);
+    f_c0 += KE;
+    if (f_c0 >= g.a.C) {
+      f_c0 = 0;
+      do { ++f_tap; if (++f_kw >= g.a.KW) { f_kw = 0; ++f_kh; } } while (PERM && f_tap < 32 && !((tapmask >> f_tap) & 1u));
+    }
+  };
+  const int gsel = lane >> 5;
+  unsigned aad[2], bad[2];
+  { const int ra = wm * (BM / 2) + (lane & 31), rb = wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      aad[q] = lds0 + (unsigned)(ra * RB + (((2 * q + gsel) ^ glds_swz<RB>(ra)) << 4));
+      bad[q] = lds0 + (unsigned)(BM * RB + rb * RB + (((2 * q + gsel) ^ glds_swz<RB>(rb)) << 4));
+    } }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  issue(IntC<0>{});
+  if (KT > 1) issue(IntC<1>{});
+  auto step = [&](const int kt, auto stagec) {
+    constexpr int S = decltype(stagec)::value;
+    if (kt + 1 < KT) AVEC_WAIT_VM(LPT); else AVEC_WAIT_VM(0);        // tile kt + 1 may still be in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      fa[q][0] = lds_read128o<S * TILE>(aad[q]); fa[q][1] = lds_read128o<S * TILE + 2048>(aad[q]);
+      fb[q][0] = lds_read128o<S * TILE>(bad[q]);
+      if (NT > 1) fb[q][1 % NT] = lds_read128o<S * TILE + 2048>(bad[q]);
+    }
+    if (kt + 2 < KT) issue(IntC<(S + 2) % STAGES>{});                 // into the slot everybody finished reading before this barrier
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q][i]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[q][j]));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt += STAGES) {
+    step(kt, IntC<0>{});
+    if (kt + 1 < KT) step(kt + 1, IntC<1>{});
+    if (kt + 2 < KT) step(kt + 2, IntC<2>{});
+  }
+#undef AVEC_WAIT_VM
+  __syncthreads();
+  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, cls);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) NT product: A [M][K] and W [N][K] one byte per element, per-tensor scales, fp32 accumulate on
 // v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at 2^0).  Same LDS-DMA ring as gemm_nt_glds_kernel with 128-byte rows (= 128 K values
 // = two MFMA K-steps); a lane's 32-byte operand is two adjacent 16-byte chunks of its row -- A and B fragments pick the same chunks, so the
@@ -1462,6 +1601,16 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
       avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
       hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g); return 0;
+    }
+  }
+  if constexpr (sizeof(T) == 2 && BM == 128 && (BN == 128 || BN == 64)) {
+    static const bool no_clean = getenv("AVEC_NO_LEAN_CONV") != nullptr;
+    if (mode != MODE_PLAIN && g.fast_conv && a16 && !f32src && use_glds && !no_clean && g.a.C % 32 == 0 && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
+      const size_t l2 = (size_t)3 * (BM + BN) * 64 > epi_lds ? (size_t)3 * (BM + BN) * 64 : epi_lds;
+      avec_note_kernel("gemm_nt_conv_lean_kernel<%d,%d>", BN, mode);
+      if (mode == MODE_CONV_FWD) { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>), grid, dim3(256), l2, st, g); }
+      else { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>), grid, dim3(256), l2, st, g); }
+      return 0;
     }
   }
   if ((a16 || plain_any) && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
