@@ -577,7 +577,7 @@ def test_conv3x3_fast_paths_match_torch_conv2d(Nimg, H, Cin, Cout, stride):
 
 
 def test_conv3x3_fast_paths_equal_generic_kernels(tmp_path):
-    """The same launches with the fast paths switched off (AVEC_NO_CONV_SHIFT / AVEC_NO_PERM2, read once per process): identical bf16 results up to the
+    """The same launches with the fast paths switched off (AVEC_NO_CONV_SHIFT / AVEC_NO_PERM2 / AVEC_NO_LEAN_CONV, read once per process): identical bf16 results up to the
     summation order (fp32 accumulation, one rounding)."""
     code = r'''
 import sys, torch
@@ -601,7 +601,7 @@ torch.save(out, sys.argv[1])
     script = tmp_path / "run.py"
     script.write_text(code)
     res = {}
-    for name, env in (("fast", {}), ("fast256", {"AVEC_SHIFT_BM": "256"}), ("generic", {"AVEC_NO_CONV_SHIFT": "1", "AVEC_NO_PERM2": "1"})):
+    for name, env in (("fast", {}), ("fast256", {"AVEC_SHIFT_BM": "256"}), ("generic", {"AVEC_NO_CONV_SHIFT": "1", "AVEC_NO_PERM2": "1", "AVEC_NO_LEAN_CONV": "1"})):
         e = dict(os.environ); e.update(env)
         p = tmp_path / (name + ".pt")
         subprocess.run([sys.executable, str(script), str(p)], check=True, env=e, timeout=600)
