@@ -140,6 +140,14 @@ struct Epi {
   int res_cls0;                    // parity-class order: `res` has one row per class-0 pixel (class-local index), none for the other classes
 };
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): id w runs on XCD w % 8.  xcd_logical() gives XCD x the CONTIGUOUS range of
+// logical ids [x*q + min(x, r), ...) (q = total / 8, r = total % 8), so that workgroups with neighbouring logical ids -- the tiles that share a reduction
+// slice of both operands -- fill ONE L2 instead of eight.
+__device__ __forceinline__ int xcd_logical(int w, int total) {
+  const int q = total >> 3, r = total & 7, x = w & 7;
+  return x * q + (x < r ? x : r) + (w >> 3);
+}
+
 struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
                   // parity classes (backward-data of a stride-2 convolution, glds kernel): input pixels are visited class by class, class = (ih & 1) * 2 + (iw & 1);
                   // inside a class every row uses the same taps (kh = ih + pad mod 2, kw likewise), so a tile runs only those K-steps: 9 of 36 tap-rows for 3x3
@@ -1191,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fp8_kernel(GemmArgs g, const f
 // ------------------------------------------------------------------------------------------------
 struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; void* Oact; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block; float* pcs;   // Oact: when set, the result is STORED in the activation dtype (one workgroup per tile, no split) instead of added to O;   // pcs: optional column sums of P (bias gradient), transposed-read kernel only
                   // Iq/Jq: load bounds (>= I/J when rows are padded)
-                int split, nb_inner; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
+                int split, nb_inner, xcd_map; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
 
 // LDS image of a TN operand: [col][word], word = reduction-row pair (bf16: rows 2p,2p+1 packed in 32 bits) or row (fp32), 32 words
 // per 144-byte row.  Word index XOR-swizzled by 16 * parity(col bits 2..4): with lanes mapped (16 pairs x 4 column chunks) both the
@@ -1508,25 +1516,31 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const 
 }
 
 template <int BI, int BJ, int MODE, int STAGES, bool Q32 = false, int KT = 64>
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) { tn_tr_body<BI, BJ, MODE, STAGES, Q32, KT>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs g) {
+  if (g.xcd_map) {                             // (tile x fastest, then tile y, then batch / reduction slice: the tiles of one slice are neighbours)
+    int l = xcd_logical(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bx = l % gridDim.x; l /= gridDim.x;
+    tn_tr_body<BI, BJ, MODE, STAGES, Q32, KT>(g, bx, l % gridDim.y, l / gridDim.y);
+  } else tn_tr_body<BI, BJ, MODE, STAGES, Q32, KT>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // ---- grouped launch: up to AVEC_TN_GROUP_MAX independent plain bf16 products (the weight gradients of one or more conformer blocks) as ONE grid.
 // The items travel BY VALUE in the kernel argument block (captured by a hipGraph node like any other argument; no device-side table to keep alive);
 // workgroup w belongs to the item whose [first, first + count) range contains it.
 struct TnItem { const void* P; const void* Q; float* O; float* pcs; int ldp, ldq, ldo, M, I, J, Iq, Jq, m_per_block, split, gx, gy, rows_out, rows_in, step, first; };
-struct TnGroup { TnItem it[AVEC_TN_GROUP_MAX]; int n, total; };
-template <int BT>
+struct TnGroup { TnItem it[AVEC_TN_GROUP_MAX]; int n, total, xcd_map; };
+template <int BT, int STG = 2, int KT = 32>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(TnGroup grp) {
-  const int w = blockIdx.x;
+  const int w = grp.xcd_map ? xcd_logical(blockIdx.x, grp.total) : (int)blockIdx.x;
   int lo = 0, hi = grp.n - 1;                   // last item with first <= w
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (grp.it[mid].first <= w) lo = mid; else hi = mid - 1; }
   const TnItem& t = grp.it[lo];
   TnArgs g; g.P = t.P; g.ldp = t.ldp; g.q.ptr = t.Q; g.q.ld = t.ldq; g.q.rows_out = t.rows_out; g.q.rows_in = t.rows_in; g.q.step = t.step;
   g.q.H = g.q.W = g.q.C = g.q.KH = g.q.KW = g.q.stride = g.q.pad = g.q.OH = g.q.OW = 0;
   g.O = t.O; g.Oact = nullptr; g.ldo = t.ldo; g.M = t.M; g.I = t.I; g.J = t.J; g.Iq = t.Iq; g.Jq = t.Jq; g.m_per_block = t.m_per_block; g.pcs = t.pcs;
-  g.split = t.split; g.nb_inner = 1; g.sPo = g.sPi = g.sQo = g.sQi = g.sOo = g.sOi = 0;
+  g.split = t.split; g.nb_inner = 1; g.xcd_map = 0; g.sPo = g.sPi = g.sQo = g.sQi = g.sOo = g.sOi = 0;
   int l = w - t.first; const int bx = l % t.gx; l /= t.gx; const int by = l % t.gy; const int bz = l / t.gy;
-  tn_tr_body<BT, BT, MODE_PLAIN, 2, false, 32>(g, bx, by, bz);
+  tn_tr_body<BT, BT, MODE_PLAIN, STG, false, KT>(g, bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1837,6 +1851,7 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
   TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.Oact = Oact; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0; g.pcs = p_colsum;
   g.split = 1; g.nb_inner = nb_inner;
+  { static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr; g.xcd_map = no_xcd ? 0 : 1; }
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
   // P batches stay dword aligned; Q batches may start on any element (heads of odd width, d = 45: the plain-load kernels issue unaligned dword loads, which gfx950 serves)
@@ -1923,15 +1938,16 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
     first += t.gx * t.gy * t.split;
   }
   grp.total = first;
-  const size_t lds = (size_t)2 * 32 * (BT + BT) * 2;
-  avec_note_kernel("gemm_tn_tr_grouped_kernel<%d>", BT);
-  if (BT == 128) {
-    if (int r = want_lds(gemm_tn_tr_grouped_kernel<128>, lds)) return r;
-    hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel<128>, dim3((unsigned)first), dim3(256), lds, stream, grp);
-  } else {
-    if (int r = want_lds(gemm_tn_tr_grouped_kernel<64>, lds)) return r;
-    hipLaunchKernelGGL(gemm_tn_tr_grouped_kernel<64>, dim3((unsigned)first), dim3(256), lds, stream, grp);
-  }
+  static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr;
+  grp.xcd_map = no_xcd ? 0 : 1;
+  static const int kt_env = getenv("AVEC_TNG_KT") ? atoi(getenv("AVEC_TNG_KT")) : 64;       // 64 reduction rows per tile: half the barriers of 32 (isolated -12 %, in the step -0.1 ms);
+  const int KT = kt_env == 32 ? 32 : 64;                                                    // rings of 3 / 4 stages change nothing (measured with tools/bench_tn_grouped.py: the loop is not latency-bound)
+  const size_t lds = (size_t)2 * KT * (BT + BT) * 2;
+  avec_note_kernel("gemm_tn_tr_grouped_kernel<%d,2,%d>", BT, KT);
+#define TNG(BT_, K_) do { if (BT == BT_ && KT == K_) { if (int r = want_lds(gemm_tn_tr_grouped_kernel<BT_, 2, K_>, lds)) return r; \
+    hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<BT_, 2, K_>), dim3((unsigned)first), dim3(256), lds, stream, grp); } } while (0)
+  TNG(128, 32); TNG(128, 64); TNG(64, 32); TNG(64, 64);
+#undef TNG
   AVEC_LAUNCH_CHECK();
   return 0;
 }

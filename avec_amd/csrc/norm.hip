@@ -494,7 +494,7 @@ constexpr int BN8_UR = 1;       // ... in the reduction pass (2 measured 4-6 % s
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,
-                                                        T* __restrict__ out, unsigned n8, int C) {
+                                                        T* __restrict__ out, unsigned n8, int C, unsigned char* __restrict__ mask = nullptr) {
   const unsigned C8 = (unsigned)C >> 3, stride = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(i0 % C8) * 8;
   float sc[8], sh[8]; ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh);
@@ -515,12 +515,24 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y,
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
       } else if (act == 2) {
+        if (mask) {                      // one bit per element: out > 0 (what the backward pass needs of `out`)
+          unsigned b = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+          mask[j] = (unsigned char)b;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       st8<T>(out + (long long)j * 8, v);
     }
   }
+}
+extern "C" int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, void* out, unsigned char* mask, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(y && ss && out && mask && M > 0 && C > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31), "bn_apply_fwd_mask: bad arguments (C %% 8 == 0, M*C < 2^34)");
+  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, 2, (T*)out, (unsigned)n8, C, mask));
+  AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: bad arguments");
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // 8-wide flat variant (C % 8 == 0): every lane busy for narrow C, 16 B accesses
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
-                                                             int act, float* dstats, long long M, int C, ColWs ws) {
+                                                             int act, float* dstats, long long M, int C, ColWs ws, const unsigned char* __restrict__ mask = nullptr) {
   const Col8 m = col8_map(C);
   float part[2][8];
 #pragma unroll
@@ -569,17 +581,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict
   if (m.active) {
     const int c = m.l * 8;
     float mu[8], rs[8], sc[8], sh[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs);
-    if (act == 1 || (act == 2 && !out)) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
+    if (act == 1 || (act == 2 && !out && !mask)) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
     const long long rstride = (long long)gridDim.x * m.R;
     for (long long row = (long long)blockIdx.x * m.R + m.r; row < M; row += rstride * BN8_UR) {
-      Raw8<T> rd[BN8_UR], rv[BN8_UR], ro[BN8_UR];
+      Raw8<T> rd[BN8_UR], rv[BN8_UR], ro[BN8_UR]; unsigned mb[BN8_UR];
 #pragma unroll
-      for (int u = 0; u < BN8_UR; ++u) { const long long r = row + u * rstride; if (r < M) { const long long off = r * C + c; rd[u].load(dout + off); rv[u].load(y + off); if (act == 2 && out) ro[u].load(out + off); } }
+      for (int u = 0; u < BN8_UR; ++u) { const long long r = row + u * rstride; if (r < M) { const long long off = r * C + c; rd[u].load(dout + off); rv[u].load(y + off);
+        if (mask) mb[u] = mask[off >> 3]; else if (act == 2 && out) ro[u].load(out + off); } }
 #pragma unroll
       for (int u = 0; u < BN8_UR; ++u) {
         if (row + u * rstride >= M) break;
         float d[8], v[8]; rd[u].get(d); rv[u].get(v);
-        if (act == 2 && out) { float o[8]; ro[u].get(o);
+        if (mask) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = (mb[u] >> e) & 1u ? d[e] : 0.f; }
+        else if (act == 2 && out) { float o[8]; ro[u].get(o);
 #pragma unroll
           for (int e = 0; e < 8; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f; }
         else if (act == 2) {
@@ -595,6 +611,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const T* __restrict
   }
   float* const dst[2] = {dstats, dstats + C};
   colreduce8_atomic<2>(part, dst, m, ws);
+}
+extern "C" int avec_bn_bwd_reduce_mask(int dtype, const void* dout, const void* y, const unsigned char* mask, const float* ss, float* dstats, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && y && mask && ss && dstats && M > 0 && col8_ok(C), "bn_bwd_reduce_mask: bad arguments");
+  ColWs ws; const unsigned nb = col8_cfg(M, C, 2, &ws, st);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)nullptr, ss, 2, dstats, M, C, ws, mask));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
+  return 0;
 }
 extern "C" int avec_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* ss, int act, float* dstats, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && ss && dstats && M > 0 && C % 4 == 0, "bn_bwd_reduce: bad arguments");
@@ -631,7 +655,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out, const float* __restrict__ ss,
                                                             const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count, int act,
-                                                            T* __restrict__ dy, T* __restrict__ dres, float* dgamma, float* dbeta, unsigned n8, int C) {
+                                                            T* __restrict__ dy, T* __restrict__ dres, float* dgamma, float* dbeta, unsigned n8, int C,
+                                                            const unsigned char* __restrict__ mask = nullptr) {
   const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
   if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, dstats[C + c]); atomicAdd(dbeta + c, dstats[c]); }
   const unsigned C8 = (unsigned)C >> 3, stride = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
@@ -641,18 +666,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const T* __restrict_
   { float g[8], s1[8], s2[8]; ld8<float>(ss + 2 * C + c, mu); ld8<float>(ss + 3 * C + c, rs); ld8<float>(gamma + c, g); ld8<float>(dstats + c, s1); ld8<float>(dstats + C + c, s2);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { A[e] = g[e] * rs[e]; m1[e] = s1[e] * inv_n; m2[e] = s2[e] * inv_n; } }
-  const bool recompute = act != 0 && !(act == 2 && out);
+  const bool recompute = act != 0 && !(act == 2 && (out || mask));
   if (recompute) { ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh); }
   for (unsigned i = i0; i < n8; i += stride * BN8_U) {
-    Raw8<T> rd[BN8_U], rv[BN8_U], ro[BN8_U];
+    Raw8<T> rd[BN8_U], rv[BN8_U], ro[BN8_U]; unsigned mb[BN8_U];
 #pragma unroll
-    for (int u = 0; u < BN8_U; ++u) { const unsigned j = i + u * stride; if (j < n8) { const long long off = (long long)j * 8; rd[u].load(dout + off); rv[u].load(y + off); if (act == 2 && out) ro[u].load(out + off); } }
+    for (int u = 0; u < BN8_U; ++u) { const unsigned j = i + u * stride; if (j < n8) { const long long off = (long long)j * 8; rd[u].load(dout + off); rv[u].load(y + off);
+      if (mask) mb[u] = mask[j]; else if (act == 2 && out) ro[u].load(out + off); } }
 #pragma unroll
     for (int u = 0; u < BN8_U; ++u) {
       const unsigned j = i + u * stride; if (j >= n8) break;
       const long long off = (long long)j * 8;
       float d[8], v[8], o[8]; rd[u].get(d); rv[u].get(v);
-      if (act == 2 && out) { float q[8]; ro[u].get(q);
+      if (mask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (mb[u] >> e) & 1u ? d[e] : 0.f;
+      } else if (act == 2 && out) { float q[8]; ro[u].get(q);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] = q[e] > 0.f ? d[e] : 0.f;
       } else if (act != 0) {
@@ -665,6 +694,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const T* __restrict_
       if (dres) st8<T>(dres + off, d);
     }
   }
+}
+extern "C" int avec_bn_bwd_apply_mask(int dtype, const void* dout, const void* y, const unsigned char* mask, const float* ss, const float* gamma, const float* dstats,
+                                      const float* count_ptr, float count, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
+  AVEC_CHECK_ARG(dout && y && mask && ss && gamma && dstats && dy && M > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31), "bn_bwd_apply_mask: bad arguments");
+  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)nullptr, ss, gamma, dstats,
+                                       count_ptr, count, 2, (T*)dy, (T*)dres, dgamma, dbeta, (unsigned)n8, C, mask));
+  AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* ss, const float* gamma, const float* dstats,
                                  const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {

@@ -131,6 +131,7 @@ def empty(shape, dtype, ref):
 
 
 ATTN_ODD_VALU = os.environ.get("AVEC_ATTN_ODD_VALU", "0") == "1"             # A/B: odd head widths take the VALU column pass of the attention backward (round 2)
+CAST_DEFER = os.environ.get("AVEC_CAST_DEFER", "1") == "1"                   # fp32-input weight gradients: cast once and join the grouped launch (0: a launch of their own)
 TNG_ALIGNED_ONLY = os.environ.get("AVEC_TNG_ALIGNED_ONLY", "0") == "1"       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
 
 
@@ -220,6 +221,7 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
 # avec_layernorm_param_grads_grouped: one grid over the tiles of up to 32 / 40 products) when a queue fills, at the explicit flush points (end of the audio
 # branch, before an early gradient all-reduce) and by a final autograd callback when the backward pass ends.  AVEC_DEFER_WGRAD=0 restores immediate launches.
 DEFER_WGRAD = os.environ.get("AVEC_DEFER_WGRAD", "1") != "0"
+_TN_WHY = os.environ.get("AVEC_TN_WHY", "0") == "1"      # debugging aid: print every weight-gradient product that misses the grouped launch
 _TN_FLUSH_AT = int(os.environ.get("AVEC_DEFER_TN_MAX", str(TN_GROUP_MAX)))
 _DEFER = {"queues": {}, "task": -1}
 
@@ -312,6 +314,12 @@ def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32
     side=True (weight gradients): may be queued for a grouped launch (see above) / launched on the side stream (runtime.wgrad_fork)."""
     if q_rows is None:
         q_rows = rows_plain(J)
+    if side and q_mode == ROWS_PLAIN and q_f32 and CAST_DEFER and dtype is None and rt.compute_dtype() == "bf16" and _in_backward() and Q.dim() == 2 and Q.dtype == torch.float32:
+        # fp32 activations (a layer fed by the residual stream): one cast launch, then the product joins the grouped launch like any other -- instead of a
+        # launch of its own on the register-staged kernel plus a column-sum / col_finalize pair for its bias (same rounding: that kernel casts while staging)
+        Qb = empty((Q.shape[0], J), rt.act_dtype(), Q)
+        lib.cast_rows(rt.dt(), Q.data_ptr(), q_rows.ld, Qb.data_ptr(), J, Q.shape[0], J, rt.stream())
+        Q, q_f32, q_rows = Qb, False, rows_plain(J, q_rows.rows_out, q_rows.rows_in, q_rows.step)
     if side and q_mode == ROWS_PLAIN and not q_f32 and dtype is None and rt.compute_dtype() == "bf16" and _in_backward():
         it = TnItem()
         it.P, it.Q, it.O, it.p_colsum = P.data_ptr(), Q.data_ptr(), O.data_ptr(), _p(p_colsum)
@@ -325,6 +333,9 @@ def gemm_tn(P, Q, O, M, I, J, *, ldp=None, q_rows=None, q_mode=ROWS_PLAIN, q_f32
             if len(q.tn) >= _TN_FLUSH_AT:
                 _launch_pending(q, "tn")
             return
+    if _TN_WHY and side:
+        print("gemm_tn not deferred: M=%d I=%d J=%d q_mode=%d q_f32=%s dtype=%s in_backward=%s P%%16=%d Q%%16=%d ldp=%s ldq=%d step=%d Pdtype=%s Qdtype=%s" % (
+            M, I, J, q_mode, q_f32, dtype, _in_backward(), P.data_ptr() % 16, Q.data_ptr() % 16, ldp, q_rows.ld, q_rows.step, P.dtype, Q.dtype), flush=True)
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     st = rt.stream()
     if side and not KERNEL_TIMER.enabled:
@@ -915,6 +926,7 @@ class BNState:
         self.C = C
 
 
+RELU_BITMASK = os.environ.get("AVEC_RELU_BITMASK", "1") == "1"    # ResNet block ends: the backward pass reads a 1-bit ReLU mask instead of the saved block output (0: reads `out`)
 def bn_finalize(bn, st, count, training):
     """bn: module with weight/bias/running_mean/running_var/num_batches_tracked/momentum/eps"""
     C = st.C
@@ -932,14 +944,17 @@ def bn_finalize(bn, st, count, training):
     return cptr
 
 
-def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False, pre=None):
-    """pre: a completed BnbFuse -- `dout` is already masked and its (sum d, sum d*y) sit in pre.stats: no reduction pass, the apply pass reads d and y only"""
+def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False, pre=None, mask=None):
+    """pre: a completed BnbFuse -- `dout` is already masked and its (sum d, sum d*y) sit in pre.stats: no reduction pass, the apply pass reads d and y only
+    mask: the ReLU mask of `out` as one bit per element (avec_bn_apply_fwd_mask): read instead of `out`"""
     C = st.C
     adt = rt.act_dtype()
     dstats = rt.zeros_scratch(2 * C, dout.device)
     if pre is not None:
         lib.bn_bwd_finalize(pre.stats.data_ptr(), BNState.NREP, st.ss.data_ptr(), dstats.data_ptr(), C, rt.stream())
-        act, out, want_dres = ACT_NONE, None, False
+        act, out, want_dres, mask = ACT_NONE, None, False, None
+    elif mask is not None:
+        lib.bn_bwd_reduce_mask(rt.dt(), dout.data_ptr(), y.data_ptr(), mask.data_ptr(), st.ss.data_ptr(), dstats.data_ptr(), M, C, rt.stream())
     else:
         lib.bn_bwd_reduce(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), act, dstats.data_ptr(), M, C, rt.stream())
     gw, gb = grad_of(bn.weight), grad_of(bn.bias)
@@ -948,8 +963,12 @@ def bn_backward(bn, st, cptr, count, dout, y, out, act, M, want_dres=False, pre=
         gw = gb = None                    # (SyncBatchNorm) already added from the LOCAL sums; the kernel must not add the global ones
     dy = empty((M, C), adt, dout)
     dres = empty((M, C), adt, dout) if want_dres else None
-    lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count), act,
-                     dy.data_ptr(), _p(dres), _p(gw), _p(gb), M, C, rt.stream())
+    if mask is not None:
+        lib.bn_bwd_apply_mask(rt.dt(), dout.data_ptr(), y.data_ptr(), mask.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count),
+                              dy.data_ptr(), _p(dres), _p(gw), _p(gb), M, C, rt.stream())
+    else:
+        lib.bn_bwd_apply(rt.dt(), dout.data_ptr(), y.data_ptr(), _p(out), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), cptr, float(count), act,
+                         dy.data_ptr(), _p(dres), _p(gw), _p(gb), M, C, rt.stream())
     return dy, (dout if pre is not None else dres)
 
 
@@ -1403,7 +1422,13 @@ class ResNetBlockFn(torch.autograd.Function):
         else:
             r = x
         out = empty((Mo, Cout), adt, x)
-        lib.bn_apply_fwd(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), ACT_RELU, out.data_ptr(), Mo, Cout, rt.stream())
+        ctx.relu_mask = None
+        if RELU_BITMASK and training and Cout % 8 == 0 and Cout <= 2048 and Mo * Cout // 8 < (1 << 31):
+            # the backward pass needs `out` only as a ReLU mask: one bit per element, written here, instead of re-reading the tensor twice (reduction + apply pass)
+            ctx.relu_mask = torch.empty(Mo * Cout // 8, dtype=torch.uint8, device=x.device)
+            lib.bn_apply_fwd_mask(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), out.data_ptr(), ctx.relu_mask.data_ptr(), Mo, Cout, rt.stream())
+        else:
+            lib.bn_apply_fwd(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), ACT_RELU, out.data_ptr(), Mo, Cout, rt.stream())
         ctx.saved = (x, y1, a1, y2, yr, out, st1, st2, str_, c1, c2, cr, blk, training, N, H, W, Cin, Cout, OH, OW, stride, has_proj)
         ctx.chain = bool(chain and training and BNB_FUSE and rt.act_dtype() == torch.bfloat16)
         if ctx.chain:
@@ -1423,7 +1448,7 @@ class ResNetBlockFn(torch.autograd.Function):
         pre2 = ResNetBlockFn._READY.pop(dout.data_ptr(), None) if ctx.chain else None      # the consumer block already masked dout and reduced it against y2
         if pre2 is not None and pre2.y is not y2:
             raise RuntimeError("ResNetBlock backward: a fused BatchNorm-backward request does not belong to this block (the block output has another consumer?)")
-        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True, pre=pre2)
+        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True, pre=pre2, mask=ctx.relu_mask)
         f1 = BnbFuse(y1, st1.ss, None, Cout)        # BatchNorm 1 + ReLU: the mask comes from the pre-activation itself
         da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW, bnb=f1)
         dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, None, ACT_RELU, Mo, pre=f1 if f1.done else None)      # no residual before this ReLU: the mask is recomputed from y1 (one tensor less to read)

@@ -321,3 +321,34 @@ def test_lean_plain_product_matches_fp32_math(M, N, K, kind):
         assert rel_err(out.float().cpu(), ref.cpu()) < (1e-2 if out.dtype == torch.bfloat16 else 2e-3)
     finally:
         avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.gpu
+def test_resnet_block_relu_bitmask_equals_reading_the_saved_output():
+    """ResNet-18 trunk (bf16): the backward pass of the block-end BatchNorm + ReLU with the 1-bit mask written by avec_bn_apply_fwd_mask against the path that reads the
+    saved block output (avec_bn_bwd_reduce / _apply with `out`): same bits"""
+    import avec_amd
+    import nnet
+    from avec_amd import ops
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(10, 22, 22, 64, generator=g).to(dev())
+    res = {}
+    try:
+        avec_amd.set_compute_dtype("bf16")
+        for bm in (True, False):
+            torch.manual_seed(23)
+            net = nnet.ResNet(dim_input=64, dim_output=256, model="ResNet18", include_stem=False, include_head=True).to(dev()).train()
+            ops.RELU_BITMASK = bm
+            xin = x.to(torch.bfloat16).requires_grad_(True)
+            y = net.forward_nhwc(xin)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev())
+            (y.float() * w).sum().backward()
+            torch.cuda.synchronize()
+            res[bm] = (y.detach().float().cpu(), xin.grad.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.RELU_BITMASK = True
+        avec_amd.set_compute_dtype("f32")
+    assert torch.equal(res[True][0], res[False][0])
+    assert rel_err(res[True][1], res[False][1]) < 1e-6, "input gradient"
+    for n in res[True][2]:
+        assert rel_err(res[True][2][n], res[False][2][n]) < 1e-5, n             # (weight gradients are sums of fp32 atomics: order-dependent in the last bits)
