@@ -494,10 +494,15 @@ constexpr int BN8_UR = 1;       // ... in the reduction pass (2 measured 4-6 % s
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,
-                                                        T* __restrict__ out, unsigned n8, int C, unsigned char* __restrict__ mask = nullptr) {
+                                                        T* __restrict__ out, unsigned n8, int C, unsigned char* __restrict__ mask = nullptr,
+                                                        const float* __restrict__ res_ss = nullptr) {
   const unsigned C8 = (unsigned)C >> 3, stride = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
   const int c = (int)(i0 % C8) * 8;
   float sc[8], sh[8]; ld8<float>(ss + c, sc); ld8<float>(ss + C + c, sh);
+  float rsc[8], rsh[8];                                   // res_ss: the residual is a raw convolution output with its own BatchNorm coefficients (projection shortcut)
+  if (res_ss) { ld8<float>(res_ss + c, rsc); ld8<float>(res_ss + C + c, rsh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[e] += rsh[e]; }
   for (unsigned i = i0; i < n8; i += stride * BN8_U) {
     Raw8<T> ry[BN8_U], rr[BN8_U];
 #pragma unroll
@@ -509,8 +514,12 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y,
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
       if (res) { float r[8]; rr[u].get(r);
+        if (res_ss) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e]; }
+          for (int e = 0; e < 8; ++e) v[e] += r[e] * rsc[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e]; } }
       if (act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
@@ -528,10 +537,11 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y,
     }
   }
 }
-extern "C" int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, void* out, unsigned char* mask, long long M, int C, hipStream_t st) {
-  AVEC_CHECK_ARG(y && ss && out && mask && M > 0 && C > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31), "bn_apply_fwd_mask: bad arguments (C %% 8 == 0, M*C < 2^34)");
+extern "C" int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, const float* residual_ss, void* out, unsigned char* mask, long long M, int C,
+                                      hipStream_t st) {
+  AVEC_CHECK_ARG(y && ss && out && mask && M > 0 && C > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31) && (residual || !residual_ss), "bn_apply_fwd_mask: bad arguments (C %% 8 == 0, M*C < 2^34)");
   const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, 2, (T*)out, (unsigned)n8, C, mask));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, 2, (T*)out, (unsigned)n8, C, mask, residual_ss));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t st) {

@@ -1417,16 +1417,20 @@ class ResNetBlockFn(torch.autograd.Function):
             str_ = BNState(Cout, x)
             yr, _, _ = conv2d_fwd(x, convr.weight, N, H, W, Cin, stride, stats=str_.stats if training else None)
             cr = bn_finalize(bnr, str_, Mo, training)
+        use_mask = RELU_BITMASK and training and Cout % 8 == 0 and Cout <= 2048 and Mo * Cout // 8 < (1 << 31)
+        if has_proj and not use_mask:
             r = empty((Mo, Cout), adt, x)
             lib.bn_apply_fwd(rt.dt(), yr.data_ptr(), str_.ss.data_ptr(), None, ACT_NONE, r.data_ptr(), Mo, Cout, rt.stream())
-        else:
+        elif not has_proj:
             r = x
         out = empty((Mo, Cout), adt, x)
         ctx.relu_mask = None
-        if RELU_BITMASK and training and Cout % 8 == 0 and Cout <= 2048 and Mo * Cout // 8 < (1 << 31):
-            # the backward pass needs `out` only as a ReLU mask: one bit per element, written here, instead of re-reading the tensor twice (reduction + apply pass)
+        if use_mask:
+            # the backward pass needs `out` only as a ReLU mask: one bit per element, written here, instead of re-reading the tensor twice (reduction + apply pass);
+            # a projection shortcut is normalised on the fly from its raw convolution output (no tensor, no launch of its own)
             ctx.relu_mask = torch.empty(Mo * Cout // 8, dtype=torch.uint8, device=x.device)
-            lib.bn_apply_fwd_mask(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), out.data_ptr(), ctx.relu_mask.data_ptr(), Mo, Cout, rt.stream())
+            lib.bn_apply_fwd_mask(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), (yr if has_proj else r).data_ptr(), str_.ss.data_ptr() if has_proj else None, out.data_ptr(),
+                                  ctx.relu_mask.data_ptr(), Mo, Cout, rt.stream())
         else:
             lib.bn_apply_fwd(rt.dt(), y2.data_ptr(), st2.ss.data_ptr(), r.data_ptr(), ACT_RELU, out.data_ptr(), Mo, Cout, rt.stream())
         ctx.saved = (x, y1, a1, y2, yr, out, st1, st2, str_, c1, c2, cr, blk, training, N, H, W, Cin, Cout, OH, OW, stride, has_proj)

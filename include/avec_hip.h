@@ -213,8 +213,11 @@ int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* ou
                       const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t stream);
 /* ReLU mask as one bit per element (C % 8 == 0; byte k = elements 8k .. 8k+7 of the row-major matrix, bit e = out[8k + e] > 0): the forward pass of a
  * residual BatchNorm + ReLU (out = relu(y*scale + shift + residual), the end of a ResNet block, nnet/blocks.py ResNetBlock) writes it next to `out`, the
- * backward passes read M*C/8 bytes instead of the whole saved output tensor (act = ReLU implied, otherwise like avec_bn_bwd_reduce / avec_bn_bwd_apply). */
-int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, void* out, unsigned char* mask, long long M, int C, hipStream_t stream);
+ * backward passes read M*C/8 bytes instead of the whole saved output tensor (act = ReLU implied, otherwise like avec_bn_bwd_reduce / avec_bn_bwd_apply).
+ * residual_ss (optional, [scale | shift | ..] of ANOTHER BatchNorm): the residual is that layer's raw input, normalised on the fly -- the projection shortcut
+ * conv1x1 + BatchNorm of a down-sampling block without a tensor of its own: out = relu(y*scale + shift + residual*rscale + rshift). */
+int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, const float* residual_ss, void* out, unsigned char* mask, long long M, int C,
+                           hipStream_t stream);
 int avec_bn_bwd_reduce_mask(int dtype, const void* dout, const void* y, const unsigned char* mask, const float* ss, float* dstats, long long M, int C, hipStream_t stream);
 int avec_bn_bwd_apply_mask(int dtype, const void* dout, const void* y, const unsigned char* mask, const float* ss, const float* gamma, const float* dstats,
                            const float* count_ptr, float count, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t stream);
