@@ -127,6 +127,17 @@ __global__ __launch_bounds__(256) void audio_stem_act_kernel(const T* __restrict
     const int c = (int)((unsigned)(i % (long long)J)) / Fo; stf(a + i, swishf_(ldf(y + i) * ss[c] + ss[C + c]));
   }
 }
+// 8 consecutive frequency bins (one channel) per thread: 16-byte accesses, 32-bit index arithmetic (Fo % 8 == 0, fewer than 2^31 chunks)
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_act8_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ a, unsigned n8, unsigned J8, int Fo, int C) {
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) {
+    const int c = (int)((i % J8) * 8) / Fo; const float sc = ss[c], sh = ss[C + c];
+    Raw8<T> r; r.load(y + (long long)i * 8); float v[8]; r.get(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e] * sc + sh);
+    st8<T>(a + (long long)i * 8, v);
+  }
+}
 // pass 1: dstats[c] += sum dr, dstats[C+c] += sum dr*yhat   with dr = da * swish'(pre)
 template <typename T>
 __global__ __launch_bounds__(256) void audio_stem_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ ss, float* dstats, StemA s) {
@@ -179,7 +190,10 @@ __global__ __launch_bounds__(256) void audio_stem_bwd_params_kernel(const T* __r
 // ---- 8-wide audio stem (Fo % 8 == 0): workgroup = AS_ROWS consecutive output rows (b, to); the 3 mel columns a row touches are staged
 // zero-padded in LDS ([NM + 2][3]), thread = 8 consecutive fo of one channel (one 16-byte store); per-channel sums accumulate in LDS
 // over the block's rows and leave through the two-pass reduction workspace (vec.h) when one is registered.
-static constexpr int AS_ROWS = 16;
+#ifndef AVEC_AS_ROWS
+#define AVEC_AS_ROWS 16
+#endif
+static constexpr int AS_ROWS = AVEC_AS_ROWS;
 __device__ __forceinline__ void stage_mel_patch(float* patch, const float* mel, long long b, int to, const StemA& s) {
   for (int idx = threadIdx.x; idx < (s.NM + 2) * 3; idx += 256) {
     const int fi = idx / 3 - 1, kw = idx - (fi + 1) * 3; const int ti = 2 * to + kw - 1;
@@ -280,6 +294,139 @@ __global__ __launch_bounds__(256) void audio_stem_bwd_params8_kernel(const T* __
   if (ws.partial) { float* mine = ws_slot(ws, 0, blockIdx.x, gridDim.x, 10 * s.C); for (int i = threadIdx.x; i < 10 * s.C; i += 256) mine[i] = lsum[i]; }
   else for (int i = threadIdx.x; i < 10 * s.C; i += 256) { const int q = i / s.C, c = i - q * s.C; if (q < 9) atomicAdd(dw + c * 9 + q, lsum[i]); else if (dbias) atomicAdd(dbias + c, lsum[i]); }
 }
+// ---- the same three passes for chunks <= 4 * 256 (180 channels x 40 bins = 900): a thread OWNS its (up to) four chunks for all rows of the workgroup.  The first
+// version ran ~10x below both the HBM and the VALU time of these passes: every chunk iteration was load -> wait -> ~600 dependent instructions -> 10 LDS atomics,
+// with 1.5 workgroups per CU to hide it.  Here a row's global loads are issued together before any arithmetic, the 51 patch values of a chunk arrive as 13 ds_read_b128
+// (were 72 ds_read_b32), per-chunk constants live in registers, and the per-channel sums stay in registers until the workgroup is through (one LDS atomic per sum).
+constexpr int AS_NIT = 4;
+__device__ __forceinline__ void as_patch51(const float* patch, int fo0, float p[52]) {      // patch rows 2 fo0 .. 2 fo0 + 16 (x 3 taps): 51 contiguous floats, 16-byte aligned
+  const float4* q = (const float4*)(patch + 6 * fo0);
+#pragma unroll
+  for (int k = 0; k < 13; ++k) { const float4 t = q[k]; p[4 * k] = t.x; p[4 * k + 1] = t.y; p[4 * k + 2] = t.z; p[4 * k + 3] = t.w; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_conv8x_kernel(const float* __restrict__ mel, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                T* __restrict__ y, float* stats, StemA s, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float asm_[];
+  float* patch = asm_; float* lsum = patch + (((s.NM + 2) * 3 + 4 + 3) & ~3);             // (+4: the last chunk's 13th float4 reaches one float past the patch)
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  int cc[AS_NIT], fo[AS_NIT]; float wk[AS_NIT][10], s1[AS_NIT], s2[AS_NIT];
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) {
+    const int ch = threadIdx.x + 256 * it; const bool ok = ch < chunks; cc[it] = ok ? ch / F8 : -1; fo[it] = ok ? (ch - cc[it] * F8) * 8 : 0; s1[it] = s2[it] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) wk[it][q] = ok ? (q < 9 ? w[cc[it] * 9 + q] : (bias ? bias[cc[it]] : 0.f)) : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * s.C; i += 256) lsum[i] = 0.f;
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    __syncthreads();
+    stage_mel_patch(patch, mel, b, to, s);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < AS_NIT; ++it) {
+      if (cc[it] < 0) continue;
+      float p[52], acc[8]; as_patch51(patch, fo[it], p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = wk[it][9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) a += wk[it][q] * p[6 * e + q];
+        acc[e] = a; s1[it] += a; s2[it] += a * a;
+      }
+      st8<T>(y + row * J + cc[it] * s.Fo + fo[it], acc);
+    }
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) if (cc[it] >= 0) { atomicAdd(lsum + cc[it], s1[it]); atomicAdd(lsum + s.C + cc[it], s2[it]); }
+  __syncthreads();
+  float* const dst[2] = {stats, stats + s.C}; as_commit(lsum, 2 * s.C, dst, 2, s.C, ws);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_reduce8x_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ ss, float* dstats, StemA s, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float asm_[];
+  float* lsum = asm_;
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  int cc[AS_NIT], off[AS_NIT]; float sc[AS_NIT], sh[AS_NIT], mu[AS_NIT], rs[AS_NIT], s1[AS_NIT], s2[AS_NIT];
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) {
+    const int ch = threadIdx.x + 256 * it; const bool ok = ch < chunks; const int c = ok ? ch / F8 : 0; cc[it] = ok ? c : -1; off[it] = c * s.Fo + (ch - c * F8) * 8;
+    sc[it] = ss[c]; sh[it] = ss[s.C + c]; mu[it] = ss[2 * s.C + c]; rs[it] = ss[3 * s.C + c]; s1[it] = s2[it] = 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * s.C; i += 256) lsum[i] = 0.f;
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    Raw8<T> rd[AS_NIT], rv[AS_NIT];
+#pragma unroll
+    for (int it = 0; it < AS_NIT; ++it) if (cc[it] >= 0) { rd[it].load(da + row * J + off[it]); rv[it].load(y + row * J + off[it]); }
+#pragma unroll
+    for (int it = 0; it < AS_NIT; ++it) {
+      if (cc[it] < 0) continue;
+      float d[8], v[8]; rd[it].get(d); rv[it].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dr = d[e] * dswishf_(v[e] * sc[it] + sh[it]); s1[it] += dr; s2[it] += dr * (v[e] - mu[it]) * rs[it]; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) if (cc[it] >= 0) { atomicAdd(lsum + cc[it], s1[it]); atomicAdd(lsum + s.C + cc[it], s2[it]); }
+  __syncthreads();
+  float* const dst[2] = {dstats, dstats + s.C}; as_commit(lsum, 2 * s.C, dst, 2, s.C, ws);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void audio_stem_bwd_params8x_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ mel, const float* __restrict__ ss,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ dstats, const float* count_ptr, float count,
+                                                                      float* dw, float* dbias, float* dgamma, float* dbeta, StemA s, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float asm_[];
+  float* patch = asm_; float* lsum = patch + (((s.NM + 2) * 3 + 4 + 3) & ~3);             // lsum: [10][C] = 9 taps, then the bias gradient
+  const int J = s.C * s.Fo, F8 = s.Fo >> 3, chunks = s.C * F8; const long long M = (long long)s.B * s.To;
+  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
+  if (blockIdx.x == 0 && dgamma) for (int c = threadIdx.x; c < s.C; c += 256) { atomicAdd(dgamma + c, dstats[s.C + c]); atomicAdd(dbeta + c, dstats[c]); }
+  int cc[AS_NIT], fo[AS_NIT]; float sc[AS_NIT], sh[AS_NIT], mu[AS_NIT], A[AS_NIT], m1[AS_NIT], rm2[AS_NIT], aw[AS_NIT][10];
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) {
+    const int ch = threadIdx.x + 256 * it; const bool ok = ch < chunks; const int c = ok ? ch / F8 : 0; cc[it] = ok ? c : -1; fo[it] = ok ? (ch - c * F8) * 8 : 0;
+    const float rs = ss[3 * s.C + c];
+    sc[it] = ss[c]; sh[it] = ss[s.C + c]; mu[it] = ss[2 * s.C + c]; A[it] = gamma[c] * rs; m1[it] = dstats[c] * inv_n; rm2[it] = rs * dstats[s.C + c] * inv_n;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) aw[it][q] = 0.f;
+  }
+  for (int i = threadIdx.x; i < 10 * s.C; i += 256) lsum[i] = 0.f;
+  for (int rr = 0; rr < AS_ROWS; ++rr) {
+    const long long row = (long long)blockIdx.x * AS_ROWS + rr; if (row >= M) break;
+    const int to = (int)(row % s.To); const long long b = row / s.To;
+    Raw8<T> rd[AS_NIT], rv[AS_NIT];                                  // this row's gradients / conv outputs: requested before the patch is staged
+#pragma unroll
+    for (int it = 0; it < AS_NIT; ++it) if (cc[it] >= 0) { const long long o = row * J + cc[it] * s.Fo + fo[it]; rd[it].load(da + o); rv[it].load(y + o); }
+    __syncthreads();
+    stage_mel_patch(patch, mel, b, to, s);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < AS_NIT; ++it) {
+      if (cc[it] < 0) continue;
+      float d[8], v[8], p[52]; rd[it].get(d); rv[it].get(v); as_patch51(patch, fo[it], p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dr = d[e] * dswishf_(v[e] * sc[it] + sh[it]); const float dy = A[it] * (dr - m1[it] - (v[e] - mu[it]) * rm2[it]);
+        aw[it][9] += dy;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) aw[it][q] += dy * p[6 * e + q];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < AS_NIT; ++it) if (cc[it] >= 0) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) atomicAdd(lsum + q * s.C + cc[it], aw[it][q]);
+  }
+  __syncthreads();
+  if (ws.partial) { float* mine = ws_slot(ws, 0, blockIdx.x, gridDim.x, 10 * s.C); for (int i = threadIdx.x; i < 10 * s.C; i += 256) mine[i] = lsum[i]; }
+  else for (int i = threadIdx.x; i < 10 * s.C; i += 256) { const int q = i / s.C, c = i - q * s.C; if (q < 9) atomicAdd(dw + c * 9 + q, lsum[i]); else if (dbias) atomicAdd(dbias + c, lsum[i]); }
+}
+static bool as8x_ok(const StemA& s) { return s.C * (s.Fo >> 3) <= AS_NIT * 256; }
 static bool as8_ok(const StemA& s) { return s.Fo % 8 == 0 && ((size_t)(s.NM + 2) * 3 + (size_t)s.C * 12) * 4 <= 60 * 1024; }
 static unsigned as8_blocks(const StemA& s) { return (unsigned)(((long long)s.B * s.To + AS_ROWS - 1) / AS_ROWS); }
 static StemA stemA(int B, int NM, int F, int C) { StemA s; s.B = B; s.NM = NM; s.F = F; s.C = C; s.Fo = (NM - 1) / 2 + 1; s.To = (F - 1) / 2 + 1; return s; }
@@ -291,6 +438,10 @@ extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float
   if (as8_ok(s)) {
     const unsigned nb = as8_blocks(s); ColWs ws = stats ? avec_reduce_ws((size_t)nb * 2 * C, st) : ColWs{nullptr};
     const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 12) * 4;
+    static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+    if (as8x_ok(s) && !no_x) { const size_t l2 = ((size_t)(((n_mels + 2) * 3 + 4 + 3) & ~3) + (size_t)C * 2) * 4;
+      DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv8x_kernel<T>, dim3(nb), dim3(256), l2, st, mel, w, bias, (T*)y, stats, s, ws)); }
+    else
     DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv8_kernel<T>, dim3(nb), dim3(256), lds, st, mel, w, bias, (T*)y, stats, s, ws));
     AVEC_LAUNCH_CHECK();
     if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
@@ -302,6 +453,11 @@ extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float
 extern "C" int avec_audio_stem_act_fwd(int dtype, const void* y, const float* ss, void* a, int B, int n_mels, int F, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && a, "audio_stem_act_fwd: null pointer");
   StemA s = stemA(B, n_mels, F, C); long long M = (long long)B * s.To; long long nb = (M * C * s.Fo + 255) / 256; if (nb > 4096) nb = 4096;
+  if (s.Fo % 8 == 0 && M * C * s.Fo / 8 < (1ll << 31)) {
+    const long long n8 = M * C * s.Fo / 8; long long nb8 = (n8 + 255) / 256; if (nb8 > 8192) nb8 = 8192;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_act8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (T*)a, (unsigned)n8, (unsigned)(C * s.Fo / 8), s.Fo, C));
+    AVEC_LAUNCH_CHECK(); return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_act_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)y, ss, (T*)a, M, C * s.Fo, s.Fo, C));
   AVEC_LAUNCH_CHECK(); return 0;
 }
@@ -314,12 +470,20 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
     const unsigned nb = as8_blocks(s);
     if (phase == 0) {
       ColWs ws = avec_reduce_ws((size_t)nb * 2 * C, st);
+      static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+      if (as8x_ok(s) && !no_x) DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8x_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
+      else
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
       AVEC_LAUNCH_CHECK();
       if (ws.partial) { float* const dst[2] = {dstats, dstats + C}; return col_finalize(ws, 1, nb, 2, C, dst, C, st); }
     } else {
       ColWs ws = avec_reduce_ws((size_t)nb * 10 * C, st);
       const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 10) * 4;
+      static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+      if (as8x_ok(s) && !no_x) { const size_t l2 = ((size_t)(((n_mels + 2) * 3 + 4 + 3) & ~3) + (size_t)C * 10) * 4;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params8x_kernel<T>, dim3(nb), dim3(256), l2, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count,
+                                             dw, dbias, dgamma, dbeta, s, ws)); }
+      else
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params8_kernel<T>, dim3(nb), dim3(256), lds, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count,
                                            dw, dbias, dgamma, dbeta, s, ws));
       AVEC_LAUNCH_CHECK();

@@ -480,15 +480,6 @@ static inline unsigned bn8_blocks(long long n8, int C, unsigned cap) {
   nb = nb / q * q; if (nb < q) nb = q;
   return (unsigned)nb;
 }
-__device__ __forceinline__ void bf8_to_f32(const uint4& t, float v[8]) {
-  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
-}
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16> { uint4 t; __device__ __forceinline__ void load(const bf16* p) { t = *(const uint4*)p; } __device__ __forceinline__ void get(float v[8]) const { bf8_to_f32(t, v); } };
-template <> struct Raw8<float> { float4 a, b; __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
-  __device__ __forceinline__ void get(float v[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; } };
 constexpr int BN8_U = 2;        // chunks in flight per thread in the element-wise passes
 constexpr int BN8_UR = 1;       // ... in the reduction pass (2 measured 4-6 % slower there)
 
