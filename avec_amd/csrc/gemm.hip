@@ -860,6 +860,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
   const int K = g.K, KT = (K + KE - 1) / KE, KF = K / KE;
   // DMA plan: pass i, thread tid -> tile row tid/8 + 32 i, physical slot tid%8 carrying logical K-chunk (tid%8) ^ swz(row)
   unsigned aoff[NCA], boff[NCB]; int kca, kcb[NCB];
+  unsigned lastrow = 0;                                              // bit i / bit 8 + i: DMA pass i of A / W fetches the LAST row of its matrix (K = 8n + 4 only, see below)
   kca = 0;
 #pragma unroll
   for (int i = 0; i < NCA; ++i) {
@@ -867,13 +868,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
     const int kc = (tid & 7) ^ glds_swz<RB>(row);
     aoff[i] = (unsigned)((row_info<MODE_PLAIN>(g.a, m, g.M).base + kc * 8) * 2);
     if (i == 0) kca = kc;                                            // (rows 32 apart share the swizzle)
+    if (m == g.M - 1) lastrow |= 1u << i;
   }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
     const int row = (tid >> 3) + i * 32; const int n = n0 + row < g.N ? n0 + row : g.N - 1;
     kcb[i] = (tid & 7) ^ glds_swz<RB>(row);
     boff[i] = (unsigned)(((long long)n * g.ldw + kcb[i] * 8) * 2);
+    if (n == g.N - 1) lastrow |= 256u << i;
   }
+  // K = 8n + 4 (the 180- / 540-wide audio stage): the chunk that holds elements K-4 .. K-1 also holds 4 elements of the next row -- zeroed in LDS once the last tile has
+  // landed (step()); the last row of a matrix fetches that chunk 8 bytes early (nothing is read behind the matrix) and its upper half is moved down first
+  const bool ktail = g.ktail != 0;
   const char* const Ab = (const char*)g.a.ptr; const char* const Wb = (const char*)g.W;
   auto issue = [&](const int kt, auto stagec) {
     constexpr int S = decltype(stagec)::value;
@@ -882,9 +888,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
     if (kt < KF) { glds16_group<NCA>(aoff, Ab + (long long)kt * (KE * 2), la); glds16_group<NCB>(boff, Wb + (long long)kt * (KE * 2), lb); }
     else {                                                           // the partial last tile: chunks at or beyond K come from the zero page
 #pragma unroll
-      for (int i = 0; i < NCA; ++i) glds16_v64(kt * KE + kca * 8 < K ? (const void*)(Ab + aoff[i] + (long long)kt * (KE * 2)) : (const void*)avec_zero16, la + i * 4096);
+      for (int i = 0; i < NCA; ++i) {
+        const int k0 = kt * KE + kca * 8; const long long early = (ktail && k0 + 8 > K && ((lastrow >> i) & 1u)) ? 8 : 0;
+        glds16_v64(k0 < K ? (const void*)(Ab + aoff[i] + (long long)kt * (KE * 2) - early) : (const void*)avec_zero16, la + i * 4096);
+      }
 #pragma unroll
-      for (int i = 0; i < NCB; ++i) glds16_v64(kt * KE + kcb[i] * 8 < K ? (const void*)(Wb + boff[i] + (long long)kt * (KE * 2)) : (const void*)avec_zero16, lb + i * 4096);
+      for (int i = 0; i < NCB; ++i) {
+        const int k0 = kt * KE + kcb[i] * 8; const long long early = (ktail && k0 + 8 > K && ((lastrow >> (8 + i)) & 1u)) ? 8 : 0;
+        glds16_v64(k0 < K ? (const void*)(Wb + boff[i] + (long long)kt * (KE * 2) - early) : (const void*)avec_zero16, lb + i * 4096);
+      }
     }
   };
   // fragment addresses inside a tile: K-substep q reads logical chunk 2 q + g of its row; A fragment i adds 4096 i (32 rows), the ring stage S * TILE
@@ -913,6 +925,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
     if (rem >= 2) AVEC_WAIT_VM(2 * LPT); else if (rem == 1) AVEC_WAIT_VM(LPT); else AVEC_WAIT_VM(0);
     if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (ktail && kt == KT - 1) {                                     // (workgroup-uniform; nothing is in flight: vmcnt(0) above)
+      if (tid < BM + BN) {
+        const int row = tid < BM ? tid : tid - BM; const int ctail = ((K - 4) % KE) >> 3;
+        char* p = smem + S * TILE + (tid < BM ? 0 : BM * RB) + row * RB + ((ctail ^ glds_swz<RB>(row)) << 4);
+        const bool last = tid < BM ? (m0 + row >= g.M - 1) : (n0 + row >= g.N - 1);
+        if (last) *(uint2*)p = *(const uint2*)(p + 8);
+        *(uint2*)(p + 8) = make_uint2(0u, 0u);
+      }
+      __syncthreads();
+    }
     u32x4 fa[KK][MT], fb[KK];
 #pragma unroll
     for (int q = 0; q < KK; ++q) {
@@ -1609,7 +1631,8 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   if constexpr (sizeof(T) == 2 && BN == 64 && BM == 64) {       // (128 x 64 with the 4-stage ring leaves one workgroup per CU: slower than the general kernel's 2-stage ring)
     // the lean plain kernel: whole 16-byte K-chunks, 32-bit byte offsets into both operands
     const long long arows = g.a.step > 1 ? (g.M / (g.a.rows_out > 0 ? g.a.rows_out : 1) + 1) * (long long)g.a.rows_in : g.M;
-    if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && g.K % 8 == 0 && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K && !g.ktail &&
+    static const bool no_lean_tail = getenv("AVEC_NO_LEAN_KTAIL") != nullptr;
+    if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && (g.K % 8 == 0 || (g.ktail && !no_lean_tail)) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
         arows * g.a.ld * 2 < (1ll << 32) && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
       const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
       avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
@@ -1706,7 +1729,7 @@ static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
   // plain bf16 products with whole 16-byte K-chunks: the lean 64 x 64 kernel beats the general 128 x 64 one up to the sizes the model has (3200 x 1024 x 256: 11.3 vs 11.8 us)
   static const bool no_lean = getenv("AVEC_NO_LEAN_NT") != nullptr;
-  const bool lean = sizeof(T) == 2 && mode == MODE_PLAIN && !src_f32 && !no_lean && g.K % 8 == 0 && ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 4096;
+  const bool lean = sizeof(T) == 2 && mode == MODE_PLAIN && !src_f32 && !no_lean && g.K % 8 == 0 && ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 4096;      // (K = 8n + 4 with many tiles: the general 128 x 64 kernel is faster, 14.3 vs 16.0 us at 6400 x 720 x 180; the lean kernel takes those shapes only where 64 x 64 tiles are chosen anyway)
   if (!lean && ((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
   return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
 }

@@ -288,7 +288,9 @@ def test_shadow_refresh_range_equals_full_refresh():
         avec_amd.set_compute_dtype("f32")
 
 
-@pytest.mark.parametrize("M,N,K,kind", [(333, 200, 360, "res"), (70, 64, 72, "plain"), (1000, 1440, 1440, "ffn1"), (800, 360, 1440, "res"), (129, 65, 8, "plain"), (64, 64, 64, "plain")])
+@pytest.mark.parametrize("M,N,K,kind", [(333, 200, 360, "res"), (70, 64, 72, "plain"), (1000, 1440, 1440, "ffn1"), (800, 360, 1440, "res"), (129, 65, 8, "plain"), (64, 64, 64, "plain"),
+                                          # K = 8n + 4 (the 180- / 540-wide audio stage): the chunk behind a row's last 4 elements is fixed up in LDS, the last row of each matrix fetches it early
+                                          (799, 180, 180, "ffn1"), (399, 180, 180, "res"), (1613, 540, 180, "plain"), (250, 180, 540, "res"), (64, 64, 12, "plain"), (65, 129, 68, "plain")])
 def test_lean_plain_product_matches_fp32_math(M, N, K, kind):
     """gemm_nt_plain_kernel<64,64> (the conformer-sized products): ragged M / N (clamped rows, unstored columns), K that is not a multiple of the 64-wide K tile
     (partial last tile from the zero page), every epilogue the conformer uses -- against fp32 math on the same bf16 operands"""
