@@ -145,6 +145,89 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   }
 }
 
+// Both halves of the backward pass in ONE launch (stride 1: every conformer block but the two stage boundaries): the workgroup of the weight-gradient kernel also
+// stages the dc rows its 32 frames can see (K - 1 rows of halo, fp32, zero outside the sequence) and produces du for those frames -- one launch, one pass over u and dc
+// instead of two (the input-gradient kernel re-read K dc rows per element from L2).  LDS: (31 + K) x 128 floats twice.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_glu_bwd_fused_kernel(const T* __restrict__ dc, const T* __restrict__ u, const float* __restrict__ w, T* __restrict__ du, float* dw, float* dbias,
+                                                                   int B, int Tn, int C, int K, int padl, int nchunks, ColWs ws) {
+  extern __shared__ __attribute__((aligned(16))) float gs[];
+  const int NR = DW_TT - 1 + K;
+  float* const ds = gs + NR * 128;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
+  const int b = blockIdx.y / nchunks, t0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, Tn - t0);
+  stage_glu<T>(gs, u, b, Tn, C, col, t0 - padl, nto - 1 + K);
+  {                                                            // dc rows of frames t0 + padl - (K - 1) + j, j < nto - 1 + K
+    const int f0 = t0 + padl - (K - 1), nrows = nto - 1 + K, cc = col < C ? col : 0;
+    for (int r0 = ty; r0 < nrows; r0 += 48) {
+      float d[6][4];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int r = r0 + 8 * q, f = f0 + r; const bool ok = r < nrows && col < C && f >= 0 && f < Tn;
+        ld4<T>(dc + ((long long)b * Tn + (ok ? f : 0)) * C + cc, d[q]);
+        if (!ok) d[q][0] = d[q][1] = d[q][2] = d[q][3] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const int r = r0 + 8 * q; if (r < nrows) *(float4*)(ds + r * 128 + tx * 4) = make_float4(d[q][0], d[q][1], d[q][2], d[q][3]); }
+    }
+  }
+  __syncthreads();
+  float part[KMAX + 1][4];
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k) for (int e = 0; e < 4; ++e) part[k][e] = 0.f;
+  if (col < C) {
+    float ww[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { if (k < K) ld4<float>(w + (long long)k * C + col, ww[k]); else ww[k][0] = ww[k][1] = ww[k][2] = ww[k][3] = 0.f; }
+    const int own = K - 1 - padl;                              // ds row of this chunk's frame 0
+#pragma unroll
+    for (int q = 0; q < DW_TT / 8; ++q) {
+      const int r = ty + 8 * q;
+      if (r >= nto) break;
+      const long long row = (long long)b * Tn + t0 + r;
+      float a[4], bq[4]; ld4<T>(u + row * 2 * C + col, a); ld4<T>(u + row * 2 * C + C + col, bq);      // (requested before the tap loop: L2 hits, the staging pass has just read them)
+      const float4 dq = *(const float4*)(ds + (own + r) * 128 + tx * 4);
+      part[KMAX][0] += dq.x; part[KMAX][1] += dq.y; part[KMAX][2] += dq.z; part[KMAX][3] += dq.w;
+      float dg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const float4 g = *(const float4*)(gs + (r + k) * 128 + tx * 4);
+          part[k][0] += dq.x * g.x; part[k][1] += dq.y * g.y; part[k][2] += dq.z * g.z; part[k][3] += dq.w * g.w;
+          const float4 dd = *(const float4*)(ds + (r + K - 1 - k) * 128 + tx * 4);
+          dg[0] += ww[k][0] * dd.x; dg[1] += ww[k][1] * dd.y; dg[2] += ww[k][2] * dd.z; dg[3] += ww[k][3] * dd.w;
+        }
+      }
+      float o1[4], o2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float sg = sigmoidf_(bq[e]); o1[e] = dg[e] * sg; o2[e] = dg[e] * a[e] * sg * (1.f - sg); }
+      st4<T>(du + row * 2 * C + col, o1); st4<T>(du + row * 2 * C + C + col, o2);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[k][e] += __shfl_xor(part[k][e], 32, 64);
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) *(float4*)(gs + ((wv * (KMAX + 1) + k) * 32 + tx) * 4) = make_float4(part[k][0], part[k][1], part[k][2], part[k][3]);
+  }
+  __syncthreads();
+  float* mine = ws.partial ? ws_slot(ws, blockIdx.x, blockIdx.y, gridDim.y, (KMAX + 1) * 128) : nullptr;
+  for (int i = threadIdx.x; i < (KMAX + 1) * 128; i += 256) {
+    const int k = i >> 7, c = i & 127;
+    const float v = gs[(0 * (KMAX + 1) + k) * 128 + c] + gs[(1 * (KMAX + 1) + k) * 128 + c] + gs[(2 * (KMAX + 1) + k) * 128 + c] + gs[(3 * (KMAX + 1) + k) * 128 + c];
+    if (mine) mine[i] = v;
+    else {
+      const int cc = blockIdx.x * 128 + c;
+      float* d = k == KMAX ? dbias : (k < K ? dw + (long long)k * C : nullptr);
+      if (d && cc < C) atomicAdd(d + cc, v);
+    }
+  }
+}
+
 extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
                                    int B, int T_, int C, int K, int stride, int pad_left, hipStream_t st) {
   AVEC_CHECK_ARG(u && w && out && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0 && pad_left >= 0 && pad_left < K, "glu_dwconv_fwd: bad arguments (C=%d K=%d pad_left=%d)", C, K, pad_left);
@@ -168,6 +251,11 @@ extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, con
   size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   if (lds < (size_t)4 * (KMAX + 1) * 128 * sizeof(float)) lds = (size_t)4 * (KMAX + 1) * 128 * sizeof(float);      // the reduction image of the weight-gradient kernel
   AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
+  static const bool no_fused = getenv("AVEC_NO_DWCONV_FUSED_BWD") != nullptr;
+  if (stride == 1 && !no_fused) {
+    size_t l2 = (size_t)2 * (DW_TT - 1 + K) * 128 * sizeof(float); if (l2 < lds) l2 = lds;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_fused_kernel<T>, grid, dim3(256), l2, st, (const T*)dc, (const T*)u, w, (T*)du, dw, dbias, B, T_, C, K, pad_left, nchunks, ws));
+  } else
   DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)dc, (const T*)u, w, (T*)du, B, T_, C, K, stride, To, pad_left);
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, grid, dim3(256), lds, st, (const T*)dc, (const T*)u, dw, dbias, B, T_, C, K, stride, To, pad_left, nchunks, ws));
   AVEC_LAUNCH_CHECK();

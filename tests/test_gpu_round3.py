@@ -408,3 +408,42 @@ def test_bn_relu_bitmask_kernels_match_the_out_reading_kernels(proj):
         assert rel_err(ds0, ds1) < 1e-6 and torch.equal(dy0, dy1) and torch.equal(dr0, dr1)
     finally:
         avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,K,stride,causal,dtype", [(3, 57, 144, 15, 1, False, "f32"), (2, 100, 256, 15, 1, False, "bf16"), (2, 33, 180, 15, 1, True, "f32"), (2, 70, 64, 7, 1, False, "f32"),
+                                                         (2, 41, 144, 15, 2, False, "f32")])
+def test_glu_depthwise_conv_backward_matches_torch(B, T, C, K, stride, causal, dtype):
+    """avec_glu_dwconv_fwd / avec_dwconv_glu_bwd (GLU + depthwise Conv1d of the conformer convolution module; stride 1 = the one-launch backward kernel, stride 2 = the two
+    kernels) against torch autograd in fp64: output, input gradient, weight and bias gradients; "same" and causal padding, a last chunk shorter than 32 frames"""
+    import avec_amd
+    from avec_amd import ops, runtime as rt
+    avec_amd.set_compute_dtype(dtype)
+    try:
+        d = dev()
+        g = torch.Generator().manual_seed(B * T + C)
+        adt = rt.act_dtype()
+        u = torch.randn(B, T, 2 * C, generator=g).to(adt).to(d)
+        w = (torch.randn(K, C, generator=g) * 0.3).to(d)                 # tap-major [K][C]
+        bias = torch.randn(C, generator=g).to(d)
+        padl = K - 1 if causal else K // 2
+        To = (T - 1) // stride + 1
+        out = torch.empty(B * To, C, dtype=adt, device=d)
+        dc = torch.randn(B * To, C, generator=g).to(adt).to(d)
+        du = torch.empty(B * T, 2 * C, dtype=adt, device=d)
+        dw, db = torch.full((K, C), 0.5, device=d), torch.full((C,), -0.25, device=d)
+        lib = ops.lib
+        lib.glu_dwconv_fwd(rt.dt(), u.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), None, B, T, C, K, stride, padl, rt.stream())
+        lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), w.data_ptr(), du.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, C, K, stride, padl, rt.stream())
+        torch.cuda.synchronize()
+        ur = u.double().requires_grad_(True); wr = w.double().requires_grad_(True); br = bias.double().requires_grad_(True)
+        gl = torch.nn.functional.glu(ur, dim=-1).transpose(1, 2)                      # (B, C, T)
+        gp = torch.nn.functional.pad(gl, (padl, K - 1 - padl))
+        y = torch.nn.functional.conv1d(gp, wr.t().unsqueeze(1), br, stride=stride, groups=C)[:, :, :To].transpose(1, 2)
+        y.backward(dc.double().view(B, To, C))
+        tol = 1e-2 if dtype == "bf16" else 1e-5
+        assert rel_err(out.double().view(B, To, C), y.detach()) < tol
+        assert rel_err(du.double().view(B, T, 2 * C), ur.grad) < (2e-2 if dtype == "bf16" else 1e-5)
+        assert rel_err(dw.double() - 0.5, wr.grad) < 1e-3 and rel_err(db.double() + 0.25, br.grad) < 1e-3
+    finally:
+        avec_amd.set_compute_dtype("f32")
