@@ -211,13 +211,20 @@ __global__ __launch_bounds__(256) void ln_param_grads_grouped_kernel(LnGroup grp
   const int m0 = (w - t.first) * LNG_ROWS; int m1 = m0 + LNG_ROWS; if (m1 > t.M) m1 = t.M;
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
   if (r < R) {
-    for (int m = m0 + r; m < m1; m += R) {
-      float d[4], v[4];
-      if (t.dy_f32) ld4<float>((const float*)t.dy + (long long)m * D + l * 4, d); else ld4<bf16>((const bf16*)t.dy + (long long)m * D + l * 4, d);
-      ld4<float>(t.x + (long long)m * D + l * 4, v);
-      const float mu = t.mean[m], rs = t.rstd[m];
+    constexpr int U = 8;                         // rows in flight per thread: one row at a time is one load latency per row (32 of them per workgroup at D = 256: 57 us per launch)
+    for (int m = m0 + r; m < m1; m += R * U) {
+      float d[U][4], v[U][4], mu[U], rs[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pg[e] += d[e] * (v[e] - mu) * rs; pb[e] += d[e]; }
+      for (int u = 0; u < U; ++u) {
+        const int mm = m + u * R; const bool ok = mm < m1; const long long mi = ok ? mm : m;
+        if (t.dy_f32) ld4<float>((const float*)t.dy + mi * D + l * 4, d[u]); else ld4<bf16>((const bf16*)t.dy + mi * D + l * 4, d[u]);
+        ld4<float>(t.x + mi * D + l * 4, v[u]); mu[u] = t.mean[mi]; rs[u] = ok ? t.rstd[mi] : 0.f;
+        if (!ok) d[u][0] = d[u][1] = d[u][2] = d[u][3] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pg[e] += d[u][e] * (v[u][e] - mu[u]) * rs[u]; pb[e] += d[u][e]; }
     }
   }
 #pragma unroll
