@@ -140,6 +140,9 @@ struct Epi {
   int res_cls0;                    // parity-class order: `res` has one row per class-0 pixel (class-local index), none for the other classes
 };
 
+#ifndef AVEC_TN_BUILTIN_DMA
+#define AVEC_TN_BUILTIN_DMA 0
+#endif
 // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): id w runs on XCD w % 8.  xcd_logical() gives XCD x the CONTIGUOUS range of
 // logical ids [x*q + min(x, r), ...) (q = total / 8, r = total % 8), so that workgroups with neighbouring logical ids -- the tiles that share a reduction
 // slice of both operands -- fill ONE L2 instead of eight.
@@ -1430,13 +1433,43 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const 
   }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // Plain products send their DMA through inline asm: behind the builtin the compiler drains the queue (s_waitcnt vmcnt(0), visible in the ISA of this loop) in front of
+  // the first transposed read it cannot prove disjoint, i.e. right behind the prefetch of the next tile (DESIGN.md 17.2 rule 3); completion is counted by hand below
+  // (AVEC_WAIT_VM).  The gathered (convolution) operand keeps the builtin: measured 131 / 170 / 244 us against 165 / 179 / 255 us with the asm form on the three
+  // stride-2 weight gradients -- its per-lane address arithmetic schedules worse around the asm blocks than it gains from the overlap.
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  auto tn_dma = [&](const void* src, unsigned off) {
+    if (!Q_CONV && !(AVEC_TN_BUILTIN_DMA)) glds16_v64(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + off)));
+    else __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + off), 16, 0, 0);
+  };
+  // plain products, whole tiles: scalar base (first row of the tile) + per-lane 32-bit offsets fixed at entry, one M0 save / restore per operand (glds16_group) --
+  // the per-lane 64-bit address arithmetic of the general path below (~25 instructions per DMA, 8 DMAs per tile) was most of what a wave issued between two
+  // groups of MFMAs.  Lanes beyond the operand's width fetch the tile's first column instead of the zero page: whatever they load only reaches result rows /
+  // columns that are not stored.  The last, partial tile (rows >= me must be ZERO) and strided rows take the general path.
+  unsigned poff[NLI], qoff[NLJ];
+  bool lean = false;
+  if constexpr (!Q_CONV) {
+    lean = g.q.step <= 1 && !(AVEC_TN_BUILTIN_DMA);
+#pragma unroll
+    for (int u = 0; u < NLI; ++u) poff[u] = (unsigned)(((long long)(prow0 + u * RI) * g.ldp + (pok ? pcol : i0)) * 2);
+#pragma unroll
+    for (int u = 0; u < NLJ; ++u) qoff[u] = (unsigned)(((long long)(qrow0 + u * RJ) * g.q.ld + (qok ? qcol : j0)) * 2);
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](long long mt0, int buf) {
-    char* Ps = smem + buf * TILE; char* Qs = Ps + PBYTES;
+    if constexpr (!Q_CONV) {
+      if (lean && mt0 + KT <= me) {
+        const unsigned l0 = lds0 + (unsigned)(buf * TILE) + (unsigned)wave_u * 1024u;
+        glds16_group<NLI>(poff, (const char*)Pp + mt0 * g.ldp * 2, l0);
+        glds16_group<NLJ>(qoff, (const char*)Qp + mt0 * g.q.ld * 2, l0 + PBYTES);
+        return;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < NLI; ++u) {
       const long long m = mt0 + prow0 + u * RI;
       const void* src = (pok && m < me) ? (const void*)(Pp + m * g.ldp + pcol) : (const void*)avec_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ps + (u * 256 + wave * 64) * 16), 16, 0, 0);
+      tn_dma(src, (unsigned)(buf * TILE + (u * 256 + wave * 64) * 16));
     }
 #pragma unroll
     for (int u = 0; u < NLJ; ++u) {
@@ -1454,7 +1487,7 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const 
         if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
         src = (qok && m < me) ? (const void*)(Qp + row * g.q.ld + qcol) : src;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Qs + (u * 256 + wave * 64) * 16), 16, 0, 0);
+      tn_dma(src, (unsigned)(buf * TILE + PBYTES + (u * 256 + wave * 64) * 16));
     }
   };
   // fragment addressing: lane = (16-lane group g4, t); operand row/col 16*(g4&1) + t of the 32-wide block, k-group g4>>1; read h fetches
@@ -1963,13 +1996,14 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
   grp.total = first;
   static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr;
   grp.xcd_map = no_xcd ? 0 : 1;
-  static const int kt_env = getenv("AVEC_TNG_KT") ? atoi(getenv("AVEC_TNG_KT")) : 64;       // 64 reduction rows per tile: half the barriers of 32 (isolated -12 %, in the step -0.1 ms);
-  const int KT = kt_env == 32 ? 32 : 64;                                                    // rings of 3 / 4 stages change nothing (measured with tools/bench_tn_grouped.py: the loop is not latency-bound)
-  const size_t lds = (size_t)2 * KT * (BT + BT) * 2;
-  avec_note_kernel("gemm_tn_tr_grouped_kernel<%d,2,%d>", BT, KT);
-#define TNG(BT_, K_) do { if (BT == BT_ && KT == K_) { if (int r = want_lds(gemm_tn_tr_grouped_kernel<BT_, 2, K_>, lds)) return r; \
-    hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<BT_, 2, K_>), dim3((unsigned)first), dim3(256), lds, stream, grp); } } while (0)
-  TNG(128, 32); TNG(128, 64); TNG(64, 32); TNG(64, 64);
+  static const int kt_env = getenv("AVEC_TNG_KT") ? atoi(getenv("AVEC_TNG_KT")) : 64;       // reduction rows per LDS tile
+  static const int stg_env = getenv("AVEC_TNG_STAGES") ? atoi(getenv("AVEC_TNG_STAGES")) : 2;
+  const int KT = kt_env == 32 ? 32 : 64, STG = (stg_env == 4 && KT == 32) ? 4 : 2;       // (2 x 64 rows and 4 x 32 rows measure the same, 3 stages are slower: profiles/r03_tn_grouped.txt)
+  const size_t lds = (size_t)STG * KT * (BT + BT) * 2;
+  avec_note_kernel("gemm_tn_tr_grouped_kernel<%d,%d,%d>", BT, STG, KT);
+#define TNG(BT_, S_, K_) do { if (BT == BT_ && STG == S_ && KT == K_) { if (int r = want_lds(gemm_tn_tr_grouped_kernel<BT_, S_, K_>, lds)) return r; \
+    hipLaunchKernelGGL((gemm_tn_tr_grouped_kernel<BT_, S_, K_>), dim3((unsigned)first), dim3(256), lds, stream, grp); } } while (0)
+  TNG(128, 2, 32); TNG(128, 2, 64); TNG(64, 2, 32); TNG(64, 2, 64); TNG(128, 4, 32); TNG(64, 4, 32);
 #undef TNG
   AVEC_LAUNCH_CHECK();
   return 0;
