@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void mma_tile_swz(const char* As, const char* Bs, int
 }
 
 template <typename T, int BI, int BJ, int MODE, bool Q_F32, bool A16>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
+__device__ __forceinline__ void gemm_tn_body(TnArgs g, const int bx, const int by, const int bz) {
   constexpr int VEC = Elt<T>::VEC;
   constexpr int RPT = sizeof(T) == 2 ? 2 : 1;   // reduction rows per task (bf16: a pair packed into one 32-bit LDS word)
   constexpr int KE = 32 * RPT;                  // reduction rows (m) per tile = 128 bytes of LDS row
@@ -1280,8 +1280,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-  const int zb = blockIdx.z / g.split, zs = blockIdx.z - zb * g.split;
+  const int i0 = bx * BI, j0 = by * BJ;
+  const int zb = bz / g.split, zs = bz - zb * g.split;
   const long long bo = zb / g.nb_inner, bi = zb - bo * g.nb_inner;
   g.P = (const T*)g.P + bo * g.sPo + bi * g.sPi;
   g.q.ptr = (Q_F32 && sizeof(T) == 2) ? (const void*)((const float*)g.q.ptr + bo * g.sQo + bi * g.sQi) : (const void*)((const T*)g.q.ptr + bo * g.sQo + bi * g.sQi);
@@ -1372,6 +1372,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
         if (row < g.I) { if (Oact) stf(Oact + (long long)row * g.ldo + col, acc[i][j][r]); else atomicAdd(g.O + (long long)row * g.ldo + col, acc[i][j][r]); }
       }
   }
+}
+
+template <typename T, int BI, int BJ, int MODE, bool Q_F32, bool A16>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) { gemm_tn_body<T, BI, BJ, MODE, Q_F32, A16>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Up to three independent batched products of the small-tile kind in ONE launch (dK, dV and dE of an attention layer's backward pass: three launches of ~5 us each
+// on 50-400 workgroups): workgroup w belongs to the problem whose [first, first + count) range contains it.
+#define AVEC_TN_MULTI_MAX 3
+struct TnMulti { TnArgs g[AVEC_TN_MULTI_MAX]; int first[AVEC_TN_MULTI_MAX + 1], gx[AVEC_TN_MULTI_MAX], gy[AVEC_TN_MULTI_MAX], n; };
+__global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti m) {
+  const int w = blockIdx.x;
+  int p = 0; if (m.n > 1 && w >= m.first[1]) p = 1; if (m.n > 2 && w >= m.first[2]) p = 2;
+  int l = w - m.first[p]; const int bx = l % m.gx[p]; l /= m.gx[p];
+  gemm_tn_body<bf16, 64, 64, MODE_PLAIN, false, false>(m.g[p], bx, l % m.gy[p], l / m.gy[p]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1840,6 +1854,7 @@ extern "C" int avec_gemm_nt_fp8(const void* A, long long lda, const void* W, lon
   return 0;
 }
 
+static thread_local TnMulti* tn_collect = nullptr;      // set while avec_gemm_tn_batched_multi gathers its problems
 template <typename T, int BI, int BJ>
 static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t st) {
   constexpr int KE = BKB / (int)sizeof(T);
@@ -1883,6 +1898,11 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
     if (int r = colsum_launch(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, !side_wgrad, st)) return r;
   }     // kernels without the fused column sums
 #define L(MODE, F, A) do { avec_note_kernel("gemm_tn_kernel<%s,%d,%d,%d,%d,%d>", (sizeof(T) == 2 ? "bf16" : "float"), BI, BJ, MODE, (int)F, (int)A); if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
+  if (tn_collect && sizeof(T) == 2 && BI == 64 && BJ == 64 && mode == MODE_PLAIN && !f32src && !a16 && !g.pcs && tn_collect->n < AVEC_TN_MULTI_MAX) {
+    TnMulti& m = *tn_collect; const int k = m.n++;           // (avec_gemm_tn_batched_multi: this problem joins the common launch)
+    m.g[k] = g; m.gx[k] = (int)grid.x; m.gy[k] = (int)grid.y; m.first[k + 1] = m.first[k] + (int)(grid.x * grid.y * grid.z);
+    return 0;
+  }
   if (mode == MODE_PLAIN) {
     if (f32src) { if (a16) L(MODE_PLAIN, true, true); else L(MODE_PLAIN, true, false); }
     else { if (a16) L(MODE_PLAIN, false, true); else L(MODE_PLAIN, false, false); }
@@ -1949,6 +1969,30 @@ extern "C" int avec_gemm_tn_batched_store(int dtype, const void* P, long long ld
   avec_rows_t rows = {}; rows.ld = ldq;
   AVEC_CHECK_ARG(strides6 && O_act, "gemm_tn_batched_store: null pointer");
   return gemm_tn_impl(dtype, P, ldp, Q, &rows, MODE_PLAIN, 0, nullptr, O_act, ldo, M, I, J, nb_outer, nb_inner, strides6, nullptr, stream);
+}
+
+extern "C" int avec_gemm_tn_batched_multi(int dtype, const avec_tn_batched_t* items, int n, hipStream_t stream) {
+  AVEC_CHECK_ARG(items && n >= 1 && n <= AVEC_TN_MULTI_MAX, "gemm_tn_batched_multi: need 1..%d problems (got %d)", AVEC_TN_MULTI_MAX, n);
+  static const bool off = getenv("AVEC_NO_TN_MULTI") != nullptr;
+  TnMulti m; m.n = 0; m.first[0] = 0;
+  if (!off) tn_collect = &m;
+  int rc = 0;
+  for (int k = 0; k < n && rc == 0; ++k) {               // a problem that does not take the common small-tile kernel is launched on its own right here
+    const avec_tn_batched_t& t = items[k];
+    avec_rows_t rows = {}; rows.ld = t.ldq;
+    if (!t.strides6 || (!t.O && !t.O_act)) { avec_set_error("gemm_tn_batched_multi: problem %d: null pointer", k); rc = -1; break; }
+    rc = gemm_tn_impl(dtype, t.P, t.ldp, t.Q, &rows, MODE_PLAIN, 0, t.O_act ? nullptr : t.O, t.O_act, t.ldo, t.M, t.I, t.J, t.nb_outer, t.nb_inner, t.strides6, nullptr, stream);
+  }
+  tn_collect = nullptr;
+  if (rc) return rc;
+  if (m.n > 0) {
+    const size_t lds = (size_t)2 * (64 + 64) * LDS_ROW;
+    avec_note_kernel("gemm_tn_multi_kernel<%d>", m.n);
+    if (int r = want_lds(gemm_tn_multi_kernel, lds)) return r;
+    hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3((unsigned)m.first[m.n]), dim3(256), lds, stream, m);
+    AVEC_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 // ---- grouped weight gradients -------------------------------------------------------------------------------------------------------------

@@ -54,6 +54,14 @@ class TnItem(ctypes.Structure):
                 ("reserved", ctypes.c_int)]
 
 
+class TnBatched(ctypes.Structure):
+    """avec_tn_batched_t"""
+    _fields_ = [("P", ctypes.c_void_p), ("ldp", ctypes.c_longlong), ("Q", ctypes.c_void_p), ("ldq", ctypes.c_longlong),
+                ("O", ctypes.c_void_p), ("O_act", ctypes.c_void_p), ("ldo", ctypes.c_longlong),
+                ("M", ctypes.c_longlong), ("I", ctypes.c_int), ("J", ctypes.c_int), ("nb_outer", ctypes.c_int), ("nb_inner", ctypes.c_int),
+                ("strides6", ctypes.POINTER(ctypes.c_longlong))]
+
+
 class LnItem(ctypes.Structure):
     """avec_ln_item_t"""
     _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("dgamma", ctypes.c_void_p),

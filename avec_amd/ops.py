@@ -10,7 +10,7 @@ import torch
 
 from . import fp8
 from . import runtime as rt
-from .lib import (ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, WGRAD_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnItem,
+from .lib import (ACT_NONE, ACT_RELU, ACT_SWISH, BF16, LN_GROUP_MAX, ROWS_CONV_BWD, ROWS_CONV_FWD, ROWS_PLAIN, ROWS_STEM3D, TN_GROUP_MAX, WGRAD_GROUP_MAX, Attn, Epilogue, LnItem, Rows, TnBatched, TnItem,
                   WgradItem, lib)
 
 _byref = ctypes.byref
@@ -130,6 +130,7 @@ def empty(shape, dtype, ref):
     return torch.empty(shape, dtype=dtype, device=ref.device)
 
 
+TN_MULTI = os.environ.get("AVEC_TN_MULTI", "1") == "1"                     # attention backward: dK, dV and dE as one launch (0: three)
 ATTN_ODD_VALU = os.environ.get("AVEC_ATTN_ODD_VALU", "0") == "1"             # A/B: odd head widths take the VALU column pass of the attention backward (round 2)
 CAST_DEFER = os.environ.get("AVEC_CAST_DEFER", "1") == "1"                   # fp32-input weight gradients: cast once and join the grouped launch (0: a launch of their own)
 TNG_ALIGNED_ONLY = os.environ.get("AVEC_TNG_ALIGNED_ONLY", "0") == "1"       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
@@ -783,12 +784,20 @@ class AttentionModuleFn(torch.autograd.Function):
             # dK and dV: one workgroup per (batch, head, tile) reduces over all Tp rows and stores straight into the K / V thirds of dqkv (no zero-filled
             # fp32 staging, no atomics, no cast pass); dE sums over the batch, so it keeps the accumulate form
             L6 = ctypes.c_longlong * 6
-            lib.gemm_tn_batched_store(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D, Tp, Tp, d, B, H,
-                                      L6(H * Tp * Tld, Tp * Tld, Tp * 3 * D, d, Tp * 3 * D, d), rt.stream())
-            lib.gemm_tn_batched_store(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D, Tp, Tp, d, B, H,
-                                      L6(H * Tp * Tld, Tp * Tld, Tp * D, d, Tp * 3 * D, d), rt.stream())
-            lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * Tp, 2 * Tp - 1, d, 1, H,
-                                L6(0, B * Tp * Rld, 0, d, 0, d), rt.stream())
+            sK, sV, sE = L6(H * Tp * Tld, Tp * Tld, Tp * 3 * D, d, Tp * 3 * D, d), L6(H * Tp * Tld, Tp * Tld, Tp * D, d, Tp * 3 * D, d), L6(0, B * Tp * Rld, 0, d, 0, d)
+            if TN_MULTI:          # the three products as ONE launch (avec_gemm_tn_batched_multi)
+                it = (TnBatched * 3)()
+                it[0].P, it[0].ldp, it[0].Q, it[0].ldq, it[0].O_act, it[0].ldo = a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D
+                it[0].M, it[0].I, it[0].J, it[0].nb_outer, it[0].nb_inner, it[0].strides6 = Tp, Tp, d, B, H, sK
+                it[1].P, it[1].ldp, it[1].Q, it[1].ldq, it[1].O_act, it[1].ldo = a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D
+                it[1].M, it[1].I, it[1].J, it[1].nb_outer, it[1].nb_inner, it[1].strides6 = Tp, Tp, d, B, H, sV
+                it[2].P, it[2].ldp, it[2].Q, it[2].ldq, it[2].O, it[2].ldo = dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D
+                it[2].M, it[2].I, it[2].J, it[2].nb_outer, it[2].nb_inner, it[2].strides6 = B * Tp, 2 * Tp - 1, d, 1, H, sE
+                lib.gemm_tn_batched_multi(rt.dt(), it, 3, rt.stream())
+            else:
+                lib.gemm_tn_batched_store(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D, Tp, Tp, d, B, H, sK, rt.stream())
+                lib.gemm_tn_batched_store(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D, Tp, Tp, d, B, H, sV, rt.stream())
+                lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * Tp, 2 * Tp - 1, d, 1, H, sE, rt.stream())
         dhp = None
         grp = rt.fused_group(wq)
         if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:

@@ -134,6 +134,16 @@ int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q,
 int avec_gemm_tn_batched_store(int dtype, const void* P, long long ldp, const void* Q, long long ldq, void* O_act, long long ldo, long long M, int I, int J,
                                int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
 
+/* up to 3 such batched products (accumulating into fp32 `O`, or stored into `O_act` when that is set) as ONE launch: dK, dV and dE of an attention layer's
+ * backward pass (nnet/attentions.py:280-323 backward) are three launches of ~5 us otherwise.  A problem that needs another kernel is launched on its own. */
+typedef struct {
+  const void* P; long long ldp; const void* Q; long long ldq;
+  float* O; void* O_act; long long ldo;       /* exactly one of O (accumulate) / O_act (store) */
+  long long M; int I, J, nb_outer, nb_inner;
+  const long long* strides6;
+} avec_tn_batched_t;
+int avec_gemm_tn_batched_multi(int dtype, const avec_tn_batched_t* items, int n, hipStream_t stream);
+
 /* ---- fused macaron feed-forward module (avec_amd/csrc/ffn.hip) --------------------------------
  * FeedForwardModule.forward (nnet/modules.py:257-289) with its residual (nnet/blocks.py:292,301) as ONE launch per direction (bf16 mode):
  *   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
