@@ -143,6 +143,9 @@ struct Epi {
 #ifndef AVEC_TN_BUILTIN_DMA
 #define AVEC_TN_BUILTIN_DMA 0
 #endif
+#ifndef AVEC_TN_CONV_ASM
+#define AVEC_TN_CONV_ASM 1
+#endif
 // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): id w runs on XCD w % 8.  xcd_logical() gives XCD x the CONTIGUOUS range of
 // logical ids [x*q + min(x, r), ...) (q = total / 8, r = total % 8), so that workgroups with neighbouring logical ids -- the tiles that share a reduction
 // slice of both operands -- fill ONE L2 instead of eight.
@@ -1224,7 +1227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fp8_kernel(GemmArgs g, const f
 // ------------------------------------------------------------------------------------------------
 struct TnArgs { const void* P; long long ldp; RowSrc q; float* O; void* Oact; long long ldo; long long M; int I, J, Iq, Jq; int m_per_block; float* pcs;   // Oact: when set, the result is STORED in the activation dtype (one workgroup per tile, no split) instead of added to O;   // pcs: optional column sums of P (bias gradient), transposed-read kernel only
                   // Iq/Jq: load bounds (>= I/J when rows are padded)
-                int split, nb_inner, xcd_map; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
+                int split, nb_inner, xcd_map, q_ohw, q_mg, q_nwrap; long long sPo, sPi, sQo, sQi, sOo, sOi; };   // q_*: the gathered operand's pixel bookkeeping (tn_tr_body); batching: blockIdx.z = batch * split + k-slice; batch = outer * nb_inner + inner; element strides
 
 // LDS image of a TN operand: [col][word], word = reduction-row pair (bf16: rows 2p,2p+1 packed in 32 bits) or row (fp32), 32 words
 // per 144-byte row.  Word index XOR-swizzled by 16 * parity(col bits 2..4): with lanes mapped (16 pairs x 4 column chunks) both the
@@ -1437,23 +1440,26 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const 
   const int prow0 = tid / CPI, pcol = i0 + (((tid % CPI) ^ tr_swz<BI>(prow0)) << 3);
   const int qrow0 = tid / CPJ, qcol = j0 + (((tid % CPJ) ^ tr_swz<BJ>(qrow0)) << 3);
   const bool pok = pcol < g.Iq, qok = qcol < (Q_CONV ? g.J : g.Jq);
-  int qkh = 0, qkw = 0, qc = 0, qoh[NLJ], qow[NLJ]; long long qimg[NLJ];
+  // gathered operand: a DMA slot follows ONE reduction row per tile; its pixel is kept as (index inside the image qpx, element offset of the image qimg) and advanced by KT
+  // pixels per tile with q_nwrap compare / subtract rounds (no data-dependent loop: the old row / column / image carry chain with its divergent while loop was most of
+  // what a wave issued per tile); row and column follow from a multiply-shift that the host has checked for every pixel index (q_mg, 20-bit shift)
+  int qkh = 0, qkw = 0, qc = 0, qpx[NLJ]; long long qimg[NLJ];
+  const int q_hwc = Q_CONV ? g.q.H * g.q.W * g.q.C : 0;
   if (Q_CONV) {
     const int tap = qcol / g.q.C; qc = qcol - tap * g.q.C; qkh = tap / g.q.KW; qkw = tap - qkh * g.q.KW;
 #pragma unroll
     for (int u = 0; u < NLJ; ++u) {
-      const long long m = mb + qrow0 + u * RJ; qow[u] = (int)(m % g.q.OW); const long long t = m / g.q.OW; qoh[u] = (int)(t % g.q.OH); qimg[u] = (t / g.q.OH) * (long long)g.q.H * g.q.W * g.q.C;
+      const long long m = mb + qrow0 + u * RJ; const long long im = m / g.q_ohw; qpx[u] = (int)(m - im * g.q_ohw); qimg[u] = im * (long long)q_hwc;
     }
   }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // Plain products send their DMA through inline asm: behind the builtin the compiler drains the queue (s_waitcnt vmcnt(0), visible in the ISA of this loop) in front of
-  // the first transposed read it cannot prove disjoint, i.e. right behind the prefetch of the next tile (DESIGN.md 17.2 rule 3); completion is counted by hand below
-  // (AVEC_WAIT_VM).  The gathered (convolution) operand keeps the builtin: measured 131 / 170 / 244 us against 165 / 179 / 255 us with the asm form on the three
-  // stride-2 weight gradients -- its per-lane address arithmetic schedules worse around the asm blocks than it gains from the overlap.
+  // The DMA goes out through inline asm: behind the builtin the compiler drains the queue (s_waitcnt vmcnt(0), visible in the ISA of this loop) in front of the first
+  // transposed read it cannot prove disjoint, i.e. right behind the prefetch of the next tile (DESIGN.md 17.2 rule 3); completion is counted by hand below (AVEC_WAIT_VM).
+  // (The gathered operand only gained from it once its per-tile address arithmetic had been cut down -- with the old carry chain the asm form was 5-25 % slower.)
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
   auto tn_dma = [&](const void* src, unsigned off) {
-    if (!Q_CONV && !(AVEC_TN_BUILTIN_DMA)) glds16_v64(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + off)));
+    if ((!Q_CONV || AVEC_TN_CONV_ASM) && !(AVEC_TN_BUILTIN_DMA)) glds16_v64(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + off)));
     else __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + off), 16, 0, 0);
   };
   // plain products, whole tiles: scalar base (first row of the tile) + per-lane 32-bit offsets fixed at entry, one M0 save / restore per operand (glds16_group) --
@@ -1490,12 +1496,13 @@ __device__ __forceinline__ void tn_tr_body(const TnArgs& g, const int bx, const 
       const long long m = mt0 + qrow0 + u * RJ;
       const void* src = (const void*)avec_zero16;
       if (Q_CONV) {
-        const int ih = qoh[u] * g.q.stride - g.q.pad + qkh, iw = qow[u] * g.q.stride - g.q.pad + qkw;
+        const int oh = (int)(((unsigned)qpx[u] * (unsigned)g.q_mg) >> 20), ow = qpx[u] - oh * g.q.OW;
+        const int ih = oh * g.q.stride - g.q.pad + qkh, iw = ow * g.q.stride - g.q.pad + qkw;
         const bool ok = qok && m < me && (unsigned)ih < (unsigned)g.q.H && (unsigned)iw < (unsigned)g.q.W;
         const T* sp = Q32 ? Qp + ((int)qimg[u] + (ih * g.q.W + iw) * g.q.C + qc) : Qp + qimg[u] + (ih * g.q.W + iw) * g.q.C + qc;
         src = ok ? (const void*)sp : src;
-        qow[u] += KT;                                            // advance this row by one reduction tile
-        while (qow[u] >= g.q.OW) { qow[u] -= g.q.OW; if (++qoh[u] >= g.q.OH) { qoh[u] = 0; qimg[u] += (long long)g.q.H * g.q.W * g.q.C; } }
+        qpx[u] += KT;                                            // advance this row by one reduction tile
+        for (int r = 0; r < g.q_nwrap; ++r) { const bool w = qpx[u] >= g.q_ohw; qpx[u] -= w ? g.q_ohw : 0; qimg[u] += w ? q_hwc : 0; }
       } else {
         long long row = m;
         if (g.q.step > 1) row = (m / g.q.rows_out) * (long long)g.q.rows_in + (m % g.q.rows_out) * (long long)g.q.step;
@@ -1607,7 +1614,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_grouped_kernel(TnGroup grp)
   TnArgs g; g.P = t.P; g.ldp = t.ldp; g.q.ptr = t.Q; g.q.ld = t.ldq; g.q.rows_out = t.rows_out; g.q.rows_in = t.rows_in; g.q.step = t.step;
   g.q.H = g.q.W = g.q.C = g.q.KH = g.q.KW = g.q.stride = g.q.pad = g.q.OH = g.q.OW = 0;
   g.O = t.O; g.Oact = nullptr; g.ldo = t.ldo; g.M = t.M; g.I = t.I; g.J = t.J; g.Iq = t.Iq; g.Jq = t.Jq; g.m_per_block = t.m_per_block; g.pcs = t.pcs;
-  g.split = t.split; g.nb_inner = 1; g.xcd_map = 0; g.sPo = g.sPi = g.sQo = g.sQi = g.sOo = g.sOi = 0;
+  g.split = t.split; g.nb_inner = 1; g.xcd_map = 0; g.q_ohw = 1; g.q_mg = 0; g.q_nwrap = 0; g.sPo = g.sPi = g.sQo = g.sQi = g.sOo = g.sOi = 0;
   int l = w - t.first; const int bx = l % t.gx; l /= t.gx; const int by = l % t.gy; const int bz = l / t.gy;
   tn_tr_body<BT, BT, MODE_PLAIN, STG, false, KT>(g, bx, by, bz);
 }
@@ -1877,7 +1884,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   const bool f32src = q_f32 && sizeof(T) == 2;
   const bool a16 = nbatch == 1 && aligned16(g.P) && aligned16(g.q.ptr) && g.Iq % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
-  if (sizeof(T) == 2 && a16 && !f32src && !g.Oact) {        // bf16: LDS-DMA + transposed-read kernel
+  if (sizeof(T) == 2 && a16 && !f32src && !g.Oact && (mode == MODE_PLAIN || g.q_mg != 0)) {        // bf16: LDS-DMA + transposed-read kernel (gathered operand: images of <= 4096 output pixels)
     static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
     if (use_tr) {
       // reduction rows per LDS tile: 32 (two 16 KB stages for 128x128) keeps 4 workgroups resident per CU; measured on the ResNet weight
@@ -1885,7 +1892,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
       static const int kt_env = getenv("AVEC_TN_KT") ? atoi(getenv("AVEC_TN_KT")) : 32;
       const long long q_elems = mode == MODE_PLAIN ? 0 : ((g.M + (long long)g.q.OH * g.q.OW - 1) / ((long long)g.q.OH * g.q.OW) + 1) * g.q.H * g.q.W * g.q.C;
       const bool q32 = q_elems < (1ll << 31);
-#define LT(MODE, Q32, KT_) do { const size_t l2 = (size_t)2 * KT_ * (BI + BJ) * 2; avec_note_kernel("gemm_tn_tr_kernel<%d,%d,%d,2,%d,%d>", BI, BJ, MODE, (int)Q32, KT_); if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>, l2)) return r; \
+#define LT(MODE, Q32, KT_) do { const size_t l2 = (size_t)2 * KT_ * (BI + BJ) * 2; g.q_nwrap = (KT_ + g.q_ohw - 1) / g.q_ohw; avec_note_kernel("gemm_tn_tr_kernel<%d,%d,%d,2,%d,%d>", BI, BJ, MODE, (int)Q32, KT_); if (int r = want_lds(gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>, l2)) return r; \
         hipLaunchKernelGGL((gemm_tn_tr_kernel<BI, BJ, MODE, 2, Q32, KT_>), grid, dim3(256), l2, st, g); return 0; } while (0)
 #define LK(KT_) do { if (mode == MODE_PLAIN) LT(MODE_PLAIN, false, KT_); else if (q32) LT(MODE_CONV_FWD, true, KT_); else LT(MODE_CONV_FWD, false, KT_); } while (0)
       if (kt_env == 64) LK(64); else LK(32);
@@ -1927,6 +1934,12 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
   AVEC_CHECK_ARG(!(q_f32 && dtype == AVEC_BF16) || Jq % 4 == 0, "gemm_tn: fp32-source staging needs J %% 4 == 0");
   TnArgs g; g.P = P; g.ldp = ldp; g.q = make_src(Q, q_rows); g.O = O; g.Oact = Oact; g.ldo = ldo; g.M = M; g.I = I; g.J = J; g.Iq = Iq; g.Jq = Jq; g.m_per_block = 0; g.pcs = p_colsum;
   g.split = 1; g.nb_inner = nb_inner;
+  g.q_ohw = 1; g.q_mg = 0; g.q_nwrap = 0;
+  if (q_mode != MODE_PLAIN && q_rows->OW > 0 && q_rows->OH > 0 && (long long)q_rows->OH * q_rows->OW <= 4096) {      // pixel -> (row, column) by multiply-shift, verified here
+    const int ohw = q_rows->OH * q_rows->OW; const unsigned mg = ((1u << 20) + (unsigned)q_rows->OW - 1u) / (unsigned)q_rows->OW;
+    bool exact = true; for (int px = 0; px < ohw && exact; ++px) exact = (int)(((unsigned)px * mg) >> 20) == px / q_rows->OW;
+    g.q_ohw = ohw; g.q_mg = exact ? (int)mg : 0;
+  }
   { static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr; g.xcd_map = no_xcd ? 0 : 1; }
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
