@@ -2031,7 +2031,7 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
   const int BT = bt_env == 64 || bt_env == 128 ? bt_env : (t128 >= 96 ? 128 : 64);
   // common reduction-slice length: the largest multiple of 64 rows (>= 256) that still yields ~wg_target workgroups over the whole group
   static const long long wg_env = getenv("AVEC_TNG_WGS") ? atoll(getenv("AVEC_TNG_WGS")) : 0;
-  const long long wg_target = wg_env > 0 ? wg_env : 384;       // in the training step fewer, longer slices win (25.55 vs 25.75 ms at 256-384 vs 1536: every slice costs I*J atomics)
+  const long long wg_target = wg_env > 0 ? wg_env : 512;       // every slice costs I*J atomics: 256-512 beat 1536 by 0.2 ms in the step; with the lean DMA loop 512 beats 384 (21.14 vs 21.24 ms, two same-box sweeps)
   long long per = 256;
   for (long long cand = 8192; cand >= 256; cand -= 64) {
     long long wgs = 0;
