@@ -1873,7 +1873,9 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   static const long long wg_env = getenv("AVEC_TN_WGS") ? atoll(getenv("AVEC_TN_WGS")) : 0;
   // re-measured per ResNet stage (tools/bench_gemm.py, AVEC_TN_WGS sweep): few output tiles (stage 2: 9) are best at ~1024 workgroups (232 vs 255 us), 36 tiles
   // (stage 3) at 2048, 144 tiles (stage 4) at 4096 (358 vs 378 us): the split has to cover the chip several times over, but every workgroup pays BI*BJ atomics
-  const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? (tiles <= 16 ? 1024 : tiles <= 64 ? 2048 : 4096) : 512);
+  // (end of round 3, after the gather loop lost its carry chain: the split should fill the ~1024 resident slots ONCE -- 4 workgroups of 32 KB per CU -- and no more: 72 tiles
+  //  x 12 slices = 864 workgroups take 127 us on the 512-channel stride-2 layer, 72 x 15 = 1080 take 154 us, the old 4096 target 227 us; tools/gpu/r3_tnkt.sh)
+  const long long wg_target = wg_env > 0 ? wg_env : (mode != MODE_PLAIN ? 896 : 512);
   long long split = (wg_target + tiles - 1) / tiles; if (split > ksteps / 4) split = ksteps / 4; if (split < 1 || g.Oact) split = 1;
   long long per = ((ksteps + split - 1) / split) * KE;
   split = (g.M + per - 1) / per;

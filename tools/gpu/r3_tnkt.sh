@@ -1,3 +1,4 @@
+# gathered weight-gradient kernel: split target (AVEC_TN_WGS) on the three stride-2 layers
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=.
-for kt in 32 64; do for w in 0 1024 2048 4096; do echo "== AVEC_TN_KT=$kt AVEC_TN_WGS=$w"; AVEC_TN_KT=$kt AVEC_TN_WGS=$w python tools/bench_gemm.py 2>&1 | grep -A4 " s2 " | grep "s2\|conv wgrad *[0-9]"; done; done
+for w in 256 384 512 640 768 896; do echo "== AVEC_TN_WGS=$w"; AVEC_TN_WGS=$w python tools/bench_gemm.py 2>&1 | grep -A4 " s2 " | grep "conv wgrad *[0-9]"; done
