@@ -487,8 +487,10 @@ static inline unsigned bn8_blocks(long long n8, int C, unsigned cap) {
   nb = nb / q * q; if (nb < q) nb = q;
   return (unsigned)nb;
 }
-constexpr int BN8_U = 2;        // chunks in flight per thread in the element-wise passes
+constexpr int BN8_U = 2;        // chunks in flight per thread in the element-wise passes (3 and 4: no gain)
 constexpr int BN8_UR = 1;       // ... in the reduction pass (2 measured 4-6 % slower there)
+constexpr unsigned BN8_CAP_FWD = 8192, BN8_CAP_BWD = 3072;      // grid caps: the 3-operand backward pass likes fewer, longer-running blocks (115200 x 256: 41.5 -> 36.7 us,
+                                                                // 28800 x 512: 28.0 -> 21.9 us), the forward pass the opposite (32.9 vs 33.9 us); tools/bench_bn.py
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y, const float* __restrict__ ss, const T* __restrict__ res, int act,
@@ -538,14 +540,14 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const T* __restrict__ y,
 extern "C" int avec_bn_apply_fwd_mask(int dtype, const void* y, const float* ss, const void* residual, const float* residual_ss, void* out, unsigned char* mask, long long M, int C,
                                       hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && mask && M > 0 && C > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31) && (residual || !residual_ss), "bn_apply_fwd_mask: bad arguments (C %% 8 == 0, M*C < 2^34)");
-  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, BN8_CAP_FWD);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, 2, (T*)out, (unsigned)n8, C, mask, residual_ss));
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_bn_apply_fwd(int dtype, const void* y, const float* ss, const void* residual, int act, void* out, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(y && ss && out && M > 0 && C > 0 && C % 4 == 0, "bn_apply_fwd: bad arguments");
   if (C % 8 == 0 && M * C / 8 < (1ll << 31)) {
-    const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+    const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, BN8_CAP_FWD);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)y, ss, (const T*)residual, act, (T*)out, (unsigned)n8, C));
     AVEC_LAUNCH_CHECK(); return 0;
   }
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const T* __restrict_
 extern "C" int avec_bn_bwd_apply_mask(int dtype, const void* dout, const void* y, const unsigned char* mask, const float* ss, const float* gamma, const float* dstats,
                                       const float* count_ptr, float count, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && mask && ss && gamma && dstats && dy && M > 0 && C % 8 == 0 && M * C / 8 < (1ll << 31), "bn_bwd_apply_mask: bad arguments");
-  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+  const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, BN8_CAP_BWD);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)nullptr, ss, gamma, dstats,
                                        count_ptr, count, 2, (T*)dy, (T*)dres, dgamma, dbeta, (unsigned)n8, C, mask));
   AVEC_LAUNCH_CHECK(); return 0;
@@ -715,7 +717,7 @@ extern "C" int avec_bn_bwd_apply(int dtype, const void* dout, const void* y, con
                                  const float* count_ptr, float count, int act, void* dy, void* dres, float* dgamma, float* dbeta, long long M, int C, hipStream_t st) {
   AVEC_CHECK_ARG(dout && y && ss && gamma && dstats && dy && M > 0 && C % 4 == 0, "bn_bwd_apply: bad arguments");
   if (C % 8 == 0 && M * C / 8 < (1ll << 31)) {
-    const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, 8192);
+    const long long n8 = M * C / 8; const unsigned nb8 = bn8_blocks(n8, C, BN8_CAP_BWD);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)nb8), dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, ss, gamma, dstats,
                                          count_ptr, count, act, (T*)dy, (T*)dres, dgamma, dbeta, (unsigned)n8, C));
     AVEC_LAUNCH_CHECK(); return 0;
