@@ -19,6 +19,13 @@ void avec_note_kernel(const char* fmt, ...) {
 }
 extern "C" const char* avec_last_kernel() { return g_kname; }
 extern "C" int avec_version() { return AVEC_ABI_VERSION; }
+extern "C" int avec_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(avec_rows_t); case 1: return (int)sizeof(avec_epilogue_t); case 2: return (int)sizeof(avec_attn_t); case 3: return (int)sizeof(avec_tn_item_t);
+    case 4: return (int)sizeof(avec_tn_batched_t); case 5: return (int)sizeof(avec_ln_item_t); case 6: return (int)sizeof(avec_fp8_item_t); case 7: return (int)sizeof(avec_wgrad3x3_item_t);
+    default: return -1;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // reduction workspace (vec.h: two-pass column reductions).  One registration per device.

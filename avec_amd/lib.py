@@ -81,6 +81,7 @@ class WgradItem(ctypes.Structure):
 
 
 TN_GROUP_MAX, LN_GROUP_MAX, WGRAD_GROUP_MAX = 32, 40, 16
+ABI_STRUCTS = (Rows, Epilogue, Attn, TnItem, TnBatched, LnItem, Fp8Item, WgradItem)      # index = `which` of avec_struct_size
 
 
 def _ctype(decl):
@@ -121,8 +122,12 @@ class _Lib:
                 fn = getattr(dll, name)  # AttributeError if the .so does not export a declared symbol
                 fn.restype = restype
                 fn.argtypes = argtypes
-            if dll.avec_version() != 1:
-                raise RuntimeError("libavec_hip.so ABI version mismatch")
+            want = int(re.search(r"#define AVEC_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+            if dll.avec_version() != want:
+                raise RuntimeError("libavec_hip.so ABI version %d, include/avec_hip.h declares %d: rebuild (python -m avec_amd.build)" % (dll.avec_version(), want))
+            for which, st in enumerate(ABI_STRUCTS):          # a struct that grew on one side only would be read past its end
+                if dll.avec_struct_size(which) != ctypes.sizeof(st):
+                    raise RuntimeError("libavec_hip.so: sizeof(%s) is %d in the library, %d in avec_amd/lib.py" % (st.__name__, dll.avec_struct_size(which), ctypes.sizeof(st)))
             self._dll = dll
         return self._dll
 

@@ -55,6 +55,9 @@ class Conv1d(nn.Conv1d):
 
     def forward(self, x):
         if self.depthwise and self.mask is None:            # on the hot path it runs fused inside ConvolutionModule; alone: the same kernels with the GLU gate pinned to 1
+            if self.dilation[0] != 1 or self.padding_type not in ("same", "causal"):
+                raise RuntimeError("depthwise Conv1d on the HIP path: dilation 1 and padding 'same' or 'causal' (got dilation %d, padding %r); the fused GLU + depthwise kernels "
+                                   "take neither a dilation nor an integer padding" % (self.dilation[0], self.padding_type))
             from .functions import DepthwiseConv1dFn
             if not self.channels_last:
                 x = x.transpose(1, 2)

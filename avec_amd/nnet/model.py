@@ -349,6 +349,10 @@ class Model(Module):
 
     # -- checkpoints (nnet/model.py:499-544) -------------------------------------------------------
     def save(self, path, save_optimizer=True):
+        if self.is_distributed:
+            from .. import peer
+            if peer.active() is not None:
+                peer.active().check()            # (synchronises) a SyncBatchNorm exchange that lost a rank since the last check: raise instead of writing a checkpoint of skipped steps
         torch.save({"model_state_dict": self.state_dict(), "optimizer_state_dict": self.optimizer.state_dict() if save_optimizer else None,
                     "model_step": self.model_step, "is_distributed": self.is_distributed or self.is_parallel,
                     "ema_model_state_dict": None, "grad_scaler_state_dict": None}, path)

@@ -1494,6 +1494,7 @@ class ResNetBlockFn(torch.autograd.Function):
 
 STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels
 STEM3P_FUSED_WGRAD = os.environ.get("AVEC_STEM3P_FUSED", "1") != "0"  # ... and the weight gradient computed from the recomputed tiles in the same kernel (no dz tensor)
+STEM_GRAD_CLONE = os.environ.get("AVEC_STEM_GRAD_CLONE", "0") == "1"   # the stem's backward masks the incoming gradient IN PLACE (it is the first ResNet block's dx: 99 MB, nothing else reads it); 1 = work on a copy
 STEM3P = os.environ.get("AVEC_STEM3P", "1") != "0"                    # ... with the max pool inside the convolution kernel and the pre-pool tensor recomputed in backward (stem3p.hip)
 
 
@@ -1555,7 +1556,10 @@ class VideoStemFn(torch.autograd.Function):
     def backward(ctx, dpool):
         v, y, idx, st, cp, conv, bn, r, B, T, OH, OW, C, M, K, training, ymax = ctx.saved
         assert training, "VideoStem backward is implemented for training-mode BatchNorm"
+        dpool_in = dpool
         dpool = dpool.to(rt.act_dtype()).contiguous()
+        if isinstance(r, tuple) and dpool.data_ptr() == dpool_in.data_ptr() and STEM_GRAD_CLONE:
+            dpool = dpool.clone()                               # stem3p_reduce masks it in place (AVEC_STEM_GRAD_CLONE=1: for code that inspects the stem output's gradient through hooks / retain_grad)
         if isinstance(r, tuple):                                # stem3p: ReLU mask + BatchNorm-backward sums over the pooled tensor, then dz from the RECOMPUTED conv output
             _, vb, w8, zp, PH, PW = r
             H, W = v.shape[2], v.shape[3]

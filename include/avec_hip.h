@@ -33,10 +33,14 @@ extern "C" {
 
 #define AVEC_F32 0
 #define AVEC_BF16 1
-#define AVEC_ABI_VERSION 1
+#define AVEC_ABI_VERSION 2      /* 2: avec_epilogue_t grew (bnb_*, res_cls0); avec_struct_size() handshake */
 #define AVEC_STAT_REPLICAS 64   /* `stats` buffers handed to avec_gemm_nt hold this many [2N] replicas (block b adds to replica b % 64) */
 
 int avec_version(void);
+/* sizeof() of the structs that cross this boundary, as THIS library was compiled: a binding compares them with its own declarations at load time, so that a header / .so
+ * pair that drifted apart fails loudly instead of reading past a shorter struct.  which: 0 avec_rows_t, 1 avec_epilogue_t, 2 avec_attn_t, 3 avec_tn_item_t,
+ * 4 avec_tn_batched_t, 5 avec_ln_item_t, 6 avec_fp8_item_t, 7 avec_wgrad3x3_item_t; -1 for an unknown index. */
+int avec_struct_size(int which);
 const char* avec_last_error(void);
 /* the kernel instance chosen by the last GEMM-family entry point called on this thread ("gemm_nt_glds_kernel<bf16,64,64,0,4,0,128>" ...): measurement aid, bench.py's roofline rows */
 const char* avec_last_kernel(void);

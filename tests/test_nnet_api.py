@@ -1,6 +1,8 @@
 """CPU: the host-side mirror keeps the reference's API surface -- state_dict keys/shapes, parameter count, seeded initialisation
 (bit-identical to the reference under the same torch seed), registries, length arithmetic -- and the C ABI is complete."""
+import os
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -105,7 +107,11 @@ def test_c_abi_exports_every_declared_symbol():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert set(decl) <= exported, sorted(set(decl) - exported)
     lib.load()                                   # resolves + types every symbol; raises if one is missing
-    assert lib.raw("avec_version")() == 1
+    assert lib.raw("avec_version")() == 2
+    from avec_amd.lib import ABI_STRUCTS
+    import ctypes
+    for which, st in enumerate(ABI_STRUCTS):
+        assert lib.raw("avec_struct_size")(which) == ctypes.sizeof(st), st.__name__
     assert lib.raw("avec_ctc_workspace_floats")(2, 10, 3) == 2 * (10 * 7 + 10)
 
 
@@ -167,3 +173,20 @@ def test_word_error_rate_standardizes_and_is_corpus_level():
     # 1 substitution in a 2-word sentence + 0 errors in an 8-word sentence: corpus level 10 %, mean of sentence rates 25 %
     assert abs(wer(["hello world", "a b c d e f g h"], ["hello word", "a b c d e f g h"]) - 10.0) < 1e-9
     assert abs(wer(["a b c"], ["a c"]) - 100.0 / 3) < 1e-9 and abs(wer(["a b"], ["a x b y"]) - 100.0) < 1e-9      # deletion; two insertions
+
+
+def test_integration_md_stub_matches_the_header():
+    """INTEGRATION.md's generated struct stubs (tools/gen_integration.py) are current, and what a maintainer would paste has the library's own struct sizes"""
+    import ctypes
+    import re
+    from avec_amd.lib import Epilogue, Rows, declared_functions, lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_integration.py"), "--check"]).returncode == 0, "INTEGRATION.md is stale: python tools/gen_integration.py"
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    blk = doc[doc.index("<!-- BEGIN GENERATED"):doc.index("<!-- END GENERATED -->")]
+    ns = {"ctypes": ctypes}
+    exec(blk[blk.index("```python") + 9:blk.rindex("```")], ns)
+    assert ctypes.sizeof(ns["Epilogue"]) == ctypes.sizeof(Epilogue) == lib.raw("avec_struct_size")(1)
+    assert ctypes.sizeof(ns["Rows"]) == ctypes.sizeof(Rows) == lib.raw("avec_struct_size")(0)
+    assert [f[0] for f in ns["Epilogue"]._fields_] == [f[0] for f in Epilogue._fields_]
+    assert int(re.search(r"\((\d+) `extern \"C\"` symbols", doc).group(1)) == len(declared_functions())

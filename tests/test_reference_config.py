@@ -54,7 +54,8 @@ def test_reference_av_config_imports_unchanged(tmp_path):
     os.makedirs(assets)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_assets.py"), assets], check=True, capture_output=True, timeout=900)
     code = "ROOT = %r\nREF_CFG = %r\n" % (ROOT, REF_CFG) + SCRIPT
-    r = subprocess.run([sys.executable, "-c", code], cwd=assets, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")      # importing the config must not drop a __pycache__ into the read-only reference tree
+    r = subprocess.run([sys.executable, "-B", "-c", code], cwd=assets, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("PROBE ")][-1][6:])
     assert got["front_end_transplanted"] and got["aligned"] and got["tokenizer_loaded"]
