@@ -79,6 +79,17 @@ extern "C" int avec_specaugment(float* mel, const long long* lens, int B, int n_
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+__global__ void debug_rng_uniform_kernel(const unsigned long long* rng, unsigned stream, const long long* ids, int n, float* out) {
+  const unsigned long long seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rng_uniform(seed, stream, (unsigned long long)ids[i]);
+}
+extern "C" int avec_debug_rng_uniform(const unsigned long long* rng, unsigned rng_stream, const long long* ids, int n, float* out, hipStream_t st) {
+  AVEC_CHECK_ARG(rng && ids && out && n > 0, "debug_rng_uniform: bad arguments");
+  hipLaunchKernelGGL(debug_rng_uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rng, rng_stream, ids, n, out);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // audio stem: y[b][to][c*Fo + fo] = bias[c] + sum_{kh,kw} w[c][kh][kw] * mel[b][2fo+kh-1][2to+kw-1]
 // ---------------------------------------------------------------------------------------------

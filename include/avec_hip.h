@@ -301,6 +301,11 @@ int avec_mel_power_log(const float* spec, const float* fb, float* out, int B, in
 /* SpecAugment (nnet/preprocessing.py:115-130) */
 int avec_specaugment(float* mel, const long long* lens, int B, int n_mels, int F, int mF, int Fparam, int mT, float pS,
                      const unsigned long long* rng, unsigned rng_stream, hipStream_t stream);
+/* debugging / parity aid: out[i] = the uniform in [0, 1) that the counter-based generator of the dropout and SpecAugment kernels yields for (rng = {seed, step}, rng_stream,
+ * ids[i]).  SpecAugment (avec_specaugment) draws, per frequency mask q, value = u(2q) * F and min = u(2q + 1) * (n_mels - value); per sample b and time mask q,
+ * value = u(1000 + 64 b + 2q) * T_b and min = u(1000 + 64 b + 2q + 1) * (len_b - value): tests replay these draws through the oracle's mask_along_axis restatement and
+ * compare the masks bit for bit. */
+int avec_debug_rng_uniform(const unsigned long long* rng, unsigned rng_stream, const long long* ids, int n, float* out, hipStream_t stream);
 /* audio stem Conv2d(1->C,3x3,s2,"same")+BatchNorm2d+Swish (nnet/networks.py:359-368) in (B,T',C*F') layout */
 int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float* w, const float* bias, void* y, float* stats, int B, int n_mels, int F, int C, hipStream_t stream);
 int avec_audio_stem_act_fwd(int dtype, const void* y, const float* ss, void* a, int B, int n_mels, int F, int C, hipStream_t stream);

@@ -129,6 +129,37 @@ def mel_frontend(audio, lengths=None, n_fft=512, win=400, hop=160, n_mels=80):
 # --------------------------------------------------------------------------------------------
 
 
+def mask_along_axis_bounds(size, mask_param, u_value, u_min):
+    """torchaudio.functional.mask_along_axis (un-vendored, version unpinned: reference requirements.txt:2; restated from the library's published algorithm, the
+    non-iid form used by transforms.FrequencyMasking / TimeMasking with p = 1.0):
+        value = rand(1) * mask_param;  min_value = rand(1) * (size - value);  mask_start = min_value.long();  mask_end = min_value.long() + value.long()
+    -> [start, end) of the masked run.  u_value, u_min: the two uniforms in draw order.  fp32 arithmetic like torch's default dtype.  "parity unpinned" at the torchaudio
+    boundary: this pins the DRAW -> MASK map of the kernel, not torch's generator stream."""
+    value = torch.tensor(u_value, dtype=torch.float32) * mask_param
+    min_value = torch.tensor(u_min, dtype=torch.float32) * (size - value)
+    start = int(min_value.long())
+    return start, start + int(value.long())
+
+
+def spec_augment(mel, lengths, mF, F_param, mT, pS, uniform):
+    """nnet/preprocessing.py:115-130 (SpecAugment.forward, training): mF frequency masks shared by the batch (FrequencyMasking(freq_mask_param=F, iid_masks=False) on the
+    whole (B, n_mels, T) tensor), then per sample b: T_b = int(pS * lengths[b]) and mT time masks TimeMasking(time_mask_param=T_b) on samples[b:b+1, :, :lengths[b]];
+    masked cells are set to 0.  `uniform(kind, b, q, which)` supplies the draw that the torchaudio call would take from the global generator: kind "f" | "t", which 0 = value,
+    1 = min_value (so the device kernel's counter-based draws can be replayed here).  Returns the masked copy."""
+    out = mel.clone()
+    B, n_mels, T = out.shape
+    for q in range(mF):
+        s0, s1 = mask_along_axis_bounds(n_mels, F_param, uniform("f", 0, q, 0), uniform("f", 0, q, 1))
+        out[:, s0:s1, :] = 0.0
+    for b in range(B):
+        L = int(lengths[b]) if lengths is not None else T
+        Tb = int(torch.tensor(pS, dtype=torch.float32) * torch.tensor(L))            # python float * int64 tensor -> fp32 tensor -> int() (preprocessing.py:126)
+        for q in range(mT):
+            s0, s1 = mask_along_axis_bounds(L, Tb, uniform("t", b, q, 0), uniform("t", b, q, 1))
+            out[b, :, :L][:, s0:s1] = 0.0
+    return out
+
+
 def swish(x):
     """nnet/activations.py:39-45"""
     return x * torch.sigmoid(x)
