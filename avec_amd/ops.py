@@ -22,7 +22,7 @@ class KernelTimer:
     NAMES = {(0, ROWS_CONV_FWD): "gemm_nt<conv_fwd>", (0, ROWS_CONV_BWD): "gemm_nt<conv_bwd_data>", (0, ROWS_STEM3D): "gemm_nt<stem3d>",
              (0, ROWS_PLAIN): "gemm_nt<plain>", (1, ROWS_CONV_FWD): "gemm_tn<conv_wgrad>", (1, ROWS_STEM3D): "gemm_tn<stem3d_wgrad>",
              (1, ROWS_PLAIN): "gemm_tn<plain>", (2, 0): "conv3x3_slab<fwd>", (2, 1): "conv3x3_slab<bwd_data>", (2, 2): "conv3x3_slab<wgrad>",
-             (3, 0): "ffn_fused<fwd>", (3, 1): "ffn_fused<bwd>"}
+             (3, 0): "ffn_chain<fwd>", (3, 1): "ffn_chain<bwd>", (3, 2): "ln_gemm"}
 
     def __init__(self):
         self.enabled = False
@@ -572,14 +572,26 @@ class DropoutFn(torch.autograd.Function):
 # FeedForwardModule (nnet/modules.py:257-289) fused with its macaron residual (nnet/blocks.py:292,301)
 #   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
 # ============================================================================================
-# csrc/ffn.hip (one launch per direction) is correct (tests/test_gpu_round2.py) but, measured on MI355X, slower than the launch sequence it replaces
-# (M = 3200, D = 256: forward 73 us against 38 us): 50 workgroups x 64 rows cannot stream 1 MB of weights each fast enough.
-# Opt-in for experiments: AVEC_FFN_FUSED=1.
-FFN_FUSED = os.environ.get("AVEC_FFN_FUSED", "0") == "1"
+# csrc/chain.hip: the module as ONE launch per direction, split over the hidden width (workgroup = 64-row tile x 256-column slice of F; partial outputs by fp32
+# atomics into a pre-zeroed tensor).  AVEC_FFN_CHAIN=0 restores the three-launch sequence (LayerNorm, W1 + Swish / dropout, W2 + residual).
+FFN_CHAIN = os.environ.get("AVEC_FFN_CHAIN", "1") != "0"
+LN_GEMM = os.environ.get("AVEC_LN_GEMM", "1") != "0"             # LayerNorm folded into the Q|K|V projection / the first pointwise convolution (avec_ln_gemm)
 
 
-def _ffn_fused_ok(M, D, F):
-    return FFN_FUSED and rt.compute_dtype() == "bf16" and bool(lib.raw("avec_ffn_fused_supported")(BF16, M, D, F))
+def _chain_ok(M, D, N):
+    return rt.compute_dtype() == "bf16" and bool(lib.raw("avec_chain_supported")(M, D, N))
+
+
+def ln_gemm(x2, ln_w, ln_b, eps, wfwd, ldw, bias, M, D, N):
+    """out = LN(x2) W^T + bias (act) in one launch; also (h = LN(x2) act, mean, rstd) for the backward pass"""
+    out, h = empty((M, N), rt.act_dtype(), x2), empty((M, D), rt.act_dtype(), x2)
+    mean, rstd = empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
+    ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
+    lib.ln_gemm(x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, wfwd.data_ptr(), ldw, _p(bias), out.data_ptr(), N, mean.data_ptr(), rstd.data_ptr(), h.data_ptr(),
+                M, D, N, rt.stream())
+    if ev is not None:
+        KERNEL_TIMER.stop(ev, (3, 2), 2.0 * M * N * D)
+    return out, h, mean, rstd
 
 
 def defer_ln_param_grads(dy, dy_f32, x, mean, rstd, w, b, M, D):
@@ -606,15 +618,18 @@ class FeedForwardFn(torch.autograd.Function):
         M, D = x2.shape
         F = w1.shape[0]
         adt = rt.act_dtype()
-        fused = _ffn_fused_ok(M, D, F)
-        if fused:        # csrc/ffn.hip: LN -> GEMM -> Swish/dropout -> GEMM -> residual in one launch, 64 rows per workgroup
+        fused = FFN_CHAIN and _chain_ok(M, D, F) and rt.shadow(w1).Cp == D and rt.shadow(w2).Cp == F
+        if fused:        # csrc/chain.hip: LN -> W1 slice -> Swish / dropout -> partial W2 product -> atomic add, one launch
             sh1, sh2 = rt.shadow(w1), rt.shadow(w2)
-            y, mean, rstd = empty((M, D), torch.float32, x2), empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
-            h0, z, h1 = empty((M, D), adt, x2), empty((M, F), adt, x2), empty((M, F), adt, x2)
+            y = rt.zeros_scratch(M * D, x2.device).view(M, D)
+            mean, rstd = empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
+            h0 = empty((M, D), adt, x2)
+            z = torch.empty(lib.raw("avec_ffn_chain_zbuf_bytes")(M, F), dtype=torch.uint8, device=x2.device)      # pre-activation in the kernel's accumulator order
+            h1 = None
             rng = rt.rng_state(x2.device).data_ptr() if drop_p > 0 else None
             ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-            lib.ffn_fused_fwd(x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, sh1.fwd.data_ptr(), sh1.Cp, b1.data_ptr(), sh2.fwd.data_ptr(), sh2.Cp, b2.data_ptr(),
-                              alpha, drop_p, rng, sid1, sid2, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), h0.data_ptr(), z.data_ptr(), h1.data_ptr(), M, D, F, rt.stream())
+            lib.ffn_chain_fwd(x2.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, sh1.fwd.data_ptr(), D, b1.data_ptr(), sh2.fwd.data_ptr(), F, b2.data_ptr(),
+                              alpha, drop_p, rng, sid1, sid2, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), h0.data_ptr(), z.data_ptr(), M, D, F, rt.stream())
             if ev is not None:
                 KERNEL_TIMER.stop(ev, (3, 0), 4.0 * M * D * F)
         else:
@@ -633,17 +648,17 @@ class FeedForwardFn(torch.autograd.Function):
         if fused:
             sh1, sh2 = rt.shadow(w1), rt.shadow(w2)
             adt = rt.act_dtype()
-            dx = empty((M, D), torch.float32, dy)
-            dacc, dz, dh0 = empty((M, D), adt, dy), empty((M, F), adt, dy), empty((M, D), adt, dy)
+            dacc, dz, h1 = empty((M, D), adt, dy), empty((M, F), adt, dy), empty((M, F), adt, dy)
+            dh0 = rt.zeros_scratch(M * D, dy.device).view(M, D)
             rng = rt.rng_state(dy.device).data_ptr() if drop_p > 0 else None
             ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-            lib.ffn_fused_bwd(dy.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln_w.data_ptr(), sh2.bwd.data_ptr(), sh2.ldb or D, sh1.bwd.data_ptr(), sh1.ldb or F,
-                              z.data_ptr(), alpha, drop_p, rng, sid1, sid2, dx.data_ptr(), dacc.data_ptr(), dz.data_ptr(), dh0.data_ptr(), M, D, F, rt.stream())
+            lib.ffn_chain_bwd(dy.data_ptr(), sh2.bwd.data_ptr(), sh2.ldb or D, sh1.bwd.data_ptr(), sh1.ldb or F, z.data_ptr(), alpha, drop_p, rng, sid1, sid2,
+                              dacc.data_ptr(), dz.data_ptr(), h1.data_ptr(), dh0.data_ptr(), M, D, F, rt.stream())
             if ev is not None:
                 KERNEL_TIMER.stop(ev, (3, 1), 4.0 * M * D * F)
             linear_bwd_weight(dacc, h1, w2, M, bias=b2)
             linear_bwd_weight(dz, h0, w1, M, bias=b1)
-            defer_ln_param_grads(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D)
+            dx = layernorm_bwd(dh0, True, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy, prep=ctx.prep_req)
             return (dx.view(shp),) + (None,) * 11
         dacc = _take_prep(dy, M, D, alpha, drop_p, sid2)
         if dacc is None:
@@ -698,7 +713,12 @@ class AttentionModuleFn(torch.autograd.Function):
         B, T, D = x.shape
         x2 = _f32c(x.reshape(-1, D))
         M, d, adt = B * T, D // H, rt.act_dtype()
-        if ln_w is not None:
+        grp = rt.fused_group(wq)
+        grp_ok = grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None
+        qkv = None
+        if ln_w is not None and patch == 1 and grp_ok and LN_GEMM and _chain_ok(M, D, 3 * D) and fp8.entry(wq, D) is None:
+            qkv, h, mean, rstd = ln_gemm(x2, ln_w, ln_b, eps, grp.fwd, D, grp.bias, M, D, 3 * D)         # LayerNorm inside the Q|K|V launch
+        elif ln_w is not None:
             h, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
         else:                      # bare attention layer (forwardQKV called directly): no pre-norm
             mean = rstd = None
@@ -714,15 +734,17 @@ class AttentionModuleFn(torch.autograd.Function):
         if mask is not None:      # dense (B or 1,1,T,T) float mask as the reference API; patch variant min-pools it on the host side
             mask = mask.reshape(mask.shape[0], T, T) if patch == 1 else _pool_mask(mask, T, patch)
             mask = mask.float().contiguous()
-        qkv = empty((Mp, 3 * D), adt, x2)
-        grp = rt.fused_group(wq)
-        if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
+        if qkv is not None:
+            pass
+        elif grp_ok:
+            qkv = empty((Mp, 3 * D), adt, x2)
             ent = fp8.entry(wq, D)
             if ent is not None and ent.N == 3 * D:
                 gemm_nt_fp8(hp, ent, qkv, Mp, 3 * D, D, bias=grp.bias)
             else:
                 gemm_nt(hp, grp.fwd, qkv, Mp, 3 * D, D, bias=grp.bias)               # Q|K|V in one launch
         else:
+            qkv = empty((Mp, 3 * D), adt, x2)
             for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
                 sh = rt.shadow(w)
                 gemm_nt(hp, sh.fwd, qkv[:, i * D:], Mp, D, D, bias=b, ldo=3 * D)
@@ -1012,8 +1034,12 @@ class ConvModuleFn(torch.autograd.Function):
         To = (T - 1) // stride + 1
         M, Mo, adt = B * T, B * To, rt.act_dtype()
         x2 = _f32c(x.reshape(M, D))
-        h, mean, rstd = layernorm_fwd(x2, ln.weight, ln.bias, M, D, False, ln.eps)
-        u = linear_fwd(h, pw1.weight, pw1.bias, M, in_f32=False, out_f32=False)
+        sh1 = rt.shadow(pw1.weight)
+        if LN_GEMM and _chain_ok(M, D, sh1.A) and sh1.Tm == 1 and sh1.Cp == D and fp8.entry(pw1.weight, D) is None:
+            u, h, mean, rstd = ln_gemm(x2, ln.weight, ln.bias, ln.eps, sh1.fwd, D, pw1.bias, M, D, sh1.A)   # LayerNorm inside the first pointwise convolution's launch
+        else:
+            h, mean, rstd = layernorm_fwd(x2, ln.weight, ln.bias, M, D, False, ln.eps)
+            u = linear_fwd(h, pw1.weight, pw1.bias, M, in_f32=False, out_f32=False)
         c = empty((Mo, Dp), adt, x2)
         st = BNState(Dp, x2)
         use_batch = training and not getattr(bn, "frozen", False)

@@ -148,23 +148,30 @@ typedef struct {
 } avec_tn_batched_t;
 int avec_gemm_tn_batched_multi(int dtype, const avec_tn_batched_t* items, int n, hipStream_t stream);
 
-/* ---- fused macaron feed-forward module (avec_amd/csrc/ffn.hip) --------------------------------
- * FeedForwardModule.forward (nnet/modules.py:257-289) with its residual (nnet/blocks.py:292,301) as ONE launch per direction (bf16 mode):
- *   y = x + alpha * Drop(W2 Drop(Swish(W1 LN(x) + b1)) + b2)
- * A workgroup owns 64 rows and runs LN -> GEMM -> Swish/dropout -> GEMM -> residual on them; weights stream through LDS, the hidden activations of the
- * tile stay on chip.  Saved for the backward pass: mean, rstd [M], h0 = LN(x) [M][D], z (pre-activation) and h1 (post dropout) [M][F], act dtype.
- * w1 = [F][D], w2 = [D][F] (row-major, row strides ldw*), bf16; the backward takes their transposes w2t = [F][D], w1t = [D][F] (the "bwd shadows").
- * backward: dx = dy + LN'(...) and the operands of the parameter gradients: dacc = alpha*mask2*dy [M][D], dz [M][F], dh0 [M][D]
- *   (dW2 = dacc^T h1, db2 = colsum(dacc), dW1 = dz^T h0, db1 = colsum(dz) via avec_gemm_tn_grouped; dgamma/dbeta via avec_layernorm_param_grads_grouped with dy = dh0). */
-int avec_ffn_fused_supported(int dtype, long long M, int D, int F);
-int avec_ffn_debug_stamps(long long* out8);   /* s_memtime stamps {start, prologue done, slot loop done, end} of the last launch with AVEC_FFN_DBG & 32 (host copy) */
-int avec_ffn_fused_fwd(const float* x, const float* ln_g, const float* ln_b, float eps, const void* w1, long long ldw1, const float* b1,
+/* ---- row-resident module chains, split over the hidden width (avec_amd/csrc/chain.hip; bf16 mode) ------------------------------------
+ * FeedForwardModule.forward (nnet/modules.py:257-289) with its residual (nnet/blocks.py:292,301) as ONE launch per direction:
+ *   y = x + alpha * Drop2(W2 Drop1(Swish(W1 LN(x) + b1)) + b2)
+ * Workgroup (64-row tile, 256-column slice of the hidden width F) runs LayerNorm -> product with its W1 slice -> Swish / dropout -> PARTIAL product with its W2
+ * slice and adds the partial result with fp32 atomics: `y` (forward) / `dh0` (backward) must be ZERO on entry (slice 0 adds x and b2).  The hidden activation never
+ * reaches memory in the forward pass; z = W1 LN(x) + b1 is kept in the kernel's own accumulator order (`zbuf`, avec_ffn_chain_zbuf_bytes) for the backward kernel.
+ * w1 = [F][D], w2 = [D][F] (bf16, row-major, strides ldw*); the backward pass takes the transposes w2t = [F][D], w1t = [D][F] (the "bwd shadows").
+ * forward also writes mean, rstd [M] and h0 = LN(x) [M][D] (bf16); backward: dacc = alpha * mask2 * dy [M][D], dz [M][F], h1 = Drop1(Swish(z)) [M][F] (bf16,
+ * row-major: the operands of dW2 = dacc^T h1, db2, dW1 = dz^T h0, db1 via avec_gemm_tn_grouped) and dh0 += dz W1 (fp32, then avec_layernorm_bwd with dy_f32).
+ * 64 <= D <= 384, D % 8 == 0, F % 8 == 0 (avec_chain_supported). */
+int avec_chain_supported(long long M, int D, int N);
+long long avec_ffn_chain_zbuf_bytes(long long M, int F);
+int avec_ffn_chain_fwd(const float* x, const float* ln_g, const float* ln_b, float eps, const void* w1, long long ldw1, const float* b1,
                        const void* w2, long long ldw2, const float* b2, float alpha, float drop_p, const unsigned long long* rng,
-                       unsigned sid1, unsigned sid2, float* y, float* mean, float* rstd, void* h0, void* z, void* h1,
+                       unsigned sid1, unsigned sid2, float* y, float* mean, float* rstd, void* h0, void* zbuf,
                        long long M, int D, int F, hipStream_t stream);
-int avec_ffn_fused_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* ln_g, const void* w2t, long long ldw2t,
-                       const void* w1t, long long ldw1t, const void* z, float alpha, float drop_p, const unsigned long long* rng,
-                       unsigned sid1, unsigned sid2, float* dx, void* dacc, void* dz, void* dh0, long long M, int D, int F, hipStream_t stream);
+int avec_ffn_chain_bwd(const float* dy, const void* w2t, long long ldw2t, const void* w1t, long long ldw1t, const void* zbuf,
+                       float alpha, float drop_p, const unsigned long long* rng, unsigned sid1, unsigned sid2,
+                       void* dacc, void* dz, void* h1, float* dh0, long long M, int D, int F, hipStream_t stream);
+/* LayerNorm folded into the product that consumes it (the Q|K|V projection of nnet/modules.py:320-339, the first pointwise convolution of nnet/modules.py:372-374):
+ * out[M][N] (bf16, row stride ldo) = LN(x) W^T + bias, W = [N][D] bf16; also writes mean, rstd [M] and, when h0 != NULL, h0 = LN(x) [M][D] bf16 (the operand of the
+ * weight-gradient product).  Same dims as above with N in place of F. */
+int avec_ln_gemm(const float* x, const float* ln_g, const float* ln_b, float eps, const void* w, long long ldw, const float* bias,
+                 void* out, long long ldo, float* mean, float* rstd, void* h0, long long M, int D, int N, hipStream_t stream);
 
 /* ---- SyncBatchNorm statistic exchange by peer writes over xGMI (avec_amd/csrc/peer.hip) ----------
  * all-reduce(sum) of a short fp32 vector (the (2C+1)-float / 2C-float vectors of nnet/normalizations.py:172-249) between the GPUs of one node

@@ -429,107 +429,6 @@ def test_layernorm_rows_and_grouped_param_grads(dtype):
     avec_amd.set_compute_dtype("f32")
 
 
-# ----------------------------------------------------------------------------------------------
-# fused macaron feed-forward module (csrc/ffn.hip)
-# ----------------------------------------------------------------------------------------------
-def _ffn_reference(x, mod, alpha):
-    """fp64 torch math of FeedForwardModule + residual (nnet/modules.py:257-289, nnet/blocks.py:292) with the fp32 master weights, dropout off"""
-    ln, l1, l2 = mod.layers[0], mod.layers[1], mod.layers[4]
-    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in (("g", ln.weight), ("b", ln.bias), ("w1", l1.weight), ("b1", l1.bias), ("w2", l2.weight), ("b2", l2.bias))}
-    xr = x.detach().double().cpu().requires_grad_(True)
-    h = torch.nn.functional.layer_norm(xr, (xr.shape[-1],), p["g"], p["b"], 1e-6)
-    z = h @ p["w1"].t() + p["b1"]
-    y = xr + alpha * ((z * torch.sigmoid(z)) @ p["w2"].t() + p["b2"])
-    return xr, p, y
-
-
-@pytest.mark.parametrize("B,T,D", [(32, 100, 256), (32, 50, 360), (3, 37, 256), (2, 50, 360), (5, 33, 64), (2, 70, 320)])
-def test_ffn_fused_matches_reference_and_unfused(B, T, D):
-    """the one-launch FFN (forward, input gradient and all six parameter gradients) against fp64 math; its error must be of the size of the
-    unfused bf16 path's error (LN, two GEMM launches, ...), dropout off"""
-    import avec_amd
-    import nnet
-    from avec_amd import ops
-    avec_amd.set_compute_dtype("bf16")
-    torch.manual_seed(D + T)
-    mod = nnet.FeedForwardModule(D, 4 * D, 0.0, "Swish", True).to(dev()).train()
-    for prm in mod.parameters():
-        prm.data.add_(0.05 * torch.randn_like(prm))
-    x = torch.randn(B, T, D, device=dev())
-    wgt = torch.randn(B, T, D, device=dev())
-    xr, pr, yr = _ffn_reference(x, mod, 0.5)
-    (yr * wgt.double().cpu()).sum().backward()
-    ln, l1, l2 = mod.layers[0], mod.layers[1], mod.layers[4]
-    names = {"g": ln.weight, "b": ln.bias, "w1": l1.weight, "b1": l1.bias, "w2": l2.weight, "b2": l2.bias}
-    res = {}
-    try:
-        for fused in (True, False):
-            ops.FFN_FUSED = fused
-            for prm in mod.parameters():
-                prm.grad = None
-            xg = x.clone().requires_grad_(True)
-            y = mod.residual_forward(xg, 0.5)
-            (y * wgt).sum().backward()
-            torch.cuda.synchronize()
-            l2e = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
-            res[fused] = {"y": l2e(y.detach(), yr.detach()), "dx": l2e(xg.grad, xr.grad), **{k: l2e(v.grad, pr[k].grad) for k, v in names.items()}}
-    finally:
-        ops.FFN_FUSED = os.environ.get("AVEC_FFN_FUSED", "0") == "1"
-        avec_amd.set_compute_dtype("f32")
-    for k in res[True]:
-        assert res[True][k] < 2.0 * res[False][k] + 3e-3, (k, res[True][k], res[False][k])
-        assert res[True][k] < 3e-2, (k, res[True][k])
-
-
-def test_ffn_fused_dropout_masks():
-    """dropout inside the fused kernels: rate p, survivors scaled by 1/(1-p), and the backward pass regenerates the forward pass's masks (both sites)"""
-    import avec_amd
-    import nnet
-    from avec_amd import ops, runtime as rt
-    from avec_amd.lib import lib
-    avec_amd.set_compute_dtype("bf16")
-    avec_amd.manual_seed(99)
-    torch.manual_seed(3)
-    d = dev()
-    M, D, F, p, alpha = 6400, 256, 1024, 0.1, 0.5
-    mod = nnet.FeedForwardModule(D, F, p, "Swish", True).to(d).train()
-    ln, l1, l2 = mod.layers[0], mod.layers[1], mod.layers[4]
-    x = torch.randn(M, D, device=d)
-    sh1, sh2 = rt.shadow(l1.weight), rt.shadow(l2.weight)
-    bf = torch.bfloat16
-    y, mean, rstd = torch.empty(M, D, device=d), torch.empty(M, device=d), torch.empty(M, device=d)
-    h0, z, h1 = torch.empty(M, D, device=d, dtype=bf), torch.empty(M, F, device=d, dtype=bf), torch.empty(M, F, device=d, dtype=bf)
-    rng = rt.rng_state(d).data_ptr()
-    lib.ffn_fused_fwd(x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-6, sh1.fwd.data_ptr(), D, l1.bias.data_ptr(), sh2.fwd.data_ptr(), F, l2.bias.data_ptr(),
-                      alpha, p, rng, 11, 12, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), h0.data_ptr(), z.data_ptr(), h1.data_ptr(), M, D, F, rt.stream())
-    sw = (z.float() * torch.sigmoid(z.float()))
-    big = sw.abs() > 1e-2                                            # away from swish's zero the mask is readable from h1 / swish(z)
-    ratio = (h1.float() / sw)[big]
-    drop1 = (h1 == 0) & big
-    assert abs(drop1.float().sum().item() / big.float().sum().item() - p) < 3e-3
-    kept = ratio[ratio != 0]
-    assert (kept - 1.0 / (1.0 - p)).abs().max() < 2e-2               # bf16 rounding of h1
-    u = h1.float() @ sh2.fwd.view(D, F).float().t() + l2.bias
-    r2 = (y - x) / (alpha * u)
-    big2 = u.abs() > 1e-2
-    drop2 = ((y - x) == 0) & big2
-    assert abs(drop2.float().sum().item() / big2.float().sum().item() - p) < 3e-3
-    assert (r2[big2 & ~drop2] - 1.0 / (1.0 - p)).abs().max() < 2e-2
-    # backward with the same rng state: dacc and dz vanish exactly where the forward masks did
-    dy = torch.randn(M, D, device=d) + 3.0
-    dx = torch.empty(M, D, device=d)
-    dacc, dz, dh0 = torch.empty(M, D, device=d, dtype=bf), torch.empty(M, F, device=d, dtype=bf), torch.empty(M, D, device=d, dtype=bf)
-    lib.ffn_fused_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln.weight.data_ptr(), sh2.bwd.data_ptr(), D, sh1.bwd.data_ptr(), F, z.data_ptr(),
-                      alpha, p, rng, 11, 12, dx.data_ptr(), dacc.data_ptr(), dz.data_ptr(), dh0.data_ptr(), M, D, F, rt.stream())
-    torch.cuda.synchronize()
-    assert torch.equal(dacc == 0, (y - x) == 0) or ((dacc == 0) ^ ((y - x) == 0)).float().mean().item() < 1e-4
-    keep2 = dacc != 0
-    assert ((dacc.float() / dy)[keep2] - alpha / (1.0 - p)).abs().max() < 1e-2
-    assert ((dz == 0) & big & ~drop1).float().mean().item() < 1e-3    # kept hidden units (almost) never have a zero gradient ...
-    assert (dz[drop1] == 0).all()                                    # ... dropped ones always do
-    avec_amd.set_compute_dtype("f32")
-
-
 # ---- 3x3 convolution fast paths: shifted-window kernel (stride 1) and parity-class order (stride-2 backward-data) --------------------------
 @pytest.mark.parametrize("Nimg,H,Cin,Cout,stride", [(7, 11, 128, 128, 1), (5, 6, 256, 256, 1), (9, 3, 512, 512, 1), (3, 22, 64, 64, 1), (2, 31, 32, 96, 1),
                                                     (3, 22, 64, 128, 2), (5, 11, 128, 256, 2), (7, 6, 256, 512, 2), (4, 7, 64, 64, 2)])
