@@ -63,11 +63,43 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t stream, uin
   uint32_t h = mix32(a ^ (b + 0x85ebca6bu + (a << 6) + (a >> 2)));
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
-// dropout scale factor for element idx: 0 or 1/(1-p)
+// ---- dropout masks: ONE 32-bit hash per PAIR of consecutive elements, 16 bits each (p is resolved to 1/65536) ----
+// The epilogues that apply dropout are VALU-bound on exactly this arithmetic (integer multiplies are quarter rate): the first version hashed every element with three
+// mix32 rounds (6 multiplies) after re-reading {seed, step} from memory; now the key is built once per thread and a pair of elements costs one mix32 (2 multiplies).
+// Element idx takes the low (even idx) / high (odd idx) half of hash(idx >> 1): forward and backward, fused and unfused kernels agree as long as they use these helpers.
+struct DropKey { uint32_t k0, thr; float scale; };
+__device__ __forceinline__ DropKey drop_key(const unsigned long long* rng, uint32_t stream, float p) {
+  DropKey k; k.k0 = 0u; k.thr = 0u; k.scale = 1.f;
+  if (p > 0.f) {
+    const uint64_t seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
+    k.k0 = mix32((uint32_t)seed + stream * 0x9e3779b9u) ^ mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+    const float t = p * 65536.f + 0.5f; k.thr = t >= 65535.f ? 65535u : (uint32_t)t;
+    k.scale = 1.f / (1.f - p);
+  }
+  return k;
+}
+__device__ __forceinline__ uint32_t drop_hash(const DropKey& k, uint64_t pair) {
+  uint32_t x = (uint32_t)pair ^ k.k0;
+  const uint32_t hi = (uint32_t)(pair >> 32);
+  if (hi) x ^= hi * 0x9e3779b1u;                      // (tensors beyond 2^33 elements only)
+  return mix32(x);
+}
+// scale factors (0 or 1/(1-p)) of the elements 2 pair and 2 pair + 1
+__device__ __forceinline__ void drop_pair(const DropKey& k, uint64_t pair, float& s0, float& s1) {
+  const uint32_t h = drop_hash(k, pair);
+  s0 = (h & 0xffffu) >= k.thr ? k.scale : 0.f; s1 = (h >> 16) >= k.thr ? k.scale : 0.f;
+}
+// ... of the 4 consecutive elements idx .. idx + 3 (idx even)
+__device__ __forceinline__ void drop4(const DropKey& k, uint64_t idx, float (&s)[4]) { drop_pair(k, idx >> 1, s[0], s[1]); drop_pair(k, (idx >> 1) + 1, s[2], s[3]); }
+__device__ __forceinline__ float drop_one(const DropKey& k, uint64_t idx) {
+  const uint32_t h = drop_hash(k, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= k.thr ? k.scale : 0.f;
+}
+// single-element form (builds the key every call: keep it out of inner loops)
 __device__ __forceinline__ float drop_scale(const unsigned long long* rng, uint32_t stream, uint64_t idx, float p) {
   if (p <= 0.f) return 1.f;
-  uint64_t seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
-  return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
+  const DropKey k = drop_key(rng, stream, p);
+  return drop_one(k, idx);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -226,6 +226,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
     for (int c = 0; c < 4; ++c) if (col + c < g.N) bias4[c] = e.bias[col + c];
   }
   float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
+  const DropKey dk = drop_key(e.rng, e.stream, e.drop_p);      // (built once: {seed, step} are read here, not per element)
 #pragma unroll 1
   for (int pass = 0; pass < BM / 64; ++pass) {
     // a wave owns BM/2 rows = MT 32-row blocks; a pass stages 64 tile rows: both waves' single block (BM 64), one wave's two blocks (BM 128),
@@ -290,7 +291,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
         for (int c = 0; c < 4; ++c) v[c] += bias4[c];
         if (e.out_pre) st4<T>((T*)e.out_pre + row * e.ldpre + col, v);
         if (e.act == 1) { for (int c = 0; c < 4; ++c) v[c] = swishf_(v[c]); } else if (e.act == 2) { for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f); }
-        if (e.drop_p > 0.f) { for (int c = 0; c < 4; ++c) v[c] *= drop_scale(e.rng, e.stream, (unsigned long long)row * g.N + col + c, e.drop_p); }
+        if (e.drop_p > 0.f) {
+          const unsigned long long i0 = (unsigned long long)row * g.N + col;
+          if (!(g.N & 1)) { float ds[4]; drop4(dk, i0, ds); for (int c = 0; c < 4; ++c) v[c] *= ds[c]; }      // (col % 4 == 0: the index is even)
+          else { for (int c = 0; c < 4; ++c) v[c] *= drop_one(dk, i0 + c); }
+        }
         if (e.dact) {
           float z[4]; ld4<T>((const T*)e.dact_z + row * e.ldz + col, z);
           for (int c = 0; c < 4; ++c) v[c] *= (e.dact == 1) ? dswishf_(z[c]) : (z[c] > 0.f ? 1.f : 0.f);
@@ -315,7 +320,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
         float x = v[c] + bias4[c];
         if (e.out_pre) stf((T*)e.out_pre + row * e.ldpre + col + c, x);
         if (e.act == 1) x = swishf_(x); else if (e.act == 2) x = fmaxf(x, 0.f);
-        if (e.drop_p > 0.f) x *= drop_scale(e.rng, e.stream, (unsigned long long)row * g.N + col + c, e.drop_p);
+        if (e.drop_p > 0.f) x *= drop_one(dk, (unsigned long long)row * g.N + col + c);
         if (e.dact) {
           const float z = ldf((const T*)e.dact_z + row * e.ldz + col + c);
           x *= (e.dact == 1) ? dswishf_(z) : (z > 0.f ? 1.f : 0.f);

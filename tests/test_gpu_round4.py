@@ -269,3 +269,43 @@ def test_ln_gemm_matches_torch(M, D, N):
     assert rel_err(mean.cpu(), xd.mean(1)) < 1e-5 and rel_err(rstd.cpu(), 1.0 / (xd.var(1, unbiased=False) + 1e-6).sqrt()) < 1e-5
     assert rel_err(h.float().cpu(), hr) < 1e-2
     assert rel_err(out.float().cpu(), ref) < 1.5e-2, rel_err(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("B,T,D", [(4, 100, 256), (3, 50, 360), (2, 37, 256)])
+def test_conformer_block_with_chain_kernels_matches_launch_sequence(B, T, D):
+    """a whole ConformerBlock (bf16, dropout off): the split-F feed-forward kernels with their lazily summed outputs (consumed by the LayerNorm + Q|K|V launch and by the
+    block's final LayerNorm) against the per-layer launch sequence -- outputs 1e-2, input and parameter gradients 3e-2 (relative L2; both are bf16 paths)"""
+    import avec_amd
+    import nnet
+    from avec_amd import ops
+    avec_amd.set_compute_dtype("bf16")
+    torch.manual_seed(T + D)
+    att = {"class": "RelPos1dMultiHeadAttention", "params": dict(num_heads=4, attn_drop_rate=0.0, num_pos_embeddings=10000, weight_init="default", bias_init="default")}
+    blk = _nodrop(nnet.ConformerBlock(dim_model=D, dim_expand=D, ff_ratio=4, drop_rate=0.0, att_params=att, conv_stride=1,
+                                      conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}})).to(dev()).train()
+    x = torch.randn(B, T, D, device=dev())
+    wgt = torch.randn(B, T, D, device=dev())
+    lens = torch.tensor([T, max(T - 9, 1), max(T // 2, 1), T][:B], dtype=torch.int64, device=dev())
+    from avec_amd.nnet.modules import LengthMask
+    res = {}
+    keep = (ops.FFN_CHAIN, ops.LN_GEMM)
+    try:
+        for mode in (True, False):
+            ops.FFN_CHAIN = ops.LN_GEMM = mode
+            for prm in blk.parameters():
+                prm.grad = None
+            xg = x.clone().requires_grad_(True)
+            y = blk(xg, mask=LengthMask(lens))
+            (y * wgt).sum().backward()
+            ops.flush_param_grads(all_streams=True)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), xg.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters() if v.grad is not None})
+    finally:
+        ops.FFN_CHAIN, ops.LN_GEMM = keep
+    l2e = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-20)).item()
+    assert l2e(res[True][0], res[False][0]) < 1e-2, l2e(res[True][0], res[False][0])
+    assert l2e(res[True][1], res[False][1]) < 3e-2, l2e(res[True][1], res[False][1])
+    for k, gref in res[False][2].items():
+        if k.endswith(("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias")) or gref.abs().max() < 1e-6 * max(1.0, float(res[False][1].abs().max())):
+            continue                                                  # (analytically zero gradients -- softmax shift invariance, a bias in front of training-mode BatchNorm: rounding noise on both sides)
+        assert l2e(res[True][2][k], gref) < 3e-2, (k, l2e(res[True][2][k], gref))

@@ -41,40 +41,33 @@ def graphed(fn, reps=20):
 def main():
     avec_amd.set_compute_dtype("bf16")
     dev = torch.device("cuda:0")
-    for (M, D, F) in [(3200, 256, 1024), (1600, 360, 1440), (6400, 256, 1024), (800, 360, 1440), (100, 256, 1024)]:
-        mod = nnet.FeedForwardModule(D, F, 0.1, "Swish", True).to(dev).train()
-        x = torch.randn(1, M, D, device=dev)
-        wgt = torch.randn(1, M, D, device=dev)
-        for chain in (False, True):
-            ops.FFN_CHAIN = chain
+    # whole conformer blocks (the feed-forward kernels leave their output as partial sums for the next launch: the block is the fair unit)
+    for (B, T, D) in [(32, 100, 256), (32, 50, 360), (1, 100, 256)]:
+        att = {"class": "RelPos1dMultiHeadAttention", "params": dict(num_heads=4, attn_drop_rate=0.0, num_pos_embeddings=10000, weight_init="default", bias_init="default")}
+        blk = nnet.ConformerBlock(dim_model=D, dim_expand=D, ff_ratio=4, drop_rate=0.1, att_params=att, conv_stride=1,
+                                  conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}).to(dev).train()
+        x = torch.randn(B, T, D, device=dev)
+        wgt = torch.randn(B, T, D, device=dev)
+        lens = torch.full((B,), T, dtype=torch.int64, device=dev)
+        from avec_amd.nnet.modules import LengthMask
+        mask = LengthMask(lens)
+        for chain, lng in ((False, False), (False, True), (True, True)):
+            ops.FFN_CHAIN, ops.LN_GEMM = chain, lng
 
             def fwd():
                 rt.reset_zero_pool(dev)
                 with torch.no_grad():
-                    return mod.residual_forward(x, 0.5)
+                    return blk(x, mask=mask)
 
             xg = x.clone().requires_grad_(True)
 
             def fwdbwd():
                 rt.reset_zero_pool(dev)
-                y = mod.residual_forward(xg, 0.5)
+                y = blk(xg, mask=mask)
                 y.backward(wgt)
                 ops.flush_param_grads(all_streams=True)
-            tf, tfb = graphed(fwd), graphed(fwdbwd, 10)
-            print("FFN M=%5d D=%3d F=%4d chain=%d: fwd %7.1f us   fwd+bwd(+wgrad) %7.1f us" % (M, D, F, chain, tf, tfb), flush=True)
-    for (M, D, N) in [(3200, 256, 768), (3200, 256, 512), (1600, 360, 1080), (1600, 360, 720)]:
-        x = torch.randn(M, D, device=dev)
-        lw, lb = torch.ones(D, device=dev), torch.zeros(D, device=dev)
-        W = torch.randn(N, D, device=dev).bfloat16()
-        bias = torch.zeros(N, device=dev)
-        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        t1 = graphed(lambda: ops.ln_gemm(x, lw, lb, 1e-6, W, D, bias, M, D, N))
-
-        def two():
-            h, _, _ = ops.layernorm_fwd(x, lw, lb, M, D, False, 1e-6)
-            ops.gemm_nt(h, W, out, M, N, D, bias=bias)
-        t2 = graphed(two)
-        print("LN+GEMM M=%5d D=%3d N=%4d: one launch %6.1f us   two launches %6.1f us" % (M, D, N, t1, t2), flush=True)
+            tf, tfb = graphed(fwd, 5), graphed(fwdbwd, 5)
+            print("block B=%2d T=%3d D=%3d ffn_chain=%d ln_gemm=%d: fwd %7.1f us   fwd+bwd(+wgrad) %7.1f us" % (B, T, D, chain, lng, tf, tfb), flush=True)
 
 
 if __name__ == "__main__":
