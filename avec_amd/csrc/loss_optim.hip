@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
 //   phase 3  gradient rows, one frame per wave (occupancy scatter into a per-wave LDS histogram)
 __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
                                              const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
-                                             int B, int T, int V, int Lmax, int blank, int zero_inf, int b) {
+                                             int B, int T, int V, int Lmax, int blank, int zero_inf, int b, float* total = nullptr, float wtot = 0.f) {
   extern __shared__ float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int Smax = 2 * Lmax + 1;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, c
   float loss = -ll;
   const bool inf = !(loss < INFINITY);
   if (inf && zero_inf) loss = 0.f;
-  if (tid == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); }
+  if (tid == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); if (total) atomicAdd(total, wtot * loss / B); }
   if (!gr) return;
   for (int i = tid; i < (T - Tb) * V; i += 256) gr[(long long)Tb * V + i] = 0.f;
   if (inf || Tb == 0) { for (int i = tid; i < Tb * V; i += 256) gr[i] = 0.f; return; }
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
 // 192 CUs instead of 32 six times).  blockIdx.x = head * B + utterance.
 #define AVEC_CTC_MAX_HEADS 8
 struct CtcHeads { const float* logits[AVEC_CTC_MAX_HEADS]; const long long* in_lens[AVEC_CTC_MAX_HEADS]; float* nll[AVEC_CTC_MAX_HEADS]; float* mean_out[AVEC_CTC_MAX_HEADS];
-                  float* grad[AVEC_CTC_MAX_HEADS]; int T[AVEC_CTC_MAX_HEADS]; };
+                  float* grad[AVEC_CTC_MAX_HEADS]; int T[AVEC_CTC_MAX_HEADS]; float w[AVEC_CTC_MAX_HEADS]; float* total; };
 __global__ __launch_bounds__(256) void ctc_lds_multi_kernel(CtcHeads h, const long long* __restrict__ targets, const long long* __restrict__ tgt_lens,
                                                             int B, int V, int Lmax, int blank, int zero_inf) {
   const int head = blockIdx.x / B, b = blockIdx.x - head * B;
-  ctc_lds_body(h.logits[head], h.in_lens[head], targets, tgt_lens, h.nll[head], h.mean_out[head], h.grad[head], B, h.T[head], V, Lmax, blank, zero_inf, b);
+  ctc_lds_body(h.logits[head], h.in_lens[head], targets, tgt_lens, h.nll[head], h.mean_out[head], h.grad[head], B, h.T[head], V, Lmax, blank, zero_inf, b, h.total, h.w[head]);
 }
 
 // Long-utterance variant (used when the three [T][S] arrays above do not fit: 15 s clips have T = 376 frames at the inter-CTC heads): only alpha lives in LDS.
@@ -301,15 +301,16 @@ extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, cons
 }
 
 extern "C" int avec_ctc_loss_multi(int n_heads, const float* const* logits, const long long* const* in_lens, const int* T, float* const* nll, float* const* mean_out, float* const* grad,
-                                   const long long* targets, const long long* tgt_lens, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
+                                   const long long* targets, const long long* tgt_lens, const float* weights, float* total, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
+  AVEC_CHECK_ARG(!total || weights, "ctc_loss_multi: a weighted total needs the weights");
   AVEC_CHECK_ARG(n_heads >= 1 && n_heads <= AVEC_CTC_MAX_HEADS && logits && in_lens && T && nll && mean_out && grad && targets && tgt_lens, "ctc_loss_multi: bad arguments (%d heads)", n_heads);
   AVEC_CHECK_ARG(B > 0 && V > 0 && Lmax >= 0 && blank >= 0 && blank < V, "ctc_loss_multi: bad dims");
-  CtcHeads h; size_t lds = 0;
+  CtcHeads h; size_t lds = 0; h.total = total;
   const size_t Smax = 2 * (size_t)Lmax + 1;
   for (int i = 0; i < AVEC_CTC_MAX_HEADS; ++i) {
     const int k = i < n_heads ? i : 0;
     AVEC_CHECK_ARG(logits[k] && in_lens[k] && nll[k] && T[k] > 0, "ctc_loss_multi: null buffer in head %d", k);
-    h.logits[i] = logits[k]; h.in_lens[i] = in_lens[k]; h.nll[i] = nll[k]; h.mean_out[i] = mean_out[k]; h.grad[i] = grad[k]; h.T[i] = T[k];
+    h.logits[i] = logits[k]; h.in_lens[i] = in_lens[k]; h.nll[i] = nll[k]; h.mean_out[i] = mean_out[k]; h.grad[i] = grad[k]; h.T[i] = T[k]; h.w[i] = (weights && i < n_heads) ? weights[i] : 0.f;
     const size_t need = (3 * (size_t)T[k] * Smax + T[k] + 4 * (size_t)V + Smax) * 4;
     if (need > lds) lds = need;
   }

@@ -95,3 +95,15 @@ extern "C" int avec_upsample_rows(int dtype, const void* src, void* dst, long lo
   DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_rows_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, (const T*)src, (T*)dst, B, T_, D, P, backward));
   AVEC_LAUNCH_CHECK(); return 0;
 }
+
+// lengths after a strided layer (nnet/preprocessing.py:77, nnet/modules.py:127-128, nnet/networks.py:298,302): out = (in - sub) / div + add on int64, ONE launch
+// instead of the three ATen element-wise launches (sub, floor-div, add) that each such point of the forward pass used to put on the dependent chain
+__global__ void len_affine_kernel(const long long* __restrict__ in, long long* __restrict__ out, int n, long long sub, long long div, long long add) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) { const long long v = in[i] - sub; const long long q = v / div; out[i] = ((v % div != 0) && ((v < 0) != (div < 0)) ? q - 1 : q) + add; }      // floor division
+}
+extern "C" int avec_len_affine(const long long* in, long long* out, int n, long long sub, long long div, long long add, hipStream_t st) {
+  AVEC_CHECK_ARG(in && out && n > 0 && div != 0, "len_affine: bad arguments");
+  hipLaunchKernelGGL(len_affine_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n, sub, div, add);
+  AVEC_LAUNCH_CHECK(); return 0;
+}

@@ -155,7 +155,7 @@ class Model(Module):
     # -- one forward + losses (nnet/model.py:227-344) ---------------------------------------------
     def forward_model(self, inputs, targets, compute_metrics=True, verbose=0):
         batch_losses, batch_metrics, batch_truths, batch_preds = {}, {}, {}, {}
-        total_loss = torch.zeros((), device=self.device)
+        total_loss = None                        # (no zero-filled accumulator: with the fused CTC heads the weighted total comes out of their launch as is)
         Model._pre_forward(self, None)       # self.forward() is called directly (no __call__): the pre-forward hook would not fire on the training / evaluation paths
         outputs = self.forward(inputs)
         if isinstance(outputs, list):
@@ -167,7 +167,7 @@ class Model(Module):
             self.build(outputs)
         fused, fused_total = self._fused_ctc_losses(outputs, targets)
         if fused_total is not None:
-            total_loss = total_loss + fused_total
+            total_loss = fused_total
         for key in outputs:
             if self.losses[key] is not None:
                 if key in fused:                     # already inside fused_total with its weight
@@ -175,7 +175,8 @@ class Model(Module):
                 else:
                     l = self.losses[key](targets[key], outputs[key])
                     batch_losses["loss_" + key] = l
-                    total_loss = total_loss + l * self.loss_weights[key].get_val_step(self.model_step + 1)
+                    wl = l * self.loss_weights[key].get_val_step(self.model_step + 1)
+                    total_loss = wl if total_loss is None else total_loss + wl
             if compute_metrics and self.metrics and self.metrics[key] is not None:
                 metric, decoder = self.metrics[key], (self.decoders[key] if self.decoders else None)
                 name = metric.name if metric.name not in batch_metrics else metric.name + "_" + key
@@ -189,8 +190,11 @@ class Model(Module):
             if getattr(module, "added_losses", None):
                 for key, value in module.added_losses.items():
                     batch_losses["loss_" + key] = value["loss"]
-                    total_loss = total_loss + value["loss"] * value["weight"]
+                    wl = value["loss"] * value["weight"]
+                    total_loss = wl if total_loss is None else total_loss + wl
                 module.reset_losses()
+        if total_loss is None:
+            total_loss = torch.zeros((), device=self.device)
         batch_losses = dict({"loss": total_loss}, **batch_losses) if len(batch_losses) > 1 else {"loss": total_loss}
         return batch_losses, batch_metrics, batch_truths, batch_preds
 

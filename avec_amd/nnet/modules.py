@@ -15,7 +15,7 @@ class LengthMask:
         self.lengths = lengths
 
     def strided(self, s):
-        return LengthMask(torch.div(self.lengths - 1, s, rounding_mode="floor") + 1)
+        return LengthMask(ops.len_affine(self.lengths, 1, s, 1))
 
 
 def _act_params(act_fun):

@@ -72,6 +72,15 @@ class ConformerInterCTC(nn.Module):
                     self.interctc_modules.append(modules.InterCTCResModule(dim_model=d_out, vocab_size=vocab_size))
                 i += 1
 
+        # the position projections of the consecutive blocks of a stage share their input (the sinusoid table of the stage's sequence length): one [L D][D] weight in the
+        # arena -> one launch per stage and pass instead of one per block (ops._pos_group_entry); state_dict names are unchanged
+        i0 = 0
+        for nb in num_blocks:
+            atts = [getattr(b.self_att_module, "attention", None) for b in self.conformer_blocks[i0:i0 + nb]]
+            i0 += nb
+            pos = [a.pos_layer for a in atts if a is not None and type(a).__name__ in ("RelPos1dMultiHeadAttention", "RelPosPatch1dMultiHeadAttention") and hasattr(a, "pos_layer")]
+            if len(pos) == len(atts) and len(pos) >= 2 and all(p.bias is not None and p.weight.shape == pos[0].weight.shape for p in pos):
+                rt.fuse_linears(self, [p.weight for p in pos], [p.bias for p in pos])
         if any(getattr(m, "causal", False) for m in self.modules()):
             # causal relative positions (nnet/attentions.py:234-256): for j <= i the reference reads E[i-j], as the full-context layout does; for j > i its
             # rel_to_abs wraps around into the next query row.  Only a mask that hides every j > i makes that well defined -- required here, not reproduced.
@@ -92,10 +101,14 @@ class ConformerInterCTC(nn.Module):
                 x, logits = self.interctc_modules[j](x)
                 j += 1
             if block.stride > 1:
-                if mask is not None:
-                    mask = mask.strided(block.stride) if isinstance(mask, modules.LengthMask) else mask[:, :, ::block.stride, ::block.stride]
+                same = isinstance(mask, modules.LengthMask) and mask.lengths is lengths      # the length mask carries the very vector that is strided below: computed once
                 if lengths is not None:
-                    lengths = torch.div(lengths - 1, block.stride, rounding_mode="floor") + 1
+                    lengths = ops.len_affine(lengths, 1, block.stride, 1)
+                if mask is not None:
+                    if isinstance(mask, modules.LengthMask):
+                        mask = modules.LengthMask(lengths) if same else mask.strided(block.stride)
+                    else:
+                        mask = mask[:, :, ::block.stride, ::block.stride]
             if logits is not None:
                 inter[self.loss_prefix + "_" + str(i)] = [logits, lengths]
         return x, lengths, inter
@@ -138,7 +151,7 @@ class AudioEfficientConformerEncoder(nn.Module):
         mel = self.spec_augment(mel, lengths)
         stem = self.subsampling_module.layers[0]
         a = ops.AudioStemFn.apply(mel, stem[0].weight, stem[0], stem[1], stem[1].training and not stem[1].frozen)     # (B, T', 7200) act
-        lengths = torch.div(lengths - 1, 2, rounding_mode="floor") + 1
+        lengths = ops.len_affine(lengths, 1, 2, 1)
         x = ops.linear(a, self.linear.weight, self.linear.bias)
         x, lengths, inter = self.back_end(x, lengths)
         if not isinstance(self.head, nn.Identity):

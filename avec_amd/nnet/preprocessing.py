@@ -62,7 +62,7 @@ class AudioPreprocessing(nn.Module):
             mel = ops.mel_spectrogram(x.float(), self.Spectrogram.window, self._dft_matrix(x.device), self.MelScale.fb,
                                       self.n_fft, self.win_length, self.hop_length, self.n_mels)
         if lengths is not None:
-            lengths = torch.div(lengths, self.hop_length, rounding_mode="floor") + 1
+            lengths = ops.len_affine(lengths, 0, self.hop_length, 1)
         if self.normalize:
             mel = (mel - self.mean) / self.std
         mel = mel.type(dtype) if dtype.is_floating_point else mel

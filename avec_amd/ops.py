@@ -764,13 +764,68 @@ def _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D, q_full=0):
     a.q_full = q_full
     esz = qkv.element_size()
     a.q, a.k, a.v, a.ld = qkv.data_ptr(), qkv.data_ptr() + D * esz, qkv.data_ptr() + 2 * D * esz, 3 * D
-    a.e, a.lde = e.data_ptr(), D
+    a.e, a.lde = e.data_ptr(), (e.stride(0) if e.dim() == 2 else D)      # (a column slice of a stack's fused position projections: row stride L * D)
     a.lens, a.len_div = _p(lens), len_div
     if mask is not None:
         a.mask, a.mask_bstride = mask.data_ptr(), (T * T if mask.shape[0] > 1 else 0)
     a.o, a.ldo, a.lse = o.data_ptr(), D, lse.data_ptr()
     a.B, a.H, a.T, a.d, a.scale = B, H, T, d, 1.0 / d ** 0.5
     return a
+
+
+# ---- position projections of a whole stack in one launch ---------------------------------------------------------------------------------------------------
+# E_l = pos_layer_l(PE) depends on weights only (nnet/attentions.py:289, nnet/embeddings.py:158: the reference recomputes it per block AND per batch element).
+# The pos_layer weights of the consecutive blocks of a stage are laid out back to back in the arena (nnet.ConformerInterCTC declares them with rt.fuse_linears), so
+# ONE product PE [2T-1][D] x W_all^T [D][L D] gives every block's E as a column slice, and in backward the L gradients dE_l accumulate in one [2T-1][L D] buffer that
+# takes ONE cast and ONE weight-gradient product when the last of them has arrived: 2 (L - 1) launches less per stage and pass.  Versioned by the arena's shadow
+# refresh counter (E follows the weights), per sequence length.
+POS_GROUP = os.environ.get("AVEC_POS_GROUP", "1") != "0"
+_POS_CACHE = {}
+
+
+class _PosGroupEntry:
+    __slots__ = ("e_all", "pe", "de_all", "remaining", "L", "D", "Tp")
+
+
+def _pos_group_entry(wp, Tp, D, device):
+    """-> (entry, index of this layer inside its group) or (None, 0)"""
+    if not POS_GROUP or rt.compute_dtype() != "bf16":
+        return None, 0
+    grp = rt.fused_group(wp)
+    if grp is None or len(grp.weights) < 2 or fp8.enabled():
+        return None, 0
+    idx = next((k for k, w in enumerate(grp.weights) if w is wp), None)
+    if idx is None:
+        return None, 0
+    arena = wp._avec_shadow.arena
+    key = (id(grp), Tp, str(device))
+    ent = _POS_CACHE.get(key)
+    ver = (getattr(arena, "refresh_count", 0), torch.cuda.current_stream().cuda_stream)
+    if ent is None or ent[0] != ver:
+        L = len(grp.weights)
+        e = _PosGroupEntry()
+        e.L, e.D, e.Tp, e.pe = L, D, Tp, rel_pos_table(Tp, D, device)
+        e.e_all = empty((2 * Tp - 1, L * D), rt.act_dtype(), e.pe)
+        gemm_nt(e.pe, grp.fwd, e.e_all, 2 * Tp - 1, L * D, D, bias=grp.bias)
+        e.de_all, e.remaining = None, L
+        _POS_CACHE[key] = ent = (ver, e, grp)
+        if len(_POS_CACHE) > 64:
+            for k in list(_POS_CACHE)[:32]:
+                _POS_CACHE.pop(k, None)
+    return ent[1], idx
+
+
+def _pos_group_backward(entry, wp):
+    """one layer of the group has accumulated its dE: when all have, cast once and queue ONE weight-gradient product for the whole group"""
+    entry.remaining -= 1
+    if entry.remaining > 0:
+        return
+    grp = rt.fused_group(wp)
+    R, W = 2 * entry.Tp - 1, entry.L * entry.D
+    dea = empty((R, W), rt.act_dtype(), entry.de_all)
+    lib.cast_rows(rt.dt(), entry.de_all.data_ptr(), W, dea.data_ptr(), W, R, W, rt.stream())
+    gemm_tn(dea, entry.pe, grp.wgrad, R, W, entry.D, p_colsum=grp.bgrad, side=True)
+    entry.de_all, entry.remaining = None, entry.L
 
 
 class AttentionModuleFn(torch.autograd.Function):
@@ -820,8 +875,12 @@ class AttentionModuleFn(torch.autograd.Function):
             for i, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
                 sh = rt.shadow(w)
                 gemm_nt(hp, sh.fwd, qkv[:, i * D:], Mp, D, D, bias=b, ldo=3 * D)
-        pe = rel_pos_table(Tp, D, x.device)
-        e = linear_fwd(pe, wp, bp, 2 * Tp - 1, in_f32=False, out_f32=False)
+        pg, pgi = _pos_group_entry(wp, Tp, D, x.device)
+        if pg is not None:
+            pe, e = pg.pe, pg.e_all[:, pgi * D:(pgi + 1) * D]          # this block's slice of the stack's position projections (one launch per stage and pass)
+        else:
+            pe = rel_pos_table(Tp, D, x.device)
+            e = linear_fwd(pe, wp, bp, 2 * Tp - 1, in_f32=False, out_f32=False)
         o = empty((Mp, D), adt, x2)
         lse = empty((B * H, Tp, 2), torch.float32, x2)
         q_full = T // patch if (patch > 1 and mask is None) else 0
@@ -838,6 +897,7 @@ class AttentionModuleFn(torch.autograd.Function):
             y = linear_fwd(o, wo, bo, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid, res=res, alpha=1.0)
         ctx.saved = (x2, mean, rstd, h, hp, qkv, pe, e, o, lse, lens, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wp, bp,
                      H, patch, drop_p, sid, residual, B, T, Tp, D)
+        ctx.pos_group = (pg, pgi)
         ctx.prep_req = _prep_request(x)
         return _tag_prep(y.view(B, T, D), 1.0, drop_p, sid) if patch == 1 else y.view(B, T, D)
 
@@ -858,19 +918,29 @@ class AttentionModuleFn(torch.autograd.Function):
         linear_bwd_weight(doo, o, wo, Mp, bias=bo)
         do = linear_bwd_input(doo, wo, Mp, out_f32=False)
         dqkv = empty((Mp, 3 * D), adt, dy)
-        de = rt.zeros_scratch((2 * Tp - 1) * D, dy.device).view(2 * Tp - 1, D)      # pre-zeroed pool: no fill launch per layer (-0.15 ms per step)
+        pg, pgi = ctx.pos_group
+        if pg is not None:
+            if pg.de_all is None:                    # first layer of the group to reach its backward: the shared [2T-1][L D] accumulator (pre-zeroed pool)
+                pg.de_all = rt.zeros_scratch((2 * Tp - 1) * pg.L * D, dy.device).view(2 * Tp - 1, pg.L * D)
+            de = pg.de_all[:, pgi * D:(pgi + 1) * D]
+        else:
+            de = rt.zeros_scratch((2 * Tp - 1) * D, dy.device).view(2 * Tp - 1, D)      # pre-zeroed pool: no fill launch per layer (-0.15 ms per step)
         a = _attn_args(qkv, e, lens, patch, mask, o, lse, B, H, Tp, d, D, T // patch if (patch > 1 and mask is None) else 0)
         a.dout = do.data_ptr()
         esz = dqkv.element_size()
         a.dq, a.lddq = dqkv.data_ptr(), 3 * D
         a.dk, a.dv, a.ldd = dqkv.data_ptr() + D * esz, dqkv.data_ptr() + 2 * D * esz, 3 * D
-        a.de, a.ldde = de.data_ptr(), D
+        a.de, a.ldde = de.data_ptr(), de.stride(0)
         Tld, Rld = (Tp + 7) // 8 * 8, (2 * Tp - 1 + 7) // 8 * 8
         scratch = empty((2, B * H, Tp, Tld), adt, dy)                # P and dS of every (batch, head), row stride padded to 8
         a.pbuf, a.dsbuf, a.ldt = scratch.data_ptr(), scratch.data_ptr() + scratch[0].numel() * esz, Tld
         use_mfma = d % 2 == 0 or not ATTN_ODD_VALU                   # odd head widths (d = 45): the batched products read their Q operand from odd element offsets (unaligned dword loads)
         if use_mfma:
-            dsrel = torch.zeros((H, B * Tp, Rld), dtype=adt, device=dy.device)
+            n_rel = H * B * Tp * Rld                         # zero-initialised, from the step's pre-zeroed pool (was a fill launch per layer on the dependent chain)
+            if adt == torch.bfloat16:
+                dsrel = rt.zeros_scratch((n_rel + 1) // 2, dy.device).view(torch.bfloat16)[:n_rel].view(H, B * Tp, Rld)
+            else:
+                dsrel = rt.zeros_scratch(n_rel, dy.device).view(H, B * Tp, Rld)
             a.dsrel, a.ldr = dsrel.data_ptr(), Rld
         lib.relpos_attention_bwd(rt.dt(), _byref(a), rt.stream())
         if use_mfma:
@@ -885,13 +955,13 @@ class AttentionModuleFn(torch.autograd.Function):
                 it[0].M, it[0].I, it[0].J, it[0].nb_outer, it[0].nb_inner, it[0].strides6 = Tp, Tp, d, B, H, sK
                 it[1].P, it[1].ldp, it[1].Q, it[1].ldq, it[1].O_act, it[1].ldo = a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D
                 it[1].M, it[1].I, it[1].J, it[1].nb_outer, it[1].nb_inner, it[1].strides6 = Tp, Tp, d, B, H, sV
-                it[2].P, it[2].ldp, it[2].Q, it[2].ldq, it[2].O, it[2].ldo = dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D
+                it[2].P, it[2].ldp, it[2].Q, it[2].ldq, it[2].O, it[2].ldo = dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), de.stride(0)
                 it[2].M, it[2].I, it[2].J, it[2].nb_outer, it[2].nb_inner, it[2].strides6 = B * Tp, 2 * Tp - 1, d, 1, H, sE
                 lib.gemm_tn_batched_multi(rt.dt(), it, 3, rt.stream())
             else:
                 lib.gemm_tn_batched_store(rt.dt(), a.dsbuf, Tld, qkv.data_ptr(), 3 * D, dqkv.data_ptr() + D * esz, 3 * D, Tp, Tp, d, B, H, sK, rt.stream())
                 lib.gemm_tn_batched_store(rt.dt(), a.pbuf, Tld, do.data_ptr(), D, dqkv.data_ptr() + 2 * D * esz, 3 * D, Tp, Tp, d, B, H, sV, rt.stream())
-                lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), D, B * Tp, 2 * Tp - 1, d, 1, H, sE, rt.stream())
+                lib.gemm_tn_batched(rt.dt(), dsrel.data_ptr(), Rld, qkv.data_ptr(), 3 * D, de.data_ptr(), de.stride(0), B * Tp, 2 * Tp - 1, d, 1, H, sE, rt.stream())
         dhp = None
         grp = rt.fused_group(wq)
         if grp is not None and grp.weights[1] is wk and grp.weights[2] is wv and bq is not None:
@@ -903,9 +973,12 @@ class AttentionModuleFn(torch.autograd.Function):
                 g = dqkv[:, i * D:]
                 linear_bwd_weight(g, hp, w, Mp, ldp=3 * D, bias=b)
                 dhp = linear_bwd_input(g, w, Mp, out_f32=False, lda=3 * D, res=dhp, res_act=True, out=dhp)
-        dea = empty((2 * Tp - 1, D), adt, dy)
-        lib.cast_rows(rt.dt(), de.data_ptr(), D, dea.data_ptr(), D, 2 * Tp - 1, D, rt.stream())
-        linear_bwd_weight(dea, pe, wp, 2 * Tp - 1, bias=bp)
+        if pg is not None:
+            _pos_group_backward(pg, wp)
+        else:
+            dea = empty((2 * Tp - 1, D), adt, dy)
+            lib.cast_rows(rt.dt(), de.data_ptr(), D, dea.data_ptr(), D, 2 * Tp - 1, D, rt.stream())
+            linear_bwd_weight(dea, pe, wp, 2 * Tp - 1, bias=bp)
         if patch > 1:
             dh = empty((M, D), adt, dy)
             lib.patch_pool_bwd(rt.dt(), dhp.data_ptr(), dh.data_ptr(), B, T, D, patch, rt.stream())
@@ -1305,17 +1378,14 @@ class CTCLossMultiFn(torch.autograd.Function):
         tl = target_len.to(device=dev, dtype=torch.int64).contiguous()
         ils = [l.to(device=dev, dtype=torch.int64).contiguous() for l in lens]
         nll = torch.empty((n, B), dtype=torch.float32, device=dev)
-        means = rt.zeros_scratch(n, dev)
+        means = rt.zeros_scratch(n + 1, dev)                 # [n]: the weighted total, accumulated by the same launch (was a rocBLAS dot + fill + add on the critical chain)
         grads = [empty(tuple(lg.shape), torch.float32, lg) if ctx.needs_input_grad[5 + 2 * i] else None for i, lg in enumerate(logits)]
         arr_p = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
         Ts = (ctypes.c_int * n)(*[lg.shape[1] for lg in logits])
         lib.ctc_loss_multi(n, arr_p([lg.data_ptr() for lg in logits]), arr_p([l.data_ptr() for l in ils]), Ts, arr_p([nll[i].data_ptr() for i in range(n)]),
                            arr_p([means[i:].data_ptr() for i in range(n)]), arr_p([g.data_ptr() if g is not None else None for g in grads]),
-                           tg.data_ptr(), tl.data_ptr(), B, V, Lmax, blank, int(zero_infinity), rt.stream())
-        wkey = (tuple(float(x) for x in weights), str(dev))
-        if wkey not in _WCACHE:                      # created in the eager warm-up steps, reused (a constant) by a captured graph
-            _WCACHE[wkey] = torch.tensor(wkey[0], dtype=torch.float32, device=dev)
-        total = torch.dot(means, _WCACHE[wkey])
+                           tg.data_ptr(), tl.data_ptr(), (ctypes.c_float * n)(*[float(x) for x in weights]), means[n:].data_ptr(), B, V, Lmax, blank, int(zero_infinity), rt.stream())
+        total = means[n]
         ctx.saved = (grads, B, n, [float(x) for x in weights])
         ctx.keep = (logits, ils, tg, tl, nll)
         outs = tuple(means[i] for i in range(n))
@@ -1797,6 +1867,15 @@ def spec_augment_(mel, lens, mF, Fp, mT, pS, sid):
     lens_ = None if lens is None else lens.to(device=mel.device, dtype=torch.int64).contiguous()
     lib.specaugment(mel.data_ptr(), _p(lens_), B, NM, F, mF, Fp, mT, pS, rt.rng_state(mel.device).data_ptr(), sid, rt.stream())
     return mel
+
+
+def len_affine(lengths, sub, div, add):
+    """floor((lengths - sub) / div) + add on an int64 length vector: one launch on the device (three ATen launches otherwise), plain torch on the host"""
+    if torch.is_tensor(lengths) and lengths.is_cuda and lengths.dtype == torch.int64 and lengths.is_contiguous() and lengths.numel() > 0:
+        out = torch.empty_like(lengths)
+        lib.len_affine(lengths.data_ptr(), out.data_ptr(), lengths.numel(), sub, div, add, rt.stream())
+        return out
+    return torch.div(lengths - sub, div, rounding_mode="floor") + add
 
 
 def argmax_rows(logits):

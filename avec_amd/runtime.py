@@ -457,6 +457,7 @@ class ParamArena:
             lib.shadow_refresh(dt(), self.master.data_ptr(), self.shadow.data_ptr(), self.table.data_ptr(), self.n_entries,
                                self.total_blocks, stream())
             self.dirty = False
+            self.refresh_count = getattr(self, "refresh_count", 0) + 1      # versions everything derived from the shadows (ops._pos_group_entry: the position projections)
             if getattr(self, "_fp8", None) is not None:          # e4m3 weight shadows follow the masters too (avec_amd/fp8.py)
                 self._fp8.refresh()
 

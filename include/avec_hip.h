@@ -414,11 +414,14 @@ int avec_ctc_loss(const float* logits, const long long* in_lens, const long long
  * fit the all-LDS kernel (avec_ctc_loss_multi_fits).  Arrays of n_heads host pointers / frame counts. */
 int avec_ctc_loss_multi_fits(int T, int V, int Lmax);
 int avec_ctc_loss_multi(int n_heads, const float* const* logits, const long long* const* in_lens, const int* T, float* const* nll, float* const* mean_out, float* const* grad,
-                        const long long* targets, const long long* tgt_lens, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
+                        const long long* targets, const long long* tgt_lens, const float* weights, float* total, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
+/* (weights: n_heads host floats, total: optional device scalar, += sum_i weights[i] * mean loss of head i -- the weighted total of nnet/model.py:275-287 out of the same launch) */
 int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t stream);
 /* losses.SoftmaxCrossEntropy (nnet/losses.py:258-290; the LRW word classifier): per-row cross entropy of fp32 logits [M][V] against int64 targets,
  * rows with target == ignore_index give 0; mean_out (optional) += loss/M; grad (optional) = softmax - onehot */
 int avec_softmax_ce(const float* logits, const long long* targets, long long ignore_index, float* loss, float* mean_out, float* grad, long long M, int V, hipStream_t stream);
+/* length arithmetic of the strided layers (nnet/preprocessing.py:77, nnet/modules.py:127-128, nnet/networks.py:298,302): out[i] = floor((in[i] - sub) / div) + add, int64 */
+int avec_len_affine(const long long* in, long long* out, int n, long long sub, long long div, long long add, hipStream_t stream);
 /* CTCGreedySearchDecoder argmax (nnet/decoders.py:97-120) */
 int avec_argmax_rows(const float* x, long long* out, long long M, int V, hipStream_t stream);
 /* optimizers.Adam.step (nnet/optimizers.py:71-75) over flat arenas; state_dev = {step, lr} */
