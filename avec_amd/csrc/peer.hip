@@ -21,6 +21,11 @@ struct PeerArgs {
   unsigned* epoch;                                  // this site's visit counter (device memory, this rank)
   int* err;
   long long timeout_spins;                          // polls (each followed by s_sleep 8, >= ~0.25 us) before a slot is given up
+  // fused producer work (round 4: one launch instead of two per SyncBatchNorm exchange): the exchanged vector is  v[i] = sum_{r < nrep} in[r * n_in + i]  for i < n_in
+  // (the statistic replicas of the producing kernel), v[n_in] = tail when has_tail (the local element count);  and, before the exchange, the LOCAL sums are added to the
+  // affine gradients: dbeta[c] += v[c], dgamma[c] += v[C + c]  (backward exchange: torch's SyncBatchNorm all-reduces the statistics, not the parameter gradients)
+  int nrep, n_in, has_tail; float tail;
+  float* dgamma; float* dbeta; int C;
 };
 
 __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
@@ -31,7 +36,11 @@ __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
   const long long poff = (long long)(e & 1u) * a.page_stride;
   // publish: slot `rank` of the page in every rank's buffer (own buffer included)
   for (int i = threadIdx.x; i < a.n; i += 256) {
-    const unsigned long long gr = ((unsigned long long)e << 32) | (unsigned long long)__float_as_uint(a.in[i]);
+    float v;
+    if (a.has_tail && i == a.n_in) v = a.tail;
+    else { v = 0.f; for (int r = 0; r < a.nrep; ++r) v += a.in[(long long)r * a.n_in + i]; }
+    if (a.dgamma && i < 2 * a.C) { if (i < a.C) a.dbeta[i] += v; else a.dgamma[i - a.C] += v; }
+    const unsigned long long gr = ((unsigned long long)e << 32) | (unsigned long long)__float_as_uint(v);
     for (int r = 0; r < a.world; ++r)
       __hip_atomic_store(a.pages[r] + poff + (long long)a.rank * a.n + i, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -57,16 +66,28 @@ __global__ __launch_bounds__(256) void peer_exchange_sum_kernel(PeerArgs a) {
   }
 }
 
-extern "C" int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
-                                      unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream) {
-  AVEC_CHECK_ARG(in && out && pages && epoch && err_flag && n > 0 && world >= 1 && world <= AVEC_PEER_MAX_WORLD && rank >= 0 && rank < world,
+static int peer_exchange_impl(const float* in, int nrep, int n_in, int has_tail, float tail, float* dgamma, float* dbeta, int C, float* out, void* const* pages,
+                              long long page_stride_granules, int rank, int world, unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream) {
+  const int n = n_in + (has_tail ? 1 : 0);
+  AVEC_CHECK_ARG(in && out && pages && epoch && err_flag && n_in > 0 && nrep >= 1 && world >= 1 && world <= AVEC_PEER_MAX_WORLD && rank >= 0 && rank < world,
                  "peer_exchange_sum: bad arguments (n=%d rank=%d world=%d)", n, rank, world);
-  PeerArgs a; a.in = in; a.out = out; a.n = n; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag; a.timeout_spins = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 4000ll;
+  AVEC_CHECK_ARG(!dgamma == !dbeta && (!dgamma || (C > 0 && 2 * C <= n_in)), "peer_exchange_sum: affine-gradient outputs need both pointers and 2 C <= n");
+  PeerArgs a; a.in = in; a.out = out; a.n = n; a.nrep = nrep; a.n_in = n_in; a.has_tail = has_tail; a.tail = tail; a.dgamma = dgamma; a.dbeta = dbeta; a.C = C; a.page_stride = page_stride_granules; a.rank = rank; a.world = world; a.epoch = epoch; a.err = err_flag; a.timeout_spins = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 4000ll;
   for (int r = 0; r < AVEC_PEER_MAX_WORLD; ++r) a.pages[r] = r < world ? (unsigned long long*)pages[r] : nullptr;
   for (int r = 0; r < world; ++r) AVEC_CHECK_ARG(a.pages[r] && (((uintptr_t)a.pages[r]) & 7) == 0, "peer_exchange_sum: page pointer of rank %d is null / not 8-byte aligned", r);
   hipLaunchKernelGGL(peer_exchange_sum_kernel, dim3(1), dim3(256), 0, stream, a);
   AVEC_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
+                                      unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream) {
+  return peer_exchange_impl(in, 1, n, 0, 0.f, nullptr, nullptr, 0, out, pages, page_stride_granules, rank, world, epoch, err_flag, timeout_ms, stream);
+}
+extern "C" int avec_peer_exchange_sum_fused(const float* in, int n_replicas, int n_in, int has_tail, float tail, float* dgamma, float* dbeta, int C, float* out,
+                                            void* const* pages, long long page_stride_granules, int rank, int world, unsigned* epoch, int* err_flag, int timeout_ms,
+                                            hipStream_t stream) {
+  return peer_exchange_impl(in, n_replicas, n_in, has_tail, tail, dgamma, dbeta, C, out, pages, page_stride_granules, rank, world, epoch, err_flag, timeout_ms, stream);
 }
 
 // hipDeviceEnablePeerAccess for the current device (kernels here dereference memory of the peer GPUs that was mapped through HIP IPC)

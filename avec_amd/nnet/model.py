@@ -237,16 +237,24 @@ class Model(Module):
           replay.  Requires the peer exchange (otherwise every BatchNorm layer needs a host-issued collective: use train_step)."""
         from .. import peer
         dist_mode = self.is_distributed
-        assert not dist_mode or peer.active() is not None, "graph capture of a data-parallel step needs the SyncBatchNorm peer exchange; use train_step"
+        # RCCL collectives are capturable: over the nccl backend the WHOLE data-parallel step -- SyncBatchNorm exchanges (peer writes, or RCCL when the peer exchange is
+        # off / refused), the range-wise gradient all-reduce (fusion + audio-visual ranges when the gradient crosses the fusion inputs, the audio encoder's from the audio
+        # branch's stream beside the visual backward, the visual encoder's at the end) and the Adam launch -- is ONE hipGraph.  AVEC_GRAPH_ALLREDUCE=0: all-reduce and
+        # Adam follow the replay (the round-3 behaviour; also what gloo debugging runs use).
+        in_graph = dist_mode and torch.distributed.get_backend() == "nccl" and os.environ.get("AVEC_GRAPH_ALLREDUCE", "1") != "0"
+        assert not dist_mode or in_graph or peer.active() is not None, "graph capture of a data-parallel step needs capturable SyncBatchNorm exchanges (RCCL, or the peer exchange); use train_step"
         rt.set_compute_dtype(precision)
         warmup = max(int(warmup), 1)                        # lazily created constants (DFT matrix, sinusoid tables, loss weights) must exist before the capture
         static_in = [t.clone() for t in inputs]
         static_tg = tuple(t.clone() for t in targets)
         if dist_mode:
-            self.arena.arm_early_all_reduce(False)          # no collective inside the capture
+            self.arena.arm_early_all_reduce(False)          # (armed per pass inside body() when the collectives are captured)
+        state = {"in_graph": in_graph}
 
         def body():
             rt.reset_zero_pool(self.device)
+            if dist_mode and state["in_graph"]:
+                self.arena.arm_early_all_reduce(os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0", sync=True)
             losses, _, _, _ = self.forward_model(static_in, static_tg, compute_metrics=False)
             ops.stamp("loss_done:f")
             losses["loss"].backward()
@@ -254,10 +262,15 @@ class Model(Module):
             rt.advance_rng(self.device)
             if not dist_mode:
                 self.optimizer.launch_step()
+            elif state["in_graph"]:
+                self.arena._sync_collectives = True
+                self.arena.all_reduce_grads()
+                self.optimizer.grad_scale = 1.0 / self.world_size
+                self.optimizer.launch_step()
             return losses
 
-        def finish():                                       # data parallel: average the gradients, then the optimizer launch
-            if dist_mode:
+        def finish():                                       # data parallel without captured collectives: average the gradients, then the optimizer launch
+            if dist_mode and not state["in_graph"]:
                 self.arena.all_reduce_grads()
                 self.optimizer.grad_scale = 1.0 / self.world_size
                 self.optimizer.launch_step()
@@ -273,8 +286,23 @@ class Model(Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):                   # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
-            static_losses = body()
+        # data parallel: the process group's watchdog thread polls the events of earlier collectives (hipEventQuery) while this thread captures -- legal only when the
+        # capture's error mode is thread-local (the default "global" mode turns that poll into a capture violation and the watchdog aborts the process)
+        gkw = {"capture_error_mode": "thread_local"} if dist_mode else {}
+        try:
+            with torch.cuda.graph(graph, **gkw):        # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
+                static_losses = body()
+        except Exception as e:
+            if not (dist_mode and state["in_graph"] and peer.active() is not None):
+                raise
+            # the collectives could not be captured on this stack: capture forward + backward only (peer-write SyncBatchNorm), all-reduce + Adam after each replay
+            print("[avec_amd] rank %d: capture with in-graph RCCL collectives failed (%s: %s); capturing forward + backward only" % (self.rank, type(e).__name__, e), flush=True)
+            state["in_graph"] = False
+            self.arena.arm_early_all_reduce(False)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, **gkw):
+                static_losses = body()
 
         replays = [0]
 
@@ -290,13 +318,14 @@ class Model(Module):
             self.optimizer.prepare_step()
             graph.replay()
             finish()
-            if not dist_mode:
+            if not dist_mode or state["in_graph"]:
                 self.arena.mark_dirty()             # host-side view of what the replay's closing Adam launch left behind: whatever runs next OUTSIDE the graph
             return static_losses                    # (evaluation, an eager step) must refresh the weight shadows first -- the captured refresh sits at the START of a replay
 
         if dist_mode:
             self.arena.arm_early_all_reduce(os.environ.get("AVEC_EARLY_ALLREDUCE", "1") != "0")      # later eager train_steps keep their overlapped exchange
         step.graph = graph
+        step.collectives_in_graph = bool(dist_mode and state["in_graph"])
         step.warm_losses = {k: v.detach().clone() for k, v in warm.items()} if warm is not None else None
         return step
 
@@ -331,7 +360,8 @@ class Model(Module):
         lw = self.compiled_loss_weights
         const_w = isinstance(lw, ConstantScheduler) or (isinstance(lw, dict) and all(isinstance(v, ConstantScheduler) for v in lw.values())) \
             or (isinstance(lw, list) and all(isinstance(v, ConstantScheduler) for v in lw))
-        if not const_w or self.grad_max_norm is not None or (self.is_distributed and peer.active() is None):
+        capturable = (not self.is_distributed) or peer.active() is not None or torch.distributed.get_backend() == "nccl"
+        if not const_w or self.grad_max_norm is not None or not capturable:
             return self.train_step(inputs, targets, precision=precision)[0]
         if bucket_frames and len(inputs) == 4 and inputs[0].dim() == 5 and isinstance(targets, (tuple, list)) and len(targets) == 2:
             inputs, targets = self.pad_av_batch(inputs, targets, bucket_frames)

@@ -1154,6 +1154,10 @@ def _add_local_affine_grads(dstats, gw, gb, C, key):
     Returns (dstats to use -- the global sums when synchronised --, whether it synchronised)."""
     if not rt.sync_batchnorm():
         return dstats, False
+    from . import peer
+    px = peer.active()
+    if px is not None and dstats.is_cuda and dstats.is_contiguous() and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
+        return px.all_reduce_sum_fused(dstats, 1, 2 * C, None, key, dgamma=gw, dbeta=gb, C=C), True      # local affine gradients added inside the exchange kernel
     lib.bn_affine_grads(dstats.data_ptr(), gw.data_ptr(), gb.data_ptr(), C, rt.stream())
     return rt.all_reduce_small(dstats, key), True
 

@@ -21,7 +21,8 @@ class PeerExchange:
     allocate() -> [all_gather_object of the handles] -> map(handles) -> [agreement all_reduce] -> ready."""
 
     def __init__(self, rank, world, device, group=None):
-        assert 1 < world <= MAX_WORLD, "peer exchange serves 2..%d ranks of one node" % MAX_WORLD
+        from . import runtime as rt
+        assert rt.dist_min_world() <= world <= MAX_WORLD, "peer exchange serves 2..%d ranks of one node" % MAX_WORLD
         self.rank, self.world, self.device, self.group = rank, world, device, group
         self.site_granules = 2 * world * MAXN                     # two parity pages of world slots
         self._own, self._opened, self.bases, self.sites = None, [], [], {}
@@ -66,6 +67,22 @@ class PeerExchange:
                               self.epochs.data_ptr() + 4 * site, self.err.data_ptr(), self.timeout_ms, torch.cuda.current_stream().cuda_stream)
         return out
 
+    def all_reduce_sum_fused(self, src, nrep, n_in, tail, key, dgamma=None, dbeta=None, C=0):
+        """all_reduce_sum of  [sum over `nrep` replicas of src[r][:n_in] | tail]  (tail None: no extra element), optionally adding the local sums to the affine gradients first:
+        the collapse / affine-gradient launch in front of every SyncBatchNorm exchange folded into the exchange kernel"""
+        site = self.sites.get(key)
+        if site is None:
+            site = self.sites[key] = len(self.sites)
+            assert site < SITES, "more than %d SyncBatchNorm exchange sites" % SITES
+        n = n_in + (0 if tail is None else 1)
+        assert src.dtype == torch.float32 and src.is_contiguous() and 0 < n <= MAXN and src.numel() >= nrep * n_in
+        out = torch.empty(n, dtype=torch.float32, device=src.device)
+        pages = (ctypes.c_void_p * self.world)(*[b + site * self.site_granules * 8 for b in self.bases])
+        lib.peer_exchange_sum_fused(src.data_ptr(), nrep, n_in, int(tail is not None), float(tail or 0.0), None if dgamma is None else dgamma.data_ptr(),
+                                    None if dbeta is None else dbeta.data_ptr(), C, out.data_ptr(), pages, self.world * MAXN, self.rank, self.world,
+                                    self.epochs.data_ptr() + 4 * site, self.err.data_ptr(), self.timeout_ms, torch.cuda.current_stream().cuda_stream)
+        return out
+
     def check(self):
         """host-side: raise if a peer ever failed to arrive (synchronises)"""
         if int(self.err.item()) != 0:
@@ -100,7 +117,8 @@ def setup(device, group=None):
     if os.environ.get("AVEC_PEER_SYNCBN", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if not (1 < world <= MAX_WORLD):
+    from . import runtime as rt
+    if not (rt.dist_min_world() <= world <= MAX_WORLD):        # (AVEC_DIST_SINGLE=1: a one-rank group exchanges with itself -- the same kernels, pages and epochs)
         return None
     px, handle, why = PeerExchange(rank, world, device, group), None, ""
     try:

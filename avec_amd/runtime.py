@@ -64,9 +64,15 @@ def set_sync_batchnorm(flag):
     _STATE["sync_bn"] = bool(flag)
 
 
+def dist_min_world():
+    """2 normally.  AVEC_DIST_SINGLE=1: a ONE-rank process group takes every data-parallel code path (SyncBatchNorm exchanges, second communicator, early / in-graph
+    gradient all-reduce): how the RCCL paths are exercised on a single-GPU box (tests/test_gpu_ddp.py)"""
+    return 1 if os.environ.get("AVEC_DIST_SINGLE", "0") == "1" else 2
+
+
 def sync_batchnorm():
     return _STATE["sync_bn"] and torch.distributed.is_available() and torch.distributed.is_initialized() \
-        and torch.distributed.get_world_size() > 1
+        and torch.distributed.get_world_size() >= dist_min_world()
 
 
 # ---- side stream for the weight-gradient GEMMs ------------------------------------------------------------------------------------------
@@ -498,10 +504,16 @@ class ParamArena:
         import torch.distributed as dist
         from . import ops
         ops.flush_param_grads()                   # queued weight / LayerNorm gradients of this stream belong to the range: they must be in the arena first
+        if getattr(self, "_sync_collectives", False):
+            # inside a hipGraph capture: a blocking collective is enqueued on the calling stream's communicator in program order and becomes part of the graph
+            # (no work handle to wait for on the host); from the audio branch's stream it runs beside the visual branch's backward
+            dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=False, group=collective_group())
+            self._early.append((lo, hi, None))
+            return
         self._early.append((lo, hi, dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=collective_group())))
 
-    def arm_early_all_reduce(self, flag):
-        self._early_armed, self._early = bool(flag), []
+    def arm_early_all_reduce(self, flag, sync=False):
+        self._early_armed, self._early, self._sync_collectives = bool(flag), [], bool(sync)
 
     def all_reduce_grads(self, bucket_bytes=64 << 20):
         """DDP gradient averaging: sum over ranks in large contiguous buckets (RCCL over xGMI); the 1/world factor is
@@ -511,29 +523,36 @@ class ParamArena:
         if os.environ.get("AVEC_DIAG_SKIP_GRAD_ALLREDUCE") == "1":      # diagnostics only (two ranks sharing one GPU over gloo: isolates compute + SyncBatchNorm exchange cost)
             early = []
             pos = self.numel
+        sync = getattr(self, "_sync_collectives", False)
         for lo, hi, _ in early + [(self.numel, self.numel, None)]:
             if lo > pos:
-                all_reduce_flat(self.grad[pos:lo], bucket_bytes)
+                all_reduce_flat(self.grad[pos:lo], bucket_bytes, sync=sync)
             pos = max(pos, hi)
         for _, _, work in early:
-            work.wait()
-        self._early, self._early_armed = [], False
+            if work is not None:
+                work.wait()
+        self._early, self._early_armed, self._sync_collectives = [], False, False
 
 
 GRAD_ALLREDUCE_BF16 = os.environ.get("AVEC_GRAD_ALLREDUCE_BF16", "0") == "1"      # opt-in: bf16 payload for the flat gradient all-reduce: half the bytes on
 # every xGMI link; each rank's gradient is rounded to bf16 once before the sum (the reference all-reduces fp32 gradients: default off)
 
 
-def all_reduce_flat(flat, bucket_bytes=64 << 20, bf16_payload=None):
-    """Sum a flat buffer over all ranks in contiguous slices of `bucket_bytes` (asynchronous, then waited in order)."""
+def all_reduce_flat(flat, bucket_bytes=64 << 20, bf16_payload=None, sync=False):
+    """Sum a flat buffer over all ranks in contiguous slices of `bucket_bytes` (asynchronous, then waited in order; sync: blocking calls in program order on the
+    calling stream -- what a hipGraph capture records)."""
     import torch.distributed as dist
     if (GRAD_ALLREDUCE_BF16 if bf16_payload is None else bf16_payload) and flat.dtype == torch.float32:
         wire = flat.to(torch.bfloat16)
-        all_reduce_flat(wire, bucket_bytes, bf16_payload=False)
+        all_reduce_flat(wire, bucket_bytes, bf16_payload=False, sync=sync)
         flat.copy_(wire)
         return flat
     n = flat.numel()
     step = max(bucket_bytes // flat.element_size(), 1)
+    if sync:
+        for s in range(0, n, step):
+            dist.all_reduce(flat[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=False)
+        return flat
     works = [dist.all_reduce(flat[s:min(s + step, n)], op=dist.ReduceOp.SUM, async_op=True) for s in range(0, n, step)]
     for w in works:
         w.wait()
@@ -555,7 +574,7 @@ def collective_group():
 def ensure_branch_group():
     """collective on all ranks: create the side-stream communicator (no-op without torch.distributed or when the branch streams are off)"""
     import torch.distributed as dist
-    if _BRANCH.get("group") is None and _BRANCH["enabled"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _BRANCH.get("group") is None and _BRANCH["enabled"] and dist.is_available() and dist.is_initialized() and dist.get_world_size() >= dist_min_world():
         _BRANCH["group"] = dist.new_group()
     return _BRANCH.get("group")
 
@@ -576,6 +595,10 @@ def sync_bn_stats(stats, nrep, C, count, key=None):
     """SyncBatchNorm statistic exchange: collapse the `nrep` replicated [sum | sumsq] partials, append the local element count and sum
     the (2C+1)-vector over ranks.  Returns the reduced vector (global sum, global sumsq, global count)."""
     if stats.is_cuda:
+        from . import peer
+        px = peer.active()
+        if px is not None and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
+            return px.all_reduce_sum_fused(stats, nrep, 2 * C, float(count), key)          # replicas collapsed inside the exchange kernel: one launch per exchange
         red = torch.empty(2 * C + 1, dtype=torch.float32, device=stats.device)
         lib.bn_collapse(stats.data_ptr(), nrep, float(count), red.data_ptr(), C, stream())
     else:       # (CPU tensors: the gloo unit tests of the exchange itself)

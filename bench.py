@@ -166,9 +166,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    single_dist = world == 1 and os.environ.get("AVEC_DIST_SINGLE", "0") == "1"       # a one-rank RCCL group through every data-parallel code path (tests / tools/gpu/r4_rccl.sh)
+    if world > 1 or single_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         else:
@@ -186,8 +190,11 @@ def main():
     model = nnet.AudioVisualEfficientConformerInterCTC(vocab_size=256, v_interctc_blocks=[3, 6], a_interctc_blocks=[8, 11], f_interctc_blocks=[2])
     model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
     model = model.to(device).train()
-    if world > 1:
+    if world > 1 or single_dist:
         model.distribute_strategy(local_rank)
+        world_dist = True
+    else:
+        world_dist = False
     inputs, targets = synthetic_batch(args.batch, device, seed=rank)
     precision = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
@@ -200,7 +207,7 @@ def main():
     # travel by peer-write kernels (avec_amd/peer.py; verified at start-up on this node), the RCCL gradient all-reduce and the Adam launch follow each replay;
     # without the peer exchange (refused IPC, gloo debugging on CPU tensors, ...) the step runs eagerly.
     from avec_amd import peer
-    use_graph = not args.eager and (world == 1 or peer.active() is not None)
+    use_graph = not args.eager and (not world_dist or peer.active() is not None or args.backend == "nccl")      # (RCCL collectives are capturable: SyncBatchNorm falls back to them inside the graph)
     graphed = None
     if use_graph:
         try:
@@ -216,6 +223,16 @@ def main():
             if int(ok.item()) == 0:
                 graphed = None
         use_graph = graphed is not None
+    # which path the timed steps take (a fallback shows here instead of as a silently slower number)
+    if use_graph:
+        if not world_dist:
+            step_path, fallback = "one hipGraph: shadow refresh + forward + losses + backward + Adam", None
+        elif getattr(graphed, "collectives_in_graph", False):
+            step_path, fallback = "one hipGraph incl. SyncBatchNorm exchanges, range-wise RCCL gradient all-reduce and Adam", (None if peer.active() is not None else "SyncBatchNorm statistics over RCCL (peer exchange unavailable)")
+        else:
+            step_path, fallback = "hipGraph forward + backward; RCCL gradient all-reduce + Adam after each replay", "collectives outside the graph"
+    else:
+        step_path, fallback = "eager launches", (None if args.eager else "graph capture unavailable: eager steps")
     if use_graph:
         run_step = lambda: graphed()
     else:
@@ -267,7 +284,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype + ("+fp8(e4m3) forward Linear operands" if args.fp8 else ""), "data": "synthetic",
             "config": {"workload": "AV EffConfInterCTC (LRS23/AV) training step: fwd + 6 CTC losses + bwd + grad all-reduce + Adam; "
                                    "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "step_path": step_path, "fallback": fallback, "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),
                        "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5),
                        "eager_instrumented_ms_per_step": (round(eager_ms, 2) if not args.no_kernel_timing else None)},
             "roofline": roof,
@@ -275,7 +292,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or single_dist:
         torch.distributed.destroy_process_group()
 
 

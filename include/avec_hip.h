@@ -199,6 +199,13 @@ int avec_layernorm_bwd_sum(int dtype, const float* dyparts, int nparts, float* d
 #define AVEC_PEER_MAX_WORLD 8
 int avec_peer_exchange_sum(const float* in, float* out, int n, void* const* pages, long long page_stride_granules, int rank, int world,
                            unsigned* epoch, int* err_flag, int timeout_ms, hipStream_t stream);
+/* the same exchange with the producer-side work folded in (one launch instead of two per SyncBatchNorm exchange): the exchanged vector is
+ *   v[i] = sum_{r < n_replicas} in[r * n_in + i] (i < n_in: the AVEC_STAT_REPLICAS statistic copies collapsed on the fly), v[n_in] = tail when has_tail (the local count);
+ * with dgamma / dbeta set (backward exchange of [sum dy | sum dy * xhat], n_in = 2 C) the LOCAL sums are first added to the affine gradients, as avec_bn_affine_grads does.
+ * out = [n_in + has_tail] sums over ranks. */
+int avec_peer_exchange_sum_fused(const float* in, int n_replicas, int n_in, int has_tail, float tail, float* dgamma, float* dbeta, int C, float* out,
+                                 void* const* pages, long long page_stride_granules, int rank, int world, unsigned* epoch, int* err_flag, int timeout_ms,
+                                 hipStream_t stream);
 int avec_enable_peer_access(int peer_device);
 /* exchange-buffer management: uncached (fine-grained) device memory + its 64-byte HIP IPC handle; peers map it with _open.  The caller owns the pointers. */
 int avec_peer_buffer_alloc(void** ptr, long long bytes, void* ipc_handle_64b);

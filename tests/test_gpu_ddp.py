@@ -132,3 +132,29 @@ def test_two_rank_evaluate_reduces_losses_and_gathers_hypotheses(tmp_path):
     assert abs(g0["loss"] - 0.5 * (l0["loss"] + l1["loss"])) < 2e-2 * abs(g0["loss"]), (g0["loss"], l0["loss"], l1["loss"])
     lo, hi = min(l0["wer"], l1["wer"]), max(l0["wer"], l1["wer"])
     assert lo - 1.0 <= g0["wer"] <= hi + 1.0, (g0["wer"], l0["wer"], l1["wer"])
+
+
+@pytest.mark.parametrize("peer_exchange", ["1", "0"], ids=["peer-write SyncBN exchange", "RCCL SyncBN exchange"])
+def test_one_rank_rccl_group_takes_every_data_parallel_path(tmp_path, peer_exchange):
+    """The data-parallel step over RCCL on ONE GPU (a one-rank nccl group, AVEC_DIST_SINGLE=1): SyncBatchNorm statistics through RCCL all-reduces (the fallback of the
+    peer exchange), the second communicator of the audio branch's stream, the early (overlapped) gradient ranges -- eagerly, and captured into ONE hipGraph together with
+    the closing all-reduce and the Adam launch.  With one rank every collective is the identity, so both runs must reproduce the plain single-process step: same loss,
+    Adam first moments within the run-to-run floor of bf16 steps with atomically accumulated gradients (4e-3, see test_graphed_two_rank_step_equals_eager_two_rank_step)."""
+    outs = {}
+    tool = os.path.join(ROOT, "tools", "ddp_graph_equiv.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AVEC_DIST_SINGLE="1",
+               AVEC_PEER_SYNCBN=peer_exchange)
+    for name, args in (("plain", ["--mode", "eager", "--backend", "none"]), ("eager", ["--mode", "eager", "--backend", "nccl"]), ("graph", ["--mode", "graph", "--backend", "nccl"])):
+        outs[name] = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, tool, "--out", outs[name]] + args, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    p, e, g = (torch.load(outs[k]) for k in ("plain", "eager", "graph"))
+    assert not p["sync_bn"] and e["sync_bn"] and g["sync_bn"] and e["branch_group"] and g["branch_group"]      # the RCCL SyncBatchNorm path and the second communicator really ran
+    assert e["peer"] == g["peer"] == (peer_exchange == "1")
+    assert g["graphed"] and g["in_graph"], "the collectives were not captured into the graph"
+    assert p["step"] == e["step"] == g["step"] == 3
+    ref = p["exp_avg"].double()
+    for k, r in (("eager", e), ("graph", g)):
+        d = ((r["exp_avg"].double() - ref).norm() / ref.norm()).item()
+        assert d < 4e-3, (k, d)
+        assert abs(r["loss"] - p["loss"]) < 1e-3 * abs(p["loss"]), (k, r["loss"], p["loss"])

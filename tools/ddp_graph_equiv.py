@@ -14,10 +14,13 @@ def main():
     ap.add_argument("--mode", default="eager")
     ap.add_argument("--backend", default="gloo", help="gloo: both ranks on cuda:0; nccl (= RCCL): one GPU per rank")
     args = ap.parse_args()
-    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
-    dev = torch.device("cuda", 0 if args.backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0")))
+    plain = args.backend == "none"               # no process group at all: the single-process reference of the one-rank RCCL runs
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", 0 if args.backend in ("gloo", "none") else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    if args.backend == "nccl":
+    if plain:
+        pass
+    elif args.backend == "nccl":
         torch.distributed.init_process_group(backend="nccl", init_method="env://", device_id=dev)
     else:
         torch.distributed.init_process_group(backend="gloo", init_method="env://")
@@ -36,7 +39,8 @@ def main():
     model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
     model = model.to(dev).train()
     model.encoder.spec_augment.eval()
-    model.distribute_strategy(rank)
+    if not plain:
+        model.distribute_strategy(rank)
     master0 = model.arena.master.clone()
     g = torch.Generator().manual_seed(11 + rank)
     audio, alen = 0.1 * torch.randn(2, 32000, generator=g), torch.tensor([32000, 25000])
@@ -53,13 +57,17 @@ def main():
     torch.cuda.synchronize()
     loss = losses["loss"].detach().float().clone()
     loss = loss if args.backend == "nccl" else loss.cpu()
-    torch.distributed.all_reduce(loss)
+    if not plain:
+        torch.distributed.all_reduce(loss)
     if peer.active() is not None:
         peer.active().check()
     if rank == 0:
-        torch.save({"peer": peer.active() is not None, "graphed": graphed, "master": model.arena.master.cpu(), "master0": master0.cpu(), "exp_avg": model.optimizer._flat["exp_avg"].cpu(), "step": int(model.model_step), "loss": float(loss) / world}, args.out)
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+        from avec_amd import runtime as rt
+        torch.save({"in_graph": bool(graphed and getattr(step, "collectives_in_graph", False)), "sync_bn": bool(rt.sync_batchnorm()), "branch_group": rt._BRANCH.get("group") is not None,
+                    "peer": peer.active() is not None, "graphed": graphed, "master": model.arena.master.cpu(), "master0": master0.cpu(), "exp_avg": model.optimizer._flat["exp_avg"].cpu(), "step": int(model.model_step), "loss": float(loss) / world}, args.out)
+    if not plain:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
