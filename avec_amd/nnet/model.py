@@ -286,9 +286,14 @@ class Model(Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        # data parallel: the process group's watchdog thread polls the events of earlier collectives (hipEventQuery) while this thread captures -- legal only when the
-        # capture's error mode is thread-local (the default "global" mode turns that poll into a capture violation and the watchdog aborts the process)
-        gkw = {"capture_error_mode": "thread_local"} if dist_mode else {}
+        # data parallel: the process group's watchdog thread polls the events of collectives it still tracks (hipEventQuery, every ~100 ms); under a "global"-mode capture
+        # such a poll is a capture violation and aborts the process, and in "thread_local" mode HIP reports the backward pass's collectives (issued from the autograd
+        # thread) as not capturing, so they ARE tracked and their captured events get polled.  So: global mode, and the watchdog's list drained before the capture starts
+        # (everything issued so far has completed -- synchronize above -- and is reaped within one watchdog period).
+        gkw = {}
+        if dist_mode and torch.distributed.get_backend() == "nccl":
+            torch.cuda.synchronize()
+            time.sleep(0.6)
         try:
             with torch.cuda.graph(graph, **gkw):        # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
                 static_losses = body()
@@ -300,6 +305,7 @@ class Model(Module):
             state["in_graph"] = False
             self.arena.arm_early_all_reduce(False)
             torch.cuda.synchronize()
+            time.sleep(0.6)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, **gkw):
                 static_losses = body()

@@ -597,8 +597,10 @@ def sync_bn_stats(stats, nrep, C, count, key=None):
     if stats.is_cuda:
         from . import peer
         px = peer.active()
-        if px is not None and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
-            return px.all_reduce_sum_fused(stats, nrep, 2 * C, float(count), key)          # replicas collapsed inside the exchange kernel: one launch per exchange
+        if px is not None and nrep * 2 * C <= 2048 and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
+            # few replicas: collapsed inside the exchange kernel (one launch).  The 64 replicas of the GEMM epilogues stay with the grid-wide collapse kernel: summed by
+            # the exchange's single workgroup they cost more than the launch they save (measured: 22.45 vs 21.75 ms per step under a one-rank group)
+            return px.all_reduce_sum_fused(stats, nrep, 2 * C, float(count), key)
         red = torch.empty(2 * C + 1, dtype=torch.float32, device=stats.device)
         lib.bn_collapse(stats.data_ptr(), nrep, float(count), red.data_ptr(), C, stream())
     else:       # (CPU tensors: the gloo unit tests of the exchange itself)
