@@ -423,6 +423,9 @@ class Model(Module):
             sampler = getattr(dataset_train, "sampler", None)
             if self.is_distributed and hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)          # reshuffle + re-shard per epoch (nnet/model.py:709-710)
+            bsamp = getattr(dataset_train, "batch_sampler", None)
+            if hasattr(bsamp, "set_epoch"):
+                bsamp.set_epoch(epoch)            # length-bucketed batches: new windows every epoch (nnet/samplers.py)
             acc_step, t0, n = 0, time.time(), 0
             for step, batch in enumerate(dataset_train):
                 inputs = self.transfer_to_device(batch["inputs"])

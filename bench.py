@@ -277,6 +277,9 @@ def main():
         roof = ops.KERNEL_TIMER.summary(peak, steps=timed_steps) if not args.no_kernel_timing else None
         if roof is not None and args.dtype == "bf16" and args.batch == 32:
             roof["traffic"] = pmc_traffic_kernel(roof["kernel"])
+            for r in roof["rows"]:                   # per row: measured HBM bytes (PMC summary) next to the algorithmic bytes -> the wasted-traffic ratio is explicit
+                r["traffic"] = pmc_traffic_kernel(r["kernel"])
+                r["traffic_over_alg"] = round(r["traffic"] / r["alg_bytes_per_launch"], 2) if (r["traffic"] and r["alg_bytes_per_launch"]) else None
             roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/%s)" % os.path.basename(pmc_summary_path() or "none")
         out = {
             "metric": "AV utterances/sec fwd+bwd (audio T=400, video 100x88x88)", "value": round(value, 2), "unit": "utt/s",

@@ -50,7 +50,31 @@ def load_model(args):
     return model
 
 
+def _sample_lengths(dataset):
+    """per-sample durations when the dataset can tell them without loading the clips (nnet.datasets.LRS: `durations`; ConcatDataset of such), else None"""
+    if hasattr(dataset, "durations"):
+        return list(dataset.durations)
+    if hasattr(dataset, "datasets") and all(hasattr(d, "durations") for d in dataset.datasets):
+        return [x for d in dataset.datasets for x in d.durations]
+    return None
+
+
 def _loader(dataset, args, drop_last):
+    # length-bucketed batches (avec_amd/nnet/samplers.py): opt-in per dataset (`bucket_by_length=True` / a window size) or by AVEC_BUCKET_BY_LENGTH=1 -- the batch
+    # COMPOSITION differs from the reference's uniform draw (same samples per epoch), which is why it is not the default
+    want = getattr(dataset, "bucket_by_length", None) or (os.environ.get("AVEC_BUCKET_BY_LENGTH", "0") == "1")
+    lengths = _sample_lengths(dataset) if (want and drop_last) else None
+    if lengths is not None:
+        from avec_amd.nnet.samplers import LengthBucketBatchSampler
+        bs = LengthBucketBatchSampler(lengths, dataset.batch_size, window=want if isinstance(want, int) and not isinstance(want, bool) else None,
+                                      shuffle=getattr(dataset, "shuffle", False), drop_last=True, rank=args.rank if args.distributed else 0,
+                                      world_size=args.world_size if args.distributed else 1)
+        loader = torch.utils.data.DataLoader(dataset, batch_sampler=bs, num_workers=args.num_workers, collate_fn=dataset.collate_fn, pin_memory=False)
+        loader.sampler_for_epoch = bs
+        if args.rank == 0:
+            print("Training dataset: {}, {:,} samples - {:,} length-bucketed batches of {} (padded-frame efficiency {:.2f})".format(
+                type(dataset).__name__, len(dataset), len(loader), dataset.batch_size, bs.padded_frame_efficiency()))
+        return loader
     sampler = None
     if args.distributed:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=args.world_size, rank=args.rank, shuffle=getattr(dataset, "shuffle", False))

@@ -5,6 +5,7 @@ variable-length mixes, reported as utterances/s and padded-frame efficiency):
 
   av15s      AV model, 15 s utterances (audio 240 000 samples = 1501 mel frames, video 376 frames), B=8
   lrs2_main  AV model, B=32, durations ~ clipped log-normal(median 2.0 s, sigma 0.6) in [0.8, 6.2] s, zero-padded to the batch maximum
+  lrs2_main_bucketed  the same distribution, 512 clips batched by the length-bucketed sampler (nnet/samplers.py)
   lrs2_pre   AV model, B=16, median 6 s, cap 16 s (pre-train mix)
   ao         audio-only InterCTC model, B=32, 63 840 samples
   vo         visual-only InterCTC model, B=32, 100 frames
@@ -106,6 +107,14 @@ def main():
         if want("lrs2_main"):
             bs = [av_batch(32, durations(32, 2.0, 0.6, 0.8, 6.2, g), g, dev) for _ in range(4)]
             out.append(run("lrs2_main", model, bs, args.steps, args.warmup + 2, prec))
+            print(json.dumps(out[-1]), flush=True)
+        if want("lrs2_main_bucketed"):
+            # the same length distribution through the length-bucketed batch sampler (avec_amd/nnet/samplers.py): 512 clips -> 16 batches of 32 neighbours in length
+            from avec_amd.nnet.samplers import LengthBucketBatchSampler
+            dur = durations(512, 2.0, 0.6, 0.8, 6.2, g)
+            bsamp = LengthBucketBatchSampler(dur.tolist(), 32, shuffle=True, seed=0)
+            bs = [av_batch(32, dur[torch.tensor(idx)], g, dev) for idx in list(bsamp)]
+            out.append(run("lrs2_main_bucketed", model, bs, max(args.steps, len(bs)), args.warmup + 2, prec))
             print(json.dumps(out[-1]), flush=True)
         if want("lrs2_pre"):
             bs = [av_batch(16, durations(16, 6.0, 0.6, 0.8, 16.0, g), g, dev) for _ in range(4)]
