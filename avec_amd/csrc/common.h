@@ -39,16 +39,27 @@ struct __attribute__((aligned(16))) chunk16 { uint32_t w[4]; };           // 16 
 struct __attribute__((packed, aligned(4))) chunk16u { uint32_t w[4]; };  // 16 B global access, only dword alignment assumed
 __device__ __forceinline__ chunk16 ldg16(const void* p) { chunk16u t = *(const chunk16u*)p; chunk16 o; o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3]; return o; }
 
-// ---- wave64 reductions (DPP/shuffle based) ----
+// ---- wave64 reductions by DPP (full-rate VALU; round 4): six levels, the result read from lane 63 and therefore wave-uniform.  The first version walked
+// __shfl_xor = ds_bpermute_b32, an LDS round trip per level: in the one-wave-per-row kernels (LayerNorm forward / backward, softmax) the two dependent chains of six
+// round trips were most of a row's latency.
+#define AVEC_DPP_F(v, old, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), ctrl, rmask, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += AVEC_DPP_F(v, 0.f, 0xB1, 0xf);        // quad_perm [1,0,3,2]
+  v += AVEC_DPP_F(v, 0.f, 0x4E, 0xf);        // quad_perm [2,3,0,1]
+  v += AVEC_DPP_F(v, 0.f, 0x141, 0xf);       // row_half_mirror
+  v += AVEC_DPP_F(v, 0.f, 0x140, 0xf);       // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += AVEC_DPP_F(v, 0.f, 0x142, 0xa);       // row_bcast:15 into rows 1 and 3
+  v += AVEC_DPP_F(v, 0.f, 0x143, 0xc);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0xB1, 0xf));
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0x4E, 0xf));
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0x141, 0xf));
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0x140, 0xf));
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0x142, 0xa));
+  v = fmaxf(v, AVEC_DPP_F(v, v, 0x143, 0xc));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- counter-based RNG for dropout / SpecAugment: stateless, reproducible in backward ----

@@ -99,7 +99,7 @@ def main():
         m.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
         return m.to(dev).train()
 
-    if want("av15s") or want("lrs2_main") or want("lrs2_pre"):
+    if want("av15s") or want("lrs2_main") or want("lrs2_main_bucketed") or want("lrs2_pre"):
         model = av_model()
         if want("av15s"):
             out.append(run("av15s", model, [av_batch(8, torch.full((8,), 15.0), g, dev)], args.steps, args.warmup, prec))
