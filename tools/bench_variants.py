@@ -51,11 +51,11 @@ GRAPHS = {"on": False, "bucket": None}
 def run(name, model, batches, steps, warmup, precision):
     import avec_amd
     if GRAPHS["on"]:
-        one = lambda inp, tgt: model.graphed_train_step(inp, tgt, precision=precision, bucket_frames=GRAPHS["bucket"])
-        warmup = max(warmup, len(batches))              # every shape captured before the timed region
+        one = lambda inp, tgt: model.graphed_train_step(inp, tgt, precision=precision, bucket_frames=GRAPHS["bucket"], cache_size=max(8, len(batches)))
         name += "+graphs" + ("(bucket %d)" % GRAPHS["bucket"] if GRAPHS["bucket"] else "")
     else:
         one = lambda inp, tgt: model.train_step(inp, tgt, precision=precision)[0]
+    warmup = max(warmup, len(batches))                  # every shape visited (captured) before the timed region: first visits pay for tables, allocator growth, captures
     for i in range(warmup):
         inp, tgt = batches[i % len(batches)][:2]
         last = one(inp, tgt)
