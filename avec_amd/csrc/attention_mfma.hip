@@ -12,6 +12,9 @@
 // bijection of the row bits chosen so that BOTH the ds_read_b128 operand reads (lanes = rows) and the transposed reads (4 rows x 32 B
 // blocks) are bank-conflict free:  pitch 128: chunk ^= ((row>>1)&1)<<2 | (row>>2)&3;   pitch 256: chunk ^= (row&3)<<2 | (row>>2)&3.
 #include "attention.h"
+#ifndef AVEC_ATTN_ABL
+#define AVEC_ATTN_ABL 0
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -34,17 +37,17 @@ __device__ __forceinline__ chunk16 tr8(const char* p0, const char* p1) {
 }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32x2_to_bf16x2(lo, hi); }
 
-// stage `nrows` rows x d channels of a bf16 matrix into the swizzled LDS image (zero outside [0, limit) and beyond d)
+// stage `nrows` rows x d channels of a bf16 matrix into the swizzled LDS image (zero outside [0, limit) and beyond d): register path, kept for the ALIAS
+// turns of long sequences (the image being replaced is still read by the other wave until the barrier in front of it)
 template <int PITCH, int NTHR>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, long long ld, int row0, int nrows, int limit, int d, int dpad) {
   const int CH = dpad >> 3;
-  const bool al4 = true;      // (gfx950 serves dword loads at any 2-byte address: rows of odd heads -- d = 45, audio stage 0 -- take the 16-byte path too; round 2 fetched them element by element)
   for (int idx = threadIdx.x; idx < nrows * CH; idx += NTHR) {
     const int r = idx / CH, c = idx - r * CH; const int gr = row0 + r;
     chunk16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
     if (gr >= 0 && gr < limit) {
       const bf16* p = src + (long long)gr * ld + c * 8;
-      if (c * 8 + 8 <= d && al4) v = ldg16(p);
+      if (c * 8 + 8 <= d) v = ldg16(p);      // (gfx950 serves dword loads at any 2-byte address: rows of odd heads -- d = 45, audio stage 0 -- take the 16-byte path too)
       else {
         uint32_t h[8];
 #pragma unroll
@@ -54,6 +57,61 @@ __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, long long
       }
     }
     *(chunk16*)(dst + r * PITCH + ((c ^ aswz<PITCH>(r)) << 4)) = v;
+  }
+}
+
+// The same image by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, no VGPR round trip, every instruction of a wave in flight at once).  Round 4: the register
+// path above was 8-15 us of a 18-22 us forward launch -- two waves per workgroup, one per SIMD, a load -> wait -> store round trip per 16 bytes.  An instruction
+// writes 64 consecutive 16-byte slots = 8 (pitch 128) or 4 (pitch 256) image rows; lane l owns slot l, i.e. (row l / SLOTS, position l % SLOTS), and fetches the
+// logical chunk that the swizzle puts there.  The DMA has no fill value, so:
+//   * rows outside [0, limit) are CLAMPED to the nearest valid row (finite values): every product that touches them is masked (keys beyond T get -inf / p = 0,
+//     E rows outside the window are only read for such pairs, query rows beyond T are never stored);
+//   * channels d .. dpad-1 of a row hold whatever follows the head in memory; the caller zeroes them in the Q / dO tiles only (zero_pad_channels) -- K, V and E
+//     meet them only in products contracted over the channels with Q or dO, or in output channels that are never stored;
+//   * the one 16-byte read that would run past the END of the tensor (last row, last head, d % 8 != 0) is replaced by a zero chunk + element loads.
+// Source addresses need 2-byte alignment only (tools/glds_align_probe.hip: any even offset copies right).
+__device__ __forceinline__ void attn_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __attribute__((aligned(64))) unsigned char attn_zero16[64];
+
+// rows [row0, row0 + nrows) of `src` (row stride ld elements, `last_row` = last row of the whole tensor, rowbytes = bytes of a tensor row counted from src's column)
+// -> image at LDS byte address lds_img; nrows is a multiple of 8; wave w of NW issues instructions w, w + NW, ...
+template <int PITCH, int NW>
+__device__ __forceinline__ void stage_rows_dma(unsigned lds_img, char* img, const bf16* src, long long ld, int row0, int nrows, int limit, int d, int dpad,
+                                               long long last_row, int rowbytes, int wave, int lane) {
+  constexpr int SLOTS = PITCH / 16, RPI = 64 / SLOTS;            // slots per image row, rows per instruction
+  const int CH = dpad >> 3;
+  const int rg = lane / SLOTS, pos = lane % SLOTS;
+  const int ninstr = nrows / RPI;
+  for (int k = wave; k < ninstr; k += NW) {
+    const int r = k * RPI + rg;
+    int c = pos ^ aswz<PITCH>(r); c = c < CH ? c : 0;            // unused slots re-read chunk 0
+    int gr = row0 + r; gr = gr < 0 ? 0 : (gr >= limit ? limit - 1 : gr);
+    const char* p = (const char*)(src + (long long)gr * ld) + c * 16;
+    const bool past = gr == last_row && c * 16 + 16 > rowbytes;
+    attn_glds16(past ? (const void*)attn_zero16 : (const void*)p, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_img + k * 1024)));
+    if (past) {      // (at most one lane of the whole grid)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bf16* dst = (bf16*)(img + k * 1024 + lane * 16);
+      for (int e = 0; e < 8; ++e) if (c * 16 + 2 * e + 2 <= rowbytes) dst[e] = ((const bf16*)p)[e];
+    }
+  }
+}
+// zero channels d .. dpad-1 of image rows [0, nrows): run by the wave that issued the row's DMA, after its s_waitcnt vmcnt(0)
+template <int PITCH, int NW>
+__device__ __forceinline__ void zero_pad_channels(char* img, int nrows, int d, int dpad, int wave, int lane) {
+  if (d == dpad) return;
+  constexpr int SLOTS = PITCH / 16, RPI = 64 / SLOTS;
+  const int rg = lane / SLOTS, pos = lane % SLOTS;
+  const int ninstr = nrows / RPI;
+  for (int k = wave; k < ninstr; k += NW) {
+    const int r = k * RPI + rg;
+    const int c = pos ^ aswz<PITCH>(r);
+    unsigned short* dst = (unsigned short*)(img + k * 1024 + lane * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (c * 8 + e >= d && c * 8 + e < dpad) dst[e] = 0;
   }
 }
 
@@ -188,11 +246,24 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   const bf16* kp = (const bf16*)a.k + (long long)b * Tn * a.ld + h * d;
   const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
   const bf16* ep = (const bf16*)a.e + h * d;
-  stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  if (!ALIAS) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
-  stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
+  {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)sm;
+    const int wv = __builtin_amdgcn_readfirstlane(w);
+    const long long lastq = (long long)(a.B - 1 - b) * Tn + Tn - 1;      // last row of the q / k / v tensors, counted from this batch element's first row
+    const int rb = (a.H - h) * d * 2;                                    // bytes from this head's first column to the end of a tensor row
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    if (!ALIAS) stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zero_pad_channels<PITCH, 2>(Qs, 64, d, G.dpad, wv, lane);
+  }
   __syncthreads();
+#if AVEC_ATTN_ABL == 1
+  if (sm[tid * 16] == 123) a.lse[0] = 1.f;
+  return;
+#endif
 
   const int i = i0 + 32 * w + il;                        // this lane's query
   const char* qrow = Qs + (32 * w + il) * PITCH;
@@ -212,6 +283,9 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   }
   lsum += __shfl_xor(lsum, 32, 64);
   if (hf == 0 && i < Tn) { a.lse[((long long)bh * Tn + i) * 2] = mx; a.lse[((long long)bh * Tn + i) * 2 + 1] = lsum; }
+#if AVEC_ATTN_ABL == 2
+  return;
+#endif
 
   if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place
   // O^T = V^T P^T
@@ -256,12 +330,26 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
   const bf16* vp = (const bf16*)a.v + (long long)b * Tn * a.ld + h * d;
   const bf16* ep = (const bf16*)a.e + h * d;
   const bf16* gp = (const bf16*)a.dout + (long long)b * Tn * a.ldo + h * d;
-  stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  if (!ALIAS) stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad);
-  stage_rows<PITCH, 128>(Qs, qp, a.ld, i0, 64, Tn, d, G.dpad);
-  stage_rows<PITCH, 128>(Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad);
+  {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)sm;
+    const int wv = __builtin_amdgcn_readfirstlane(w);
+    const long long lastq = (long long)(a.B - 1 - b) * Tn + Tn - 1;
+    const int rb = (a.H - h) * d * 2;
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    if (!ALIAS) stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ + 64 * PITCH, Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zero_pad_channels<PITCH, 2>(Qs, 64, d, G.dpad, wv, lane);
+    zero_pad_channels<PITCH, 2>(Gs, 64, d, G.dpad, wv, lane);
+  }
   __syncthreads();
+#if AVEC_ATTN_ABL == 1
+  if (sm[tid * 16] == 123) a.lse[0] = 1.f;
+  return;
+#endif
 
   const int i = i0 + 32 * w + il;
   const int swr = aswz<PITCH>(il);
@@ -283,6 +371,10 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
 
   f32x16 S[NTM];
   scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+#if AVEC_ATTN_ABL == 2
+  if (S[0][0] + S[1][3] + delta == 1234.5f) a.lse[0] = 1.f;
+  return;
+#endif
   if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // V takes K's place for dP
   bf16* prow = (bf16*)a.pbuf + ((long long)bh * Tn + i) * a.ldt;
   bf16* srow = (bf16*)a.dsbuf + ((long long)bh * Tn + i) * a.ldt;
@@ -326,6 +418,9 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
       }
     }
   }
+#if AVEC_ATTN_ABL == 3
+  return;
+#endif
   if (ALIAS) { __syncthreads(); stage_rows<PITCH, 128>(Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad); __syncthreads(); }      // and K comes back for dQ
   // dQ^T = K^T dS^T   (A = K^T via transposed reads, B = dS^T registers)
   f32x16 DQ[CTMAX];

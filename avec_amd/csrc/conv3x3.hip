@@ -521,8 +521,16 @@ extern "C" int avec_wgrad3x3_c128_supported(int H, int W, int Cin, int Cout, int
   return Cin == Cout && KH == 3 && KW == 3 && stride == 1 && c3_wide_geometry(H, W, Cin, KP, RS, IT);
 }
 
+// wgrad_pairs.hip: the pair formulation (round 4) for the model's geometries (11x11 / 6x6 / 3x3 images); everything else stays on the slab kernel above
+bool wgrad3x3_pairs_supported(int H, int W, int C);
+int wgrad3x3_pairs_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t st);
+
 extern "C" int avec_wgrad3x3_c128(const void* x, const void* dy, float* dw, long long images, int C, int H, int W, hipStream_t st) {
   AVEC_CHECK_ARG(x && dy && dw && images > 0, "wgrad3x3_c128: null buffer");
+  if (wgrad3x3_pairs_supported(H, W, C)) {
+    avec_wgrad3x3_item_t it; it.x = x; it.dy = dy; it.dw = dw; it.images = images; it.C = C; it.H = H; it.W = W; it.reserved = 0;
+    return wgrad3x3_pairs_grouped(&it, 1, st);
+  }
   C3WWArgs a; a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.dw = dw; a.N = (int)images; a.H = H; a.W = W; a.C = C;
   AVEC_CHECK_ARG(c3_wide_geometry(H, W, C, a.KP, a.RS, a.IT), "wgrad3x3_c128: %d channels, %dx%d images do not fit the slabs", C, H, W);
   static bool attr_set = false;
@@ -574,6 +582,18 @@ extern "C" int avec_wgrad3x3_c64_grouped(const avec_wgrad3x3_item_t* items, int 
 
 extern "C" int avec_wgrad3x3_c128_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t st) {
   AVEC_CHECK_ARG(items && n > 0 && n <= AVEC_WGRAD_GROUP_MAX, "wgrad3x3_c128_grouped: 1..%d items", AVEC_WGRAD_GROUP_MAX);
+  {   // the model's geometries go to the pair kernel (one launch), the rest to the slab kernel (another)
+    avec_wgrad3x3_item_t fast[AVEC_WGRAD_GROUP_MAX], slow[AVEC_WGRAD_GROUP_MAX]; int nf = 0, ns = 0;
+    for (int i = 0; i < n; ++i) {
+      AVEC_CHECK_ARG(items[i].x && items[i].dy && items[i].dw && items[i].images > 0, "wgrad3x3_c128_grouped: null buffer in item %d", i);
+      if (wgrad3x3_pairs_supported(items[i].H, items[i].W, items[i].C)) fast[nf++] = items[i]; else slow[ns++] = items[i];
+    }
+    if (nf) {
+      if (int r = wgrad3x3_pairs_grouped(fast, nf, st)) return r;
+      if (!ns) return 0;
+      return avec_wgrad3x3_c128_grouped(slow, ns, st);
+    }
+  }
   C3WWGroup g; g.n = n;
   long long cost[AVEC_WGRAD_GROUP_MAX]; int kinds[AVEC_WGRAD_GROUP_MAX], nwg[AVEC_WGRAD_GROUP_MAX], total = 0;
   for (int i = 0; i < n; ++i) {
