@@ -5,7 +5,9 @@ import avec_amd
 from avec_amd import runtime as rt
 from avec_amd.lib import WgradItem, lib
 
-GEOS = [(3200, 128, 11, 11), (3200, 256, 6, 6), (3200, 512, 3, 3)]
+import os
+NIMG = int(os.environ.get("WG_IMAGES", "3200"))
+GEOS = [(NIMG, 128, 11, 11), (NIMG, 256, 6, 6), (NIMG, 512, 3, 3)]
 
 
 def timed(fn, reps=5):
