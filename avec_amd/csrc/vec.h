@@ -96,9 +96,13 @@ __device__ __forceinline__ void colreduce_atomic(float (&part)[NV][4], float* co
 // workspace for a col_grid launch with NV reduced quantities (finish with col_finalize(ws, grid.x, grid.y, NV, 128, dst, C, st))
 static inline ColWs col_ws(dim3 grid, int NV, hipStream_t st) { return avec_reduce_ws((size_t)grid.x * grid.y * NV * 128, st); }
 // ... only when the one-pass version would issue many atomics (the second pass costs a launch)
+// AVEC_COLWS_MIN_ATOMICS: one-pass below this many atomics (default 16384).  Round 4 measured the step with 70 000 (the BatchNorm reductions of the conformer
+// convolution modules lose their second-pass launch, ~4.7 us each inside a dependent chain): 20.00 vs 19.90 ms; with 270 000: 21.2 ms -- the contended fp32 atomics
+// cost more than the launch they replace.
+static inline long long col_ws_min_atomics() { static long long v = -1; if (v < 0) { const char* e = getenv("AVEC_COLWS_MIN_ATOMICS"); v = e ? atoll(e) : 16384; } return v; }
 static inline ColWs col_ws_if(dim3 grid, int NV, int C, hipStream_t st) {
   const long long atomics = (long long)grid.y * NV * C;
-  return atomics > 16384 ? col_ws(grid, NV, st) : ColWs{nullptr};
+  return atomics > col_ws_min_atomics() ? col_ws(grid, NV, st) : ColWs{nullptr};
 }
 
 static inline dim3 col_grid(long long M, int C) {
@@ -144,6 +148,7 @@ static inline unsigned col8_blocks(long long M, int C) { const int R = 256 / (C 
 // block count is kept low (every block issues NV*C atomics)
 static inline unsigned col8_cfg(long long M, int C, int NV, ColWs* ws, hipStream_t st) {
   unsigned nb = col8_blocks(M, C);
+  if ((long long)nb * NV * C <= col_ws_min_atomics()) { *ws = ColWs{nullptr}; return nb; }      // small reductions: one pass, atomics
   *ws = avec_reduce_ws((size_t)nb * NV * C, st);
   if (!ws->partial && nb > 256) nb = 256;
   return nb;
