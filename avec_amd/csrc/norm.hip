@@ -242,6 +242,117 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__
   }
 }
 
+// ---- two consecutive LayerNorms per launch (round 4): the block-closing norm and the next block's first pre-norm; one wave per row, the row in registers (D <= 512) ----
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ g1, const float* __restrict__ b1, float eps1,
+                                                      float* __restrict__ y1, float* __restrict__ mean1, float* __restrict__ rstd1,
+                                                      const float* __restrict__ g2, const float* __restrict__ b2, float eps2,
+                                                      TO* __restrict__ h2, float* __restrict__ mean2, float* __restrict__ rstd2, long long M, int D) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) ld4<float>(x + row * D + c, v[i]); else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+  auto norm = [&](const float* g, const float* b, float eps, float* mean, float* rstd) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sm += v[i][0] + v[i][1] + v[i][2] + v[i][3];      // (columns beyond D hold zeros)
+    const float mu = wave_sum(sm) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; } }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane * 4 + i * 256; if (c >= D) break;
+      float gg[4], bb[4]; ld4<float>(g + c, gg); ld4<float>(b + c, bb);
+      for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mu) * rs * gg[e] + bb[e];
+    }
+  };
+  norm(g1, b1, eps1, mean1, rstd1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) st4<float>(y1 + row * D + c, v[i]); }
+  norm(g2, b2, eps2, mean2, rstd2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) st4<TO>(h2 + row * D + c, v[i]); }
+}
+extern "C" int avec_layernorm_fwd2(int dtype, const float* x, const float* gamma1, const float* beta1, float eps1, float* y1, float* mean1, float* rstd1,
+                                   const float* gamma2, const float* beta2, float eps2, void* h2, float* mean2, float* rstd2, long long M, int D, hipStream_t st) {
+  AVEC_CHECK_ARG(x && gamma1 && beta1 && y1 && mean1 && rstd1 && gamma2 && beta2 && h2 && mean2 && rstd2, "layernorm_fwd2: null pointer");
+  AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 512, "layernorm_fwd2: D=%d must be a multiple of 4 in [4, 512]", D);
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (dtype == AVEC_F32) hipLaunchKernelGGL(ln_fwd2_kernel<float>, grid, dim3(256), 0, st, x, gamma1, beta1, eps1, y1, mean1, rstd1, gamma2, beta2, eps2, (float*)h2, mean2, rstd2, M, D);
+  else hipLaunchKernelGGL(ln_fwd2_kernel<bf16>, grid, dim3(256), 0, st, x, gamma1, beta1, eps1, y1, mean1, rstd1, gamma2, beta2, eps2, (bf16*)h2, mean2, rstd2, M, D);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+template <typename TG>
+__global__ __launch_bounds__(256) void ln_bwd_rows2_kernel(const TG* __restrict__ dy2, const float* __restrict__ x2, const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                           const float* __restrict__ g2, const float* __restrict__ dres2, float* __restrict__ dx2,
+                                                           const float* __restrict__ x1, const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                           const float* __restrict__ g1, float* __restrict__ dx1, long long M, int D, LnPrep pr) {
+  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float d[2][4], v[2][4], o[2][4], gg[2][4], w1[2][4], gg1[2][4];
+  const float mu2 = mean2[row], rs2 = rstd2[row], mu1 = mean1[row], rs1 = rstd1[row];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < D) {
+      ld4<TG>(dy2 + row * D + c, d[i]); ld4<float>(x2 + row * D + c, v[i]); ld4<float>(g2 + c, gg[i]); ld4<float>(x1 + row * D + c, w1[i]); ld4<float>(g1 + c, gg1[i]);
+      if (dres2) ld4<float>(dres2 + row * D + c, o[i]); else { o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[i][e] = 0.f; v[i][e] = mu2; o[i][e] = 0.f; gg[i][e] = 0.f; w1[i][e] = mu1; gg1[i][e] = 0.f; }
+    }
+  }
+  // the same arithmetic, in the same order, as two ln_bwd_rows_kernel launches
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float xh = (v[i][e] - mu2) * rs2, t = d[i][e] * gg[i][e]; v[i][e] = xh; s1 += t; s2 += t * xh; }
+  s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane * 4 + i * 256;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[i][e] += rs2 * (d[i][e] * gg[i][e] - s1 - v[i][e] * s2);
+    if (c < D) st4<float>(dx2 + row * D + c, o[i]); else { o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f; }
+  }
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float xh = (w1[i][e] - mu1) * rs1, t = o[i][e] * gg1[i][e]; w1[i][e] = xh; t1 += t; t2 += t * xh; }
+  t1 = wave_sum(t1) / D; t2 = wave_sum(t2) / D;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane * 4 + i * 256; if (c >= D) break;
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = rs1 * (o[i][e] * gg1[i][e] - t1 - w1[i][e] * t2);
+    st4<float>(dx1 + row * D + c, r);
+    if (pr.out) {
+      float q[4], ds[4]; drop4(drop_key(pr.rng, pr.stream, pr.p), (unsigned long long)row * D + c, ds);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = r[e] * (pr.alpha * ds[e]);
+      if (pr.f32) st4<float>((float*)pr.out + row * D + c, q); else st4<bf16>((bf16*)pr.out + row * D + c, q);
+    }
+  }
+}
+extern "C" int avec_layernorm_bwd2(int dtype, const void* dy2, const float* x2, const float* mean2, const float* rstd2, const float* gamma2, const float* dres2, float* dx2,
+                                   const float* x1, const float* mean1, const float* rstd1, const float* gamma1, float* dx1,
+                                   void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream, long long M, int D, hipStream_t st) {
+  AVEC_CHECK_ARG(dy2 && x2 && mean2 && rstd2 && gamma2 && dx2 && x1 && mean1 && rstd1 && gamma1 && dx1, "layernorm_bwd2: null pointer");
+  AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 512 && (!prep || prep_drop_p <= 0.f || rng), "layernorm_bwd2: D=%d must be a multiple of 4 in [4, 512]; dropout needs rng", D);
+  LnPrep pr; pr.out = prep; pr.alpha = prep_alpha; pr.p = prep ? prep_drop_p : 0.f; pr.rng = rng; pr.stream = rng_stream; pr.f32 = dtype == AVEC_F32;
+  dim3 grid((unsigned)((M + 3) / 4));
+  if (dtype == AVEC_F32) hipLaunchKernelGGL(ln_bwd_rows2_kernel<float>, grid, dim3(256), 0, st, (const float*)dy2, x2, mean2, rstd2, gamma2, dres2, dx2, x1, mean1, rstd1, gamma1, dx1, M, D, pr);
+  else hipLaunchKernelGGL(ln_bwd_rows2_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy2, x2, mean2, rstd2, gamma2, dres2, dx2, x1, mean1, rstd1, gamma1, dx1, M, D, pr);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // ---- grouped LayerNorm parameter gradients: dgamma_k[c] += sum_m dy_k[m][c] * xhat_k[m][c], dbeta_k[c] += sum_m dy_k[m][c] for up to AVEC_LN_GROUP_MAX layers in ONE launch.
 // They only feed the optimizer, so the caller queues them (with the weight-gradient GEMMs) instead of paying a column reduction inside every LayerNorm backward.
 // Workgroup = 128 rows of one layer; thread = 4 consecutive columns of every R-th row; LDS reduction over the row lanes, then one atomic per column per workgroup.

@@ -64,7 +64,7 @@ class ConformerBlock(nn.Module):
         x = self.conv_module.residual_forward(x, None if isinstance(self.conv_res, nn.Identity) else self.conv_res)
         x = self.ff_module2.residual_forward(x, 0.5, lazy_out=isinstance(self.norm, nn.LayerNorm))
         if isinstance(self.norm, nn.LayerNorm):
-            x = normalizations.torch_layer_norm_forward(self.norm, x)
+            x = normalizations.torch_layer_norm_forward(self.norm, x, getattr(self, "_next_ln", None))
         return x
 
 

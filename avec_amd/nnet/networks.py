@@ -72,6 +72,12 @@ class ConformerInterCTC(nn.Module):
                     self.interctc_modules.append(modules.InterCTCResModule(dim_model=d_out, vocab_size=vocab_size))
                 i += 1
 
+        # the LayerNorm that closes block i is read next by the first pre-norm of block i + 1 (unless an InterCTC module sits between them): one launch for both
+        # (ops.LN_PAIR); a plain attribute, not a registered submodule (the state_dict is the reference's)
+        for i in range(len(self.conformer_blocks) - 1):
+            b0, b1 = self.conformer_blocks[i], self.conformer_blocks[i + 1]
+            if (i + 1) not in interctc_blocks and isinstance(b0.norm, nn.LayerNorm) and b0.norm.normalized_shape == b1.ff_module1.layers[0].normalized_shape:
+                object.__setattr__(b0, "_next_ln", b1.ff_module1.layers[0])
         # the position projections of the consecutive blocks of a stage share their input (the sinusoid table of the stage's sequence length): one [L D][D] weight in the
         # arena -> one launch per stage and pass instead of one per block (ops._pos_group_entry); state_dict names are unchanged
         i0 = 0

@@ -20,9 +20,10 @@ class LayerNorm(nn.LayerNorm):
         return y if self.channels_last else y.transpose(1, -1)
 
 
-def torch_layer_norm_forward(ln, x):
-    """nn.LayerNorm instances created by the composites (FeedForwardModule / ConformerBlock) use the same kernel."""
-    return ops.LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+def torch_layer_norm_forward(ln, x, nxt=None):
+    """nn.LayerNorm instances created by the composites (FeedForwardModule / ConformerBlock) use the same kernel.
+    nxt: the LayerNorm that reads the result next (the following block's first pre-norm): its output comes out of the same launch (ops.LN_PAIR)."""
+    return ops.LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, None if nxt is None else (nxt.weight, nxt.bias, nxt.eps))
 
 
 class _BatchNormMixin:

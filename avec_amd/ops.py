@@ -456,6 +456,28 @@ def layernorm_bwd_parts(parts, S, x, mean, rstd, w, b, M, D, dres=None, prep=Non
     return dx
 
 
+def layernorm_bwd_pair(dy2, x2, mean2, rstd2, w2, b2, dres2, x1, mean1, rstd1, w1, req1, ctx1, M, D):
+    """LayerNorm backward of a module's pre-norm (dy2: act, residual gradient dres2) AND of the LayerNorm that produced its input (LayerNormFn ctx1; req1 = the prepared
+    gradient wanted by the module in front of that one): one launch; returns dx2 and leaves dx1 for LayerNormFn.backward (see LN_PAIR)"""
+    dx2, dx1 = empty((M, D), torch.float32, x2), empty((M, D), torch.float32, x2)
+    task = torch._C._current_graph_task_id()
+    pt, alpha, drop_p, sid = None, 1.0, 0.0, 0
+    if req1 is not None:
+        if _PREP_READY["task"] != task:
+            _PREP_READY["task"], _PREP_READY["m"] = task, {}
+        pt = empty((M, D), rt.act_dtype(), x2)
+        alpha, drop_p, sid = req1
+        _PREP_READY["m"][dx1.data_ptr()] = (pt, M, D, alpha, drop_p, sid)
+    rng = rt.rng_state(x2.device).data_ptr() if (pt is not None and drop_p > 0) else None
+    lib.layernorm_bwd2(rt.dt(), dy2.data_ptr(), x2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), w2.data_ptr(), dres2.data_ptr(), dx2.data_ptr(),
+                       x1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), w1.data_ptr(), dx1.data_ptr(), _p(pt), alpha, drop_p, rng, sid, M, D, rt.stream())
+    if _LN2_READY["task"] != task:
+        _LN2_READY["task"], _LN2_READY["m"] = task, {}
+    _LN2_READY["m"][dx2.data_ptr()] = (dx1, ctx1)
+    defer_ln_param_grads(dy2, False, x2, mean2, rstd2, w2, b2, M, D)
+    return dx2
+
+
 def grad_prep(dout, M, N, alpha=1.0, drop_p=0.0, sid=0, dbias=None):
     dacc = empty((M, N), rt.act_dtype(), dout)
     rng = rt.rng_state(dout.device).data_ptr() if drop_p > 0 else None
@@ -542,14 +564,24 @@ def linear(x, weight, bias, out_f32=True):
     return LinearFn.apply(x.to(rt.act_dtype()), weight, bias, False, out_f32)
 
 
+# ---- two consecutive LayerNorms as one launch per pass (round 4) --------------------------------------------------------------------------------------------
+# The LayerNorm that closes a ConformerBlock is followed at once by the pre-norm of the next block's first feed-forward module: rows are independent, so the closing
+# norm's launch also produces the next one's output (avec_layernorm_fwd2) and leaves it on its result tensor; FeedForwardFn picks it up when the tensor, the
+# parameters and eps are the ones it was made for.  Backward: the feed-forward module's LayerNorm backward also runs the closing norm's (avec_layernorm_bwd2) and
+# leaves dx1 under the address of the gradient it returns; LayerNormFn.backward takes it if that very tensor comes back from autograd (one consumer), else computes.
+LN_PAIR = os.environ.get("AVEC_LN_PAIR", "1") != "0"
+_LN2_READY = {"task": -1, "m": {}}
+
+
 class LayerNormFn(torch.autograd.Function):
-    """nn.LayerNorm over the last dim of an fp32 tensor -> fp32."""
+    """nn.LayerNorm over the last dim of an fp32 tensor -> fp32.  nxt = (weight, bias, eps) of a LayerNorm that will read the result next (see above)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, nxt=None):
         rt.require_gpu(x)
         shp = x.shape
         lz = _lazy_of(x)
+        pair = None
         if lz is not None and shp[-1] <= 512 and shp[-1] % 4 == 0 and x.is_contiguous():
             base, parts, S = lz                      # the input is still a sum of partial tensors: summed while loading, stored into x (see _lazy_of)
             x2 = x.view(base.shape)
@@ -562,15 +594,31 @@ class LayerNormFn(torch.autograd.Function):
             materialise(x)
             x2 = _f32c(x.reshape(-1, shp[-1]))
             M, D = x2.shape
-            y, mean, rstd = layernorm_fwd(x2, w, b, M, D, True, eps)
+            if nxt is not None and LN_PAIR and D <= 512 and D % 4 == 0:
+                w2, b2, eps2 = nxt
+                y, mean, rstd = empty((M, D), torch.float32, x2), empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
+                h2, mean2, rstd2 = empty((M, D), rt.act_dtype(), x2), empty((M,), torch.float32, x2), empty((M,), torch.float32, x2)
+                lib.layernorm_fwd2(rt.dt(), x2.data_ptr(), w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   w2.data_ptr(), b2.data_ptr(), eps2, h2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), M, D, rt.stream())
+                pair = (h2, mean2, rstd2, w2.data_ptr(), float(eps2), M, D, ctx)
+            else:
+                y, mean, rstd = layernorm_fwd(x2, w, b, M, D, True, eps)
         ctx.saved = (x2, mean, rstd, w, b, M, D, shp, _prep_request(x))
-        return y.view(shp)
+        out = y.view(shp)
+        if pair is not None:
+            out._avec_ln2 = pair
+        return out
 
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd, w, b, M, D, shp, req = ctx.saved
+        if _LN2_READY["task"] == torch._C._current_graph_task_id():
+            r = _LN2_READY["m"].pop(dy.data_ptr(), None)
+            if r is not None and r[1] is ctx and dy.dtype == torch.float32 and dy.is_contiguous():      # the feed-forward module behind has done this LayerNorm's backward already
+                defer_ln_param_grads(dy.reshape(M, D), True, x2, mean, rstd, w, b, M, D)
+                return r[0].view(shp), None, None, None, None
         dx = layernorm_bwd(_f32c(dy.reshape(M, D)), True, x2, mean, rstd, w, b, M, D, prep=req)
-        return dx.view(shp), None, None, None
+        return dx.view(shp), None, None, None, None
 
 
 class ActivationFn(torch.autograd.Function):
@@ -697,6 +745,7 @@ class FeedForwardFn(torch.autograd.Function):
         F = w1.shape[0]
         adt = rt.act_dtype()
         fused = FFN_CHAIN and _chain_ok(M, D, F) and rt.shadow(w1).Cp == D and rt.shadow(w2).Cp == F
+        ln_prev = None
         if fused:        # csrc/chain.hip: LN -> W1 slice -> Swish / dropout -> partial W2 product -> atomic add, one launch
             sh1, sh2 = rt.shadow(w1), rt.shadow(w2)
             S = lib.raw("avec_chain_slices")(F)
@@ -713,12 +762,18 @@ class FeedForwardFn(torch.autograd.Function):
             if ev is not None:
                 KERNEL_TIMER.stop(ev, (3, 0), 4.0 * M * D * F)
         else:
-            h0, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
+            pre = getattr(x, "_avec_ln2", None)
+            if pre is not None and pre[3] == ln_w.data_ptr() and pre[4] == float(eps) and pre[5:7] == (M, D) and x2.data_ptr() == x.data_ptr() and pre[0].dtype == adt:
+                h0, mean, rstd = pre[0], pre[1], pre[2]          # made by the LayerNorm launch that produced x (LayerNormFn, nxt)
+                ln_prev = pre[7]
+            else:
+                h0, mean, rstd = layernorm_fwd(x2, ln_w, ln_b, M, D, False, eps)
             z = empty((M, F), adt, x2)
             h1 = linear_fwd(h0, w1, b1, M, in_f32=False, out_f32=False, act=ACT_SWISH, out_pre=z, drop_p=drop_p, sid=sid1)
             y = linear_fwd(h1, w2, b2, M, in_f32=False, out_f32=True, drop_p=drop_p, sid=sid2, res=x2, alpha=alpha)
         ctx.saved = (x2, mean, rstd, h0, z, h1, ln_w, ln_b, w1, b1, w2, b2, alpha, drop_p, sid1, sid2, M, D, F, shp, fused)
         ctx.prep_req = _prep_request(x)
+        ctx.ln_prev = ln_prev
         if fused:
             out = y.view(shp)
             out._avec_lazy = (x2, parts, S)
@@ -752,6 +807,11 @@ class FeedForwardFn(torch.autograd.Function):
         dz = linear_bwd_input(dacc, w2, M, out_f32=False, dact_z=z, dact=ACT_SWISH, drop_p=drop_p, sid=sid1)
         linear_bwd_weight(dz, h0, w1, M, bias=b1)
         dh0 = linear_bwd_input(dz, w1, M, out_f32=False)
+        pv = ctx.ln_prev
+        if pv is not None and _in_backward() and D <= 512 and D % 4 == 0 and dh0.dtype == rt.act_dtype():
+            x1, mean1, rstd1, w1n, b1n, M1, D1, shp1, req1 = pv.saved
+            if (M1, D1) == (M, D):
+                return (layernorm_bwd_pair(dh0, x2, mean, rstd, ln_w, ln_b, dy, x1, mean1, rstd1, w1n, req1, pv, M, D).view(shp),) + (None,) * 12
         dx = layernorm_bwd(dh0, False, x2, mean, rstd, ln_w, ln_b, M, D, dres=dy, prep=ctx.prep_req)
         return (dx.view(shp),) + (None,) * 12
 

@@ -225,6 +225,15 @@ int avec_layernorm_bwd(int dtype, const void* dy, int dy_f32, const float* x, co
 int avec_layernorm_bwd_prep(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, const float* dres, void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream,
                             long long M, int D, hipStream_t stream);
+/* Two consecutive LayerNorms in one launch (D <= 512): the one that closes a ConformerBlock (nnet/blocks.py:267,303: y1 = LN1(x), fp32) and the one that opens the
+ * next block's first feed-forward module (nnet/modules.py:278: h2 = LN2(y1), act) -- rows are independent, the second reads the first's registers.
+ * Backward: dy2 (act) = gradient of h2, dres2 (fp32, may be NULL) = the gradient that reaches y1 past LN2 (the residual path); writes dx2 = dres2 + LN2'(dy2)
+ * (= the gradient of y1: also LN1's dy for avec_layernorm_param_grads_grouped) and dx1 = LN1'(dx2), plus the optional prepared gradient of dx1 (see _bwd_prep). */
+int avec_layernorm_fwd2(int dtype, const float* x, const float* gamma1, const float* beta1, float eps1, float* y1, float* mean1, float* rstd1,
+                        const float* gamma2, const float* beta2, float eps2, void* h2, float* mean2, float* rstd2, long long M, int D, hipStream_t stream);
+int avec_layernorm_bwd2(int dtype, const void* dy2, const float* x2, const float* mean2, const float* rstd2, const float* gamma2, const float* dres2, float* dx2,
+                        const float* x1, const float* mean1, const float* rstd1, const float* gamma1, float* dx1,
+                        void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream, long long M, int D, hipStream_t stream);
 /* avec_layernorm_bwd with dgamma == dbeta == NULL computes dx only (one wave per row); the parameter gradients of up to AVEC_LN_GROUP_MAX such layers are
  * then produced by ONE launch: dgamma_k[c] += sum_m dy_k[m][c] * xhat_k[m][c], dbeta_k[c] += sum_m dy_k[m][c]  (native_layer_norm_backward's weight / bias terms). */
 #define AVEC_LN_GROUP_MAX 40
