@@ -94,24 +94,31 @@ template <typename G, int I> struct WpIt {
 };
 
 template <typename G, int I>
-__device__ __forceinline__ void wp_iter(WpRegs& R, wp_f32x16 (&acc)[9], unsigned (&m0)[4], unsigned (&m2)[4], const int oyb, const unsigned (&aA)[2], const unsigned (&aB)[3][2]) {
+__device__ __forceinline__ void wp_iter(WpRegs& R, wp_f32x16 (&acc)[9], unsigned (&m0)[4], unsigned (&m2)[4], const int oyb, const bool hi_half, const unsigned (&aA)[2], const unsigned (&aB)[3][2]) {
   typedef WpIt<G, I> It;
   constexpr int H = G::H, W = G::W, NIT = G::KS * W, g = It::g;
   constexpr bool more = I + 1 < NIT;
   constexpr int N0N = more ? WpIt<G, more ? I + 1 : I>::N0 : 0;      // reads of the next iteration's first group
   if constexpr (It::xp == 0) {
-    // k-element e of this lane is image row oy = (oyb + 16 s + e) % H of its image: kh = 0 pairs it with row oy - 1 (invalid: oy = 0), kh = 2 with row oy + 1
-    // (invalid: oy = H - 1).  The invalid elements are e0, e0 + H, ... with e0 = (-oyb - 16 s) mod H, and one element earlier for kh = 2.
+    // k-element e of this lane is image row oy = (oyb + 8 (lane >> 5) + 16 s + e) % H of its image (oyb: the stage's first row, wave-uniform): kh = 0 pairs it with
+    // row oy - 1 (invalid: oy = 0), kh = 2 with row oy + 1 (invalid: oy = H - 1).  The invalid elements are e0, e0 + H, ... with e0 = (-first row) mod H, and one
+    // element earlier for kh = 2.  Both half-waves' masks are built on the SCALAR unit and selected per lane (built per lane they were ~50 VALU instructions per
+    // K-step: 90 of the launch's 740 us without the DMA).
     constexpr unsigned PAT = 1u | (1u << H) | (2 * H < 16 ? 1u << ((2 * H) & 15) : 0u) | (3 * H < 16 ? 1u << ((3 * H) & 15) : 0u) | (4 * H < 16 ? 1u << ((4 * H) & 15) : 0u);      // bits k H < 16
-    int bs = oyb + (16 * It::s) % H; bs = bs >= H ? bs - H : bs;
-    asm volatile("" : "+v"(bs));      // (keeps the masks of the KS K-steps from being computed up front: 8 registers each)
-    const int e0 = bs == 0 ? 0 : H - bs, e2 = e0 == 0 ? H - 1 : e0 - 1;
-    const unsigned b0 = (WP_ABL & 8) ? 0u : (PAT << e0), b2 = (WP_ABL & 8) ? 0u : (PAT << e2);
+    unsigned ml0[2][4], ml2[2][4];
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-      m0[dd] = ~((((b0 >> (2 * dd)) & 1u) * 0xffffu) | (((b0 >> (2 * dd + 1)) & 1u) * 0xffff0000u));
-      m2[dd] = ~((((b2 >> (2 * dd)) & 1u) * 0xffffu) | (((b2 >> (2 * dd + 1)) & 1u) * 0xffff0000u));
+    for (int hh = 0; hh < 2; ++hh) {
+      int bs = oyb + (8 * hh + 16 * It::s) % H; bs = bs >= H ? bs - H : bs;
+      const int e0 = bs == 0 ? 0 : H - bs, e2 = e0 == 0 ? H - 1 : e0 - 1;
+      const unsigned b0 = (WP_ABL & 8) ? 0u : (PAT << e0), b2 = (WP_ABL & 8) ? 0u : (PAT << e2);
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        ml0[hh][dd] = ~((((b0 >> (2 * dd)) & 1u) * 0xffffu) | (((b0 >> (2 * dd + 1)) & 1u) * 0xffff0000u));
+        ml2[hh][dd] = ~((((b2 >> (2 * dd)) & 1u) * 0xffffu) | (((b2 >> (2 * dd + 1)) & 1u) * 0xffff0000u));
+      }
     }
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) { m0[dd] = hi_half ? ml0[1][dd] : ml0[0][dd]; m2[dd] = hi_half ? ml2[1][dd] : ml2[0][dd]; }
   }
   // tap (kh, kw) pairs x column xp with dy column ox = xp + 1 - kw
   // ---- kh = 0: in flight behind this group's fragments: B1, B2 of this iteration
@@ -139,7 +146,7 @@ __device__ __forceinline__ void wp_iter(WpRegs& R, wp_f32x16 (&acc)[9], unsigned
   acc[7] = wp_mma(R.A[g & 3], R.B[2], acc[7]);
   if constexpr (It::xp >= 1) acc[8] = wp_mma(R.A[(g - 1) & 3], R.B[2], acc[8]);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (more) { WpIt<G, more ? I + 1 : I>::template issueB<2>(R, aB); wp_iter<G, more ? I + 1 : I>(R, acc, m0, m2, oyb, aA, aB); }
+  if constexpr (more) { WpIt<G, more ? I + 1 : I>::template issueB<2>(R, aB); wp_iter<G, more ? I + 1 : I>(R, acc, m0, m2, oyb, hi_half, aA, aB); }
 }
 
 // stages [s_begin, s_end) of the reduction for one kind (64 output x 128 input channels) of layer `a`; adds the result to a.dw
@@ -235,8 +242,8 @@ __device__ __attribute__((noinline)) void wp_body(const WpArgs a_, char* const s
     WpRegs R; unsigned m0[4], m2[4];
     WpIt<G, 0>::issue0(R, aA, aB); WpIt<G, 0>::template issueB<1>(R, aB); WpIt<G, 0>::template issueB<2>(R, aB);
     if (q + 1 < s_end && !(WP_ABL & 1)) load_stage(q + 1, par ^ 1);
-    const int oyb = (int)(((unsigned)q * (unsigned)ROWS + 8u * (unsigned)(lane >> 5)) % (unsigned)H);       // image row (inside its image) of this lane's first k-element of K-step 0
-    wp_iter<G, 0>(R, acc, m0, m2, oyb, aA, aB);
+    const int oyb = (int)(((unsigned)q * (unsigned)ROWS) % (unsigned)H);       // image row (inside its image) of the stage's first row (wave-uniform)
+    wp_iter<G, 0>(R, acc, m0, m2, oyb, lane >= 32, aA, aB);
     const unsigned dlt = par ? (unsigned)-G::STAGE : (unsigned)G::STAGE;      // the other stage of the ring
 #pragma unroll
     for (int h = 0; h < 2; ++h) { aA[h] += dlt; aB[0][h] += dlt; aB[1][h] += dlt; aB[2][h] += dlt; }
