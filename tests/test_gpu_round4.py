@@ -309,3 +309,93 @@ def test_conformer_block_with_chain_kernels_matches_launch_sequence(B, T, D):
         if k.endswith(("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias")) or gref.abs().max() < 1e-6 * max(1.0, float(res[False][1].abs().max())):
             continue                                                  # (analytically zero gradients -- softmax shift invariance, a bias in front of training-mode BatchNorm: rounding noise on both sides)
         assert l2e(res[True][2][k], gref) < 3e-2, (k, l2e(res[True][2][k], gref))
+
+
+# ----------------------------------------------------------------------------------------------
+# two consecutive LayerNorms per launch (avec_layernorm_fwd2 / _bwd2, ops.LN_PAIR)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,D", [(100, 256), (37, 360), (64, 180), (5, 512)])
+def test_layernorm_pair_kernels_match_two_launches_and_torch(M, D, dtype):
+    """y1 = LN1(x) (nnet/blocks.py:267,303), h2 = LN2(y1) (nnet/modules.py:278) from ONE launch == the two single launches bit for bit (same arithmetic in the same
+    order), and torch.nn.functional.layer_norm in fp32 to 1e-5; likewise backward (dx2 = dres2 + LN2'(dy2), dx1 = LN1'(dx2), prepared gradient of dx1)."""
+    import avec_amd
+    from avec_amd import ops, runtime as rt
+    from avec_amd.lib import lib
+    avec_amd.set_compute_dtype(dtype)
+    d = dev()
+    adt = rt.act_dtype()
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g).to(d)
+    w1, b1, w2, b2 = [(torch.randn(D, generator=g) * 0.3 + (1.0 if i % 2 == 0 else 0.0)).to(d) for i in range(4)]
+    eps1, eps2 = 1e-6, 1e-5
+    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
+    y1, m1, r1, m2, r2 = f32(M, D), f32(M), f32(M), f32(M), f32(M)
+    h2 = torch.empty(M, D, dtype=adt, device=d)
+    lib.layernorm_fwd2(rt.dt(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), eps1, y1.data_ptr(), m1.data_ptr(), r1.data_ptr(),
+                       w2.data_ptr(), b2.data_ptr(), eps2, h2.data_ptr(), m2.data_ptr(), r2.data_ptr(), M, D, rt.stream())
+    ya, ma, ra = ops.layernorm_fwd(x, w1, b1, M, D, True, eps1)
+    hb, mb, rb = ops.layernorm_fwd(ya, w2, b2, M, D, False, eps2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, ya) and torch.equal(m1, ma) and torch.equal(r1, ra)
+    assert torch.equal(h2, hb) and torch.equal(m2, mb) and torch.equal(r2, rb)
+    ref1 = torch.nn.functional.layer_norm(x.cpu(), (D,), w1.cpu(), b1.cpu(), eps1)
+    ref2 = torch.nn.functional.layer_norm(ref1, (D,), w2.cpu(), b2.cpu(), eps2)
+    assert rel_err(y1.cpu(), ref1) < 1e-5 and rel_err(h2.float().cpu(), ref2) < (1e-5 if dtype == "f32" else 6e-3)
+    # backward
+    dy2 = torch.randn(M, D, generator=g).to(d).to(adt)
+    dres2 = torch.randn(M, D, generator=g).to(d)
+    dx2, dx1, prep = f32(M, D), f32(M, D), torch.empty(M, D, dtype=adt, device=d)
+    lib.layernorm_bwd2(rt.dt(), dy2.data_ptr(), y1.data_ptr(), m2.data_ptr(), r2.data_ptr(), w2.data_ptr(), dres2.data_ptr(), dx2.data_ptr(),
+                       x.data_ptr(), m1.data_ptr(), r1.data_ptr(), w1.data_ptr(), dx1.data_ptr(), prep.data_ptr(), 0.5, 0.0, None, 0, M, D, rt.stream())
+    dxa, dxb, prepb = f32(M, D), f32(M, D), torch.empty(M, D, dtype=adt, device=d)
+    lib.layernorm_bwd(rt.dt(), dy2.data_ptr(), int(dtype == "f32"), y1.data_ptr(), m2.data_ptr(), r2.data_ptr(), w2.data_ptr(), dxa.data_ptr(), dres2.data_ptr(), None, None, M, D, rt.stream())
+    lib.layernorm_bwd_prep(rt.dt(), dxa.data_ptr(), 1, x.data_ptr(), m1.data_ptr(), r1.data_ptr(), w1.data_ptr(), dxb.data_ptr(), None, prepb.data_ptr(), 0.5, 0.0, None, 0, M, D, rt.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dxa) and torch.equal(dx1, dxb) and torch.equal(prep, prepb)
+    xr = x.cpu().double().requires_grad_(True)
+    y1r = torch.nn.functional.layer_norm(xr, (D,), w1.cpu().double(), b1.cpu().double(), eps1)
+    y1r.retain_grad()
+    h2r = torch.nn.functional.layer_norm(y1r, (D,), w2.cpu().double(), b2.cpu().double(), eps2)
+    (h2r * dy2.cpu().double()).sum().backward(retain_graph=True)
+    g2 = y1r.grad + dres2.cpu().double()
+    xr.grad = None
+    y1r.backward(g2)
+    assert rel_err(dx2.cpu().double(), g2) < 1e-4 and rel_err(dx1.cpu().double(), xr.grad) < 1e-4
+
+
+def test_layernorm_pair_hand_over_in_a_block_stack_matches_separate_launches():
+    """two ConformerBlocks back to back (the first one's closing LayerNorm feeds the second one's first pre-norm): losses and every parameter gradient with the
+    paired launches (ops.LN_PAIR) equal the separate launches bit for bit"""
+    import avec_amd
+    import nnet
+    from avec_amd import ops
+    avec_amd.set_compute_dtype("f32")
+    d = dev()
+    res, calls = {}, {True: 0, False: 0}
+    orig = ops.layernorm_bwd_pair
+    for pair in (True, False):
+        ops.LN_PAIR = pair
+
+        def counted(*a, _pair=pair, **k):
+            calls[_pair] += 1
+            return orig(*a, **k)
+        ops.layernorm_bwd_pair = counted
+        try:
+            torch.manual_seed(3)
+            net = nnet.ConformerInterCTC(dim_model=64, num_blocks=3, interctc_blocks=[], vocab_size=16,
+                                         att_params={"class": "RelPos1dMultiHeadAttention", "params": {"num_heads": 4, "attn_drop_rate": 0.0, "num_pos_embeddings": 200}},
+                                         conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}}, drop_rate=0.0).to(d).train()
+            x = torch.randn(2, 20, 64, generator=torch.Generator().manual_seed(5)).to(d).requires_grad_(True)
+            y, _, _ = net(x, torch.tensor([20, 13], device=d))
+            (y * y).sum().backward()
+            torch.cuda.synchronize()
+            res[pair] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu().clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            ops.LN_PAIR = True
+            ops.layernorm_bwd_pair = orig
+    assert calls == {True: 2, False: 0}, calls          # blocks 0 -> 1 and 1 -> 2 take the paired launches, forward (else there is nothing to hand over) and backward
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) > 20
+    for k in res[True][2]:
+        assert torch.allclose(res[True][2][k], res[False][2][k], rtol=1e-5, atol=1e-6), k
