@@ -377,6 +377,11 @@ class Model(Module):
         if step is None:
             while len(cache) >= cache_size:
                 cache.pop(next(iter(cache)))                 # least recently used (dict order = recency)
+                ev = self.__dict__["_graph_evictions"] = self.__dict__.get("_graph_evictions", 0) + 1
+                if ev == 2 * cache_size:                     # every new shape costs an eager warm-up step, a capture and a private activation pool
+                    import warnings
+                    warnings.warn("graphed_train_step: %d captured steps evicted from a cache of %d -- the batch shapes do not repeat; bucket the batches "
+                                  "(graph_bucket_frames / a length-bucketed sampler, nnet/samplers.py) or raise graph_cache_size" % (ev, cache_size))
             step = self.make_graphed_train_step(inputs, targets, precision=precision, warmup=1)      # (the warm-up pass is a real optimisation step on this batch)
             cache[key] = step
             return step.warm_losses
