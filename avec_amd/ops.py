@@ -298,7 +298,7 @@ def _launch_pending(q, part=None):
             chunk = q.cw[i:i + WGRAD_GROUP_MAX]
             lib.wgrad3x3_c128_grouped((WgradItem * len(chunk))(*chunk), len(chunk), rt.stream())
         if ev is not None:
-            KERNEL_TIMER.stop(ev, (2, 2), q.cw_flops)
+            KERNEL_TIMER.stop(ev, (2, 2), q.cw_flops, sum(2.0 * 2 * it.images * it.H * it.W * it.C + 4.0 * 9 * it.C * it.C for it in q.cw))      # x, dy once (bf16) + dW once (fp32)
         q.cw, q.cw_flops = [], 0.0
     if q.cw64 and part in (None, "cw"):
         ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
@@ -306,7 +306,7 @@ def _launch_pending(q, part=None):
             chunk = q.cw64[i:i + WGRAD_GROUP_MAX]
             lib.wgrad3x3_c64_grouped((WgradItem * len(chunk))(*chunk), len(chunk), rt.stream())
         if ev is not None:
-            KERNEL_TIMER.stop(ev, (2, 2), q.cw64_flops)
+            KERNEL_TIMER.stop(ev, (2, 2), q.cw64_flops, sum(2.0 * 2 * it.images * it.H * it.W * it.C + 4.0 * 9 * it.C * it.C for it in q.cw64))
         q.cw64, q.cw64_flops = [], 0.0
     if not q.tn and not q.ln and not q.cw and not q.cw64:
         q.keep = []
