@@ -201,6 +201,13 @@ __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wm,
   }
 }
 
+// 4 elements as they lie in memory (conversion deferred: the loads of several rows are issued before any arithmetic); same values as ld4<T>
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16> { uint2 t; __device__ __forceinline__ void load(const bf16* p) { t = *(const uint2*)p; }
+  __device__ __forceinline__ void get(float v[4]) const { v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); } };
+template <> struct Raw4<float> { float4 t; __device__ __forceinline__ void load(const float* p) { t = *(const float4*)p; }
+  __device__ __forceinline__ void get(float v[4]) const { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
+
 // ---- shared epilogue of the NT kernels ----
 template <typename T, int BM, int BN, int MT, int NT>
 __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, long long m0, int n0, int tid, int lane, int wm, int wn, int perm_cls = 0) {
@@ -247,6 +254,53 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
     __syncthreads();
     // 4-wide vector I/O whenever the 4 columns are inside N and every row stride keeps them 8/16-byte aligned
     const bool v4 = vec_ok && !(e.ldo & 3) && !(e.ldpre & 3) && !(e.ldres & 3) && !(e.ldz & 3);
+#if !AVEC_ABL
+    if (BN == 64 && v4 && !e.bnb_y && !g.perm2) {
+      // 64-column tiles (the conformer-sized products): the four row groups of a pass at once -- every residual / act'(z) row is requested before the first
+      // store, ONE memory round trip per pass instead of one per row group (the rolled loop below waits for its loads row group by row group: ~1 us each on
+      // kernels whose whole life is 4-6 us).  Each element is read and written by the same thread, so `out` may alias `res`.  Same arithmetic, same order.
+      constexpr int RPI = 256 / TPR, NIT = 64 / RPI;
+      const bool has_res = e.res != nullptr;
+      Raw4<T> rb[NIT], zb[NIT]; Raw4<float> rf[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const long long row = m0 + pass * 64 + tid / TPR + it * RPI;
+        if (row >= g.M) continue;
+        if (has_res) { if (e.res_act) rb[it].load((const T*)e.res + row * e.ldres + col); else rf[it].load((const float*)e.res + row * e.ldres + col); }
+        if (e.dact) zb[it].load((const T*)e.dact_z + row * e.ldz + col);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int lr = tid / TPR + it * RPI;
+        const long long row = m0 + pass * 64 + lr;
+        if (row >= g.M) continue;
+        float v[4];
+        { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bias4[c];
+        if (e.out_pre) st4<T>((T*)e.out_pre + row * e.ldpre + col, v);
+        if (e.act == 1) { for (int c = 0; c < 4; ++c) v[c] = swishf_(v[c]); } else if (e.act == 2) { for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f); }
+        if (e.drop_p > 0.f) {
+          const unsigned long long i0 = (unsigned long long)row * g.N + col;
+          if (!(g.N & 1)) { float ds[4]; drop4(dk, i0, ds); for (int c = 0; c < 4; ++c) v[c] *= ds[c]; }
+          else { for (int c = 0; c < 4; ++c) v[c] *= drop_one(dk, i0 + c); }
+        }
+        if (e.dact) {
+          float z[4]; zb[it].get(z);
+          for (int c = 0; c < 4; ++c) v[c] *= (e.dact == 1) ? dswishf_(z[c]) : (z[c] > 0.f ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * v[c]; v[c] *= e.alpha; }
+        if (has_res) {
+          float r4[4]; if (e.res_act) rb[it].get(r4); else rf[it].get(r4);
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+      }
+      __syncthreads();
+      continue;
+    }
+#endif
 #pragma unroll 1
     for (int lr = tid / TPR; lr < 64; lr += 256 / TPR) {
       long long row = m0 + pass * 64 + lr;
