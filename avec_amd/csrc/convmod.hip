@@ -45,11 +45,33 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) float gs[];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; const int col = (blockIdx.x * 32 + tx) * 4;
   const int b = blockIdx.y / nchunks, to0 = (blockIdx.y - b * nchunks) * DW_TT; const int nto = min(DW_TT, To - to0);
+  // the taps of this thread's four channels in registers, requested in front of the staging pass (one memory round trip for both): the tap loop used to fetch
+  // w[k][col] from memory once per (row, tap) -- 60 dependent L1 / L2 round trips per thread, most of the kernel's 10 us (tools/block_trace.py)
+  const bool wreg = K <= KMAX;
+  float ww[KMAX][4], bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (wreg && col < C) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { if (k < K) ld4<float>(w + (long long)k * C + col, ww[k]); else ww[k][0] = ww[k][1] = ww[k][2] = ww[k][3] = 0.f; }
+  }
+  if (col < C && bias) ld4<float>(bias + col, bb);
   stage_glu<T>(gs, u, b, Tn, C, col, to0 * stride - padl, (nto - 1) * stride + K);
   __syncthreads();
   float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (col < C && wreg) {
+    for (int r = ty; r < nto; r += 8) {
+      float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const float4 g = *(const float4*)(gs + (r * stride + k) * 128 + tx * 4);
+          acc[0] += ww[k][0] * g.x; acc[1] += ww[k][1] * g.y; acc[2] += ww[k][2] * g.z; acc[3] += ww[k][3] * g.w;
+        }
+      }
+      st4<T>(out + ((long long)b * To + to0 + r) * C + col, acc);
+      for (int e = 0; e < 4; ++e) { part[0][e] += acc[e]; part[1][e] += acc[e] * acc[e]; }
+    }
+  } else
   if (col < C) {
-    float bb[4] = {0.f, 0.f, 0.f, 0.f}; if (bias) ld4<float>(bias + col, bb);
     for (int r = ty; r < nto; r += 8) {
       float acc[4] = {bb[0], bb[1], bb[2], bb[3]};
       for (int k = 0; k < K; ++k) {
