@@ -82,20 +82,49 @@ template <int PITCH, int NW>
 __device__ __forceinline__ void stage_rows_dma(unsigned lds_img, char* img, const bf16* src, long long ld, int row0, int nrows, int limit, int d, int dpad,
                                                long long last_row, int rowbytes, int wave, int lane) {
   constexpr int SLOTS = PITCH / 16, RPI = 64 / SLOTS;            // slots per image row, rows per instruction
+  constexpr int NV = PITCH == 128 ? 2 : 4;                       // the swizzle of row RPI k + rg depends on k only through k % NV (aswz: bits 1-3 / 0-3 of the row)
   const int CH = dpad >> 3;
   const int rg = lane / SLOTS, pos = lane % SLOTS;
   const int ninstr = nrows / RPI;
-  for (int k = wave; k < ninstr; k += NW) {
-    const int r = k * RPI + rg;
-    int c = pos ^ aswz<PITCH>(r); c = c < CH ? c : 0;            // unused slots re-read chunk 0
-    int gr = row0 + r; gr = gr < 0 ? 0 : (gr >= limit ? limit - 1 : gr);
-    const char* p = (const char*)(src + (long long)gr * ld) + c * 16;
-    const bool past = gr == last_row && c * 16 + 16 > rowbytes;
-    attn_glds16(past ? (const void*)attn_zero16 : (const void*)p, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_img + k * 1024)));
-    if (past) {      // (at most one lane of the whole grid)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      bf16* dst = (bf16*)(img + k * 1024 + lane * 16);
-      for (int e = 0; e < 8; ++e) if (c * 16 + 2 * e + 2 <= rowbytes) dst[e] = ((const bf16*)p)[e];
+  // a row of the image never leaves 2^31 bytes of its tensor (T <= 384 rows of one batch element): 32-bit byte offsets, one multiply-add per instruction; the
+  // chunk a lane fetches and whether it is the chunk that would run past the end of the tensor are fixed per k % NV.  The loop is branch-free: it was ~50 VALU
+  // instructions + a divergent branch per DMA instruction, 64 DMA instructions per workgroup -- most of the 4 us the staging took.
+  const unsigned ldb = (unsigned)ld * 2u;
+  const bool can_past = dpad * 2 > rowbytes && last_row <= (long long)limit - 1;      // (uniform) the last row of the TENSOR is among the rows, and its padded width overhangs
+  const int lastr = can_past ? (int)last_row : -1;
+  // this wave's instructions are k = wave + j NW; the v-th of every NV consecutive ones has the swizzle of row RPI (wave + v NW) + rg
+  unsigned coff[NV]; bool cpast[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int c = pos ^ aswz<PITCH>(RPI * (wave + v * NW) + rg); c = c < CH ? c : 0;            // unused slots re-read chunk 0
+    coff[v] = (unsigned)c * 16u; cpast[v] = c * 16 + 16 > rowbytes;
+  }
+  for (int k0 = wave; k0 < ninstr; k0 += NW * NV) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = k0 + v * NW;
+      if (k < ninstr) {
+        int gr = row0 + k * RPI + rg; gr = gr < 0 ? 0 : (gr >= limit ? limit - 1 : gr);
+        const char* p = (const char*)src + ((unsigned)gr * ldb + coff[v]);
+        const bool past = gr == lastr && cpast[v];
+        attn_glds16(past ? (const void*)attn_zero16 : (const void*)p, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_img + k * 1024)));
+      }
+    }
+  }
+  if (can_past) {      // the overhanging chunk(s) of the tensor's last row: zero chunk above, its elements here
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k0 = wave; k0 < ninstr; k0 += NW * NV) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int k = k0 + v * NW;
+        if (k >= ninstr) break;
+        int gr = row0 + k * RPI + rg; gr = gr < 0 ? 0 : (gr >= limit ? limit - 1 : gr);
+        if (gr == lastr && cpast[v]) {
+          const bf16* p = (const bf16*)((const char*)src + ((unsigned)gr * ldb + coff[v]));
+          bf16* dst = (bf16*)(img + k * 1024 + lane * 16);
+          for (int e = 0; e < 8; ++e) if ((int)coff[v] + 2 * e + 2 <= rowbytes) dst[e] = p[e];
+        }
+      }
     }
   }
 }
@@ -131,9 +160,12 @@ static MfmaGeom mfma_geom(int T, int d, int pitch, bool bwd) {
 
 // S^T tiles of one wave: S[jt][r] = scale * (K_j.Q_i + E_{T-1-i+j}.Q_i) (+ -1e9 on masked keys, -inf beyond T) for key
 // j = 32 jt + (r&3) + 8 (r>>2) + 4 hf and query il = lane & 31; returns this lane-half's running maximum.
-template <int PITCH, int NTM>
+// DKS: K-steps of 16 channels as a compile-time constant (3 / 4 / 6 = head widths 45 / 64 / 90; 0: G.DKS at run time).  With a run-time trip count the loops
+// below stay rolled: two LDS reads -> wait -> one MFMA per iteration, with ONE wave per SIMD and nothing to overlap the round trips with.
+template <int PITCH, int NTM, int DKS>
 __device__ __forceinline__ float scores(f32x16 (&S)[NTM], const char* Ks, const char* Es, const char* qrow, float* ring, const MfmaGeom& G, float scale,
                                         int w, int il, int hf, int Tn, int klen, bool row_masked) {
+  const int dks = DKS ? DKS : G.DKS;
   const int swr = aswz<PITCH>(il);                       // swizzle of operand row (tile bases are multiples of 32: same bits)
 #pragma unroll
   for (int jt = 0; jt < NTM; ++jt)
@@ -145,7 +177,8 @@ __device__ __forceinline__ float scores(f32x16 (&S)[NTM], const char* Ks, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) R[r] = 0.f;
     const char* erow = Es + (32 * et + 32 * (1 - w) + il) * PITCH;
-    for (int kk = 0; kk < G.DKS; ++kk) {
+#pragma unroll
+    for (int kk = 0; kk < dks; ++kk) {
       const chunk16 fa = *(const chunk16*)(erow + (((2 * kk + hf) ^ swr) << 4));
       const chunk16 fb = *(const chunk16*)(qrow + (((2 * kk + hf) ^ swr) << 4));
       R = mma(fa, fb, R);
@@ -159,7 +192,8 @@ __device__ __forceinline__ float scores(f32x16 (&S)[NTM], const char* Ks, const 
   for (int jt = 0; jt < NTM; ++jt) {
     if (jt < G.NT) {
       const char* krow = Ks + (32 * jt + il) * PITCH;
-      for (int kk = 0; kk < G.DKS; ++kk) {
+#pragma unroll
+      for (int kk = 0; kk < dks; ++kk) {
         const chunk16 fa = *(const chunk16*)(krow + (((2 * kk + hf) ^ swr) << 4));
         const chunk16 fb = *(const chunk16*)(qrow + (((2 * kk + hf) ^ swr) << 4));
         S[jt] = mma(fa, fb, S[jt]);
@@ -234,8 +268,11 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&O)[CTMAX], float mul
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int PITCH, int NTM, bool ALIAS>
-__global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
+// Workgroup = 2 compute waves (32 queries each) + 2 waves that only help with the staging DMAs and leave at the first barrier (not in the ALIAS variants, whose later
+// staging turns are written for 128 threads): the staging loop is ~50 VALU instructions of address arithmetic per DMA instruction, 64 of them per workgroup.
+template <int PITCH, int NTM, bool ALIAS, int DKS>
+__global__ __launch_bounds__(ALIAS ? 128 : 256) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom G) {
+  constexpr int NWS = ALIAS ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5, il = lane & 31;
@@ -252,14 +289,16 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
     const int wv = __builtin_amdgcn_readfirstlane(w);
     const long long lastq = (long long)(a.B - 1 - b) * Tn + Tn - 1;      // last row of the q / k / v tensors, counted from this batch element's first row
     const int rb = (a.H - h) * d * 2;                                    // bytes from this head's first column to the end of a tensor row
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
-    if (!ALIAS) stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    if (!ALIAS) stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    // (E last: for the last head of a width that is not a multiple of 8 its staging ends with a wait + patch of the tensor's last row, which would serialise what follows)
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    zero_pad_channels<PITCH, 2>(Qs, 64, d, G.dpad, wv, lane);
+    zero_pad_channels<PITCH, NWS>(Qs, 64, d, G.dpad, wv, lane);
   }
   __syncthreads();
+  if (NWS > 2 && w >= 2) return;                          // the staging helpers are done
 #if AVEC_ATTN_ABL == 1
   if (sm[tid * 16] == 123) a.lse[0] = 1.f;
   return;
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
   const bool row_masked = i >= a.q_full;
 
   f32x16 S[NTM];
-  float mx = scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  float mx = scores<PITCH, NTM, DKS>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float lsum = 0.f;
 #pragma unroll
@@ -317,8 +356,9 @@ __global__ __launch_bounds__(128) void attn_mfma_fwd_kernel(AttnArgs a, MfmaGeom
 // backward, row pass: P and dS (stored for the batched dK / dV / dE GEMMs) and dQ
 //     dP^T[j][i] = V_j . dO_i ;  dS^T = P^T o (dP^T - delta_i) * scale ;  dQ^T = K^T dS^T + E_win^T unskew(dS^T)
 // ------------------------------------------------------------------------------------------------
-template <int PITCH, int NTM, bool ALIAS>
-__global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom G) {
+template <int PITCH, int NTM, bool ALIAS, int DKS>
+__global__ __launch_bounds__(ALIAS ? 128 : 256) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom G) {
+  constexpr int NWS = ALIAS ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* Ks = sm + G.offK; char* Vs = sm + G.offV; char* Es = sm + G.offE; char* Qs = sm + G.offQ; char* Gs = Qs + 64 * PITCH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5, il = lane & 31;
@@ -336,16 +376,17 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
     const int wv = __builtin_amdgcn_readfirstlane(w);
     const long long lastq = (long long)(a.B - 1 - b) * Tn + Tn - 1;
     const int rb = (a.H - h) * d * 2;
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
-    if (!ALIAS) stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
-    stage_rows_dma<PITCH, 2>(lds0 + (unsigned)G.offQ + 64 * PITCH, Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offK, Ks, kp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    if (!ALIAS) stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offV, Vs, vp, a.ld, 0, G.Tp, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offQ, Qs, qp, a.ld, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offQ + 64 * PITCH, Gs, gp, a.ldo, i0, 64, Tn, d, G.dpad, lastq, rb, wv, lane);
+    stage_rows_dma<PITCH, NWS>(lds0 + (unsigned)G.offE, Es, ep, a.lde, (Tn - 1) - (i0 + 63), G.NE, 2 * Tn - 1, d, G.dpad, 2 * Tn - 2, rb, wv, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    zero_pad_channels<PITCH, 2>(Qs, 64, d, G.dpad, wv, lane);
-    zero_pad_channels<PITCH, 2>(Gs, 64, d, G.dpad, wv, lane);
+    zero_pad_channels<PITCH, NWS>(Qs, 64, d, G.dpad, wv, lane);
+    zero_pad_channels<PITCH, NWS>(Gs, 64, d, G.dpad, wv, lane);
   }
   __syncthreads();
+  if (NWS > 2 && w >= 2) return;                          // the staging helpers are done
 #if AVEC_ATTN_ABL == 1
   if (sm[tid * 16] == 123) a.lse[0] = 1.f;
   return;
@@ -370,7 +411,7 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
   delta += __shfl_xor(delta, 32, 64);
 
   f32x16 S[NTM];
-  scores<PITCH, NTM>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
+  scores<PITCH, NTM, DKS>(S, Ks, Es, qrow, ring, G, a.scale, w, il, hf, Tn, klen, row_masked);
 #if AVEC_ATTN_ABL == 2
   if (S[0][0] + S[1][3] + delta == 1234.5f) a.lse[0] = 1.f;
   return;
@@ -387,7 +428,8 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
 #pragma unroll
       for (int r = 0; r < 16; ++r) dP[r] = 0.f;
       const char* vrow = Vs + (32 * jt + il) * PITCH;
-      for (int kk = 0; kk < G.DKS; ++kk) {
+#pragma unroll
+      for (int kk = 0; kk < (DKS ? DKS : G.DKS); ++kk) {
         const chunk16 fa = *(const chunk16*)(vrow + (((2 * kk + hf) ^ swr) << 4));
         const chunk16 fb = *(const chunk16*)(grow + (((2 * kk + hf) ^ swr) << 4));
         dP = mma(fa, fb, dP);
@@ -484,11 +526,11 @@ __global__ __launch_bounds__(128) void attn_mfma_bwd_kernel(AttnArgs a, MfmaGeom
 static const bool g_mfma_off = getenv("AVEC_NO_MFMA_ATTN") != nullptr;
 
 template <typename K> static int mfma_set_lds(K kern, size_t bytes) {
-  static const void* done[8]; static size_t done_bytes[8]; static int ndone = 0;
+  static const void* done[40]; static size_t done_bytes[40]; static int ndone = 0;
   for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern && done_bytes[i] >= bytes) return 0;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
   if (e != hipSuccess) { avec_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-  if (ndone < 8) { done[ndone] = (const void*)kern; done_bytes[ndone] = 160 * 1024; ++ndone; }
+  if (ndone < 40) { done[ndone] = (const void*)kern; done_bytes[ndone] = 160 * 1024; ++ndone; }
   return 0;
 }
 
@@ -498,11 +540,14 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   const MfmaGeom G = mfma_geom(a.T, a.d, pitch, false);
   if (G.total > 160 * 1024) return 1;
   dim3 grid((a.T + 63) / 64, a.B * a.H);
-#define AVEC_LAUNCH_ATTN(KERNEL) do { if (int r = mfma_set_lds(KERNEL, G.total)) return r; hipLaunchKernelGGL(KERNEL, grid, dim3(128), G.total, st, a, G); } while (0)
+#define AVEC_LAUNCH_ATTN(KERNEL) do { if (int r = mfma_set_lds(KERNEL, G.total)) return r; hipLaunchKernelGGL(KERNEL, grid, dim3(G.alias ? 128 : 256), G.total, st, a, G); } while (0)
+#define AVEC_PICK_DKS(NAME, N, A) do { \
+    if (pitch == 128) { if (G.DKS == 4) AVEC_LAUNCH_ATTN((NAME<128, N, A, 4>)); else if (G.DKS == 3) AVEC_LAUNCH_ATTN((NAME<128, N, A, 3>)); else AVEC_LAUNCH_ATTN((NAME<128, N, A, 0>)); } \
+    else { if (G.DKS == 6) AVEC_LAUNCH_ATTN((NAME<256, N, A, 6>)); else AVEC_LAUNCH_ATTN((NAME<256, N, A, 0>)); } } while (0)
 #define AVEC_PICK_ATTN(NAME) do { \
-    if (a.T <= 224 && !G.alias) { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 7, false>)); else AVEC_LAUNCH_ATTN((NAME<256, 7, false>)); } \
-    else if (!G.alias) { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 12, false>)); else AVEC_LAUNCH_ATTN((NAME<256, 12, false>)); } \
-    else { if (pitch == 128) AVEC_LAUNCH_ATTN((NAME<128, 12, true>)); else AVEC_LAUNCH_ATTN((NAME<256, 12, true>)); } } while (0)
+    if (a.T <= 224 && !G.alias) AVEC_PICK_DKS(NAME, 7, false); \
+    else if (!G.alias) AVEC_PICK_DKS(NAME, 12, false); \
+    else AVEC_PICK_DKS(NAME, 12, true); } while (0)
   AVEC_PICK_ATTN(attn_mfma_fwd_kernel);
   AVEC_LAUNCH_CHECK(); return 0;
 }
@@ -515,6 +560,7 @@ int attn_mfma_bwd_rows(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.T + 63) / 64, a.B * a.H);
   AVEC_PICK_ATTN(attn_mfma_bwd_kernel);
 #undef AVEC_PICK_ATTN
+#undef AVEC_PICK_DKS
 #undef AVEC_LAUNCH_ATTN
   AVEC_LAUNCH_CHECK(); return 0;
 }
