@@ -92,6 +92,21 @@ __device__ __forceinline__ void stage_rows_dma(unsigned lds_img, char* img, cons
   const unsigned ldb = (unsigned)ld * 2u;
   const bool can_past = dpad * 2 > rowbytes && last_row <= (long long)limit - 1;      // (uniform) the last row of the TENSOR is among the rows, and its padded width overhangs
   const int lastr = can_past ? (int)last_row : -1;
+  // the overhanging chunk of the tensor's LAST row (clamped copies of that row are never used: they get the zero chunk and keep it): its elements are requested
+  // here, in front of the DMAs, and stored behind them -- no memory round trip of their own (they cost the last head's workgroups 2.5 us when d % 8 != 0)
+  unsigned short pe[8]; int pk = -1, pn = 0; unsigned pc = 0;
+  if (can_past) {
+    const int rt = lastr - row0;
+    if (rt >= 0 && rt < nrows && (rt / RPI) % NW == wave && rt % RPI == rg) {
+      int c = pos ^ aswz<PITCH>(rt);
+      if (c < CH && c * 16 + 16 > rowbytes) {
+        pk = rt / RPI; pc = (unsigned)c * 16u; pn = (rowbytes - c * 16) >> 1; pn = pn < 0 ? 0 : pn;
+        const unsigned short* q = (const unsigned short*)((const char*)src + ((unsigned)lastr * ldb + pc));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pe[e] = e < pn ? q[e] : (unsigned short)0;
+      }
+    }
+  }
   // this wave's instructions are k = wave + j NW; the v-th of every NV consecutive ones has the swizzle of row RPI (wave + v NW) + rg
   unsigned coff[NV]; bool cpast[NV];
 #pragma unroll
@@ -111,20 +126,12 @@ __device__ __forceinline__ void stage_rows_dma(unsigned lds_img, char* img, cons
       }
     }
   }
-  if (can_past) {      // the overhanging chunk(s) of the tensor's last row: zero chunk above, its elements here
+  if (can_past && __builtin_amdgcn_readfirstlane(__any(pk >= 0) ? 1 : 0)) {      // (one wave of the last head's workgroups)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int k0 = wave; k0 < ninstr; k0 += NW * NV) {
+    if (pk >= 0) {
+      unsigned short* dst = (unsigned short*)(img + pk * 1024 + lane * 16);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int k = k0 + v * NW;
-        if (k >= ninstr) break;
-        int gr = row0 + k * RPI + rg; gr = gr < 0 ? 0 : (gr >= limit ? limit - 1 : gr);
-        if (gr == lastr && cpast[v]) {
-          const bf16* p = (const bf16*)((const char*)src + ((unsigned)gr * ldb + coff[v]));
-          bf16* dst = (bf16*)(img + k * 1024 + lane * 16);
-          for (int e = 0; e < 8; ++e) if ((int)coff[v] + 2 * e + 2 <= rowbytes) dst[e] = p[e];
-        }
-      }
+      for (int e = 0; e < 8; ++e) if (e < pn) dst[e] = pe[e];
     }
   }
 }
