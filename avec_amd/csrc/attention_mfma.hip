@@ -460,8 +460,13 @@ __global__ __launch_bounds__(ALIAS ? 128 : 256) void attn_mfma_bwd_kernel(AttnAr
             for (int e = 0; e < 4; ++e) if (j0 + e < Tn) { prow[j0 + e].v = f32_to_bf16(pv[e]); srow[j0 + e].v = f32_to_bf16(dv[e]); }
           }
           if (rrow) {
+            // (the skewed row starts at an odd element in every other row: an 8-byte store at a 2-byte-aligned address, like the dword stores of store_rows_T)
+            typedef uint2 __attribute__((aligned(2))) u64_u;
+            if (j0 + 3 < Tn) { uint2 ud; ud.x = pack2(dv[0], dv[1]); ud.y = pack2(dv[2], dv[3]); *(u64_u*)(rrow + j0) = ud; }
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (j0 + e < Tn) rrow[j0 + e].v = f32_to_bf16(dv[e]);
+              for (int e = 0; e < 4; ++e) if (j0 + e < Tn) rrow[j0 + e].v = f32_to_bf16(dv[e]);
+            }
           }
         }
       }
