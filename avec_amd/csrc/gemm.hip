@@ -908,10 +908,13 @@ __device__ __forceinline__ void glds16_v64(const void* gsrc, unsigned lds_dst_un
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
-template <int BM, int BN>
+// STAGES = 4: all of K <= 256 in flight, two workgroups per CU (64 KB).  STAGES = 2 (AVEC_NT_S2): 32 KB, four workgroups per CU -- for products whose 64 x 64 tiling
+// exceeds the 512 slots of the deep ring (3200 x 1024 x 256: 800 tiles) one round of workgroups that hide each other's DMA latency instead of two rounds.
+template <int BM, int BN, int STAGES = 4>
 __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
   typedef bf16 T;
-  constexpr int RB = 128, KE = 64, STAGES = 4;
+  constexpr int RB = 128, KE = 64;
+  static_assert(STAGES == 2 || STAGES == 4, "ring of 2 or 4 K tiles");
   constexpr int NCA = BM / 32, NCB = BN / 32, LPT = NCA + NCB;         // DMA passes (32 rows x 128 B) per tile
   constexpr int MT = BM / 64, NT = BN / 64, KK = 4;                    // K-substeps of 16 per tile
   constexpr int TILE = (BM + BN) * RB;
@@ -982,12 +985,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
 
 #define AVEC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
   issue(0, IntC<0>{});
-  if (KT > 1) issue(1, IntC<1>{});
-  if (KT > 2) issue(2, IntC<2>{});
+  if (STAGES > 2 && KT > 1) issue(1, IntC<1 % STAGES>{});
+  if (STAGES > 2 && KT > 2) issue(2, IntC<2 % STAGES>{});
   auto step = [&](const int kt, auto stagec) {
     constexpr int S = decltype(stagec)::value;
-    const int rem = KT - 1 - kt;                                     // tiles issued after kt: min(rem, 2) may still be in flight
-    if (rem >= 2) AVEC_WAIT_VM(2 * LPT); else if (rem == 1) AVEC_WAIT_VM(LPT); else AVEC_WAIT_VM(0);
+    const int rem = KT - 1 - kt;                                     // tiles issued after kt: min(rem, STAGES - 2) may still be in flight
+    if (STAGES > 2 && rem >= 2) AVEC_WAIT_VM(2 * LPT); else if (STAGES > 2 && rem == 1) AVEC_WAIT_VM(LPT); else AVEC_WAIT_VM(0);
     if (!(AVEC_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ktail && kt == KT - 1) {                                     // (workgroup-uniform; nothing is in flight: vmcnt(0) above)
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
       if (MT > 1) fa[q][1 % MT] = lds_read128o<(S & 1) * TILE + 4096>(aad[S >> 1][q]);
       fb[q] = lds_read128o<(S & 1) * TILE>(bad[S >> 1][q]);
     }
-    if (kt + 3 < KT) issue(kt + 3, IntC<(S + 3) % STAGES>{});        // into the slot everybody finished reading before this barrier
+    if (kt + STAGES - 1 < KT) issue(kt + STAGES - 1, IntC<(S + STAGES - 1) % STAGES>{});        // into the slot everybody finished reading before this barrier
 #pragma unroll
     for (int q = 0; q < KK; ++q) {
       if (q == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * (MT + 1)) : "memory");
@@ -1029,8 +1032,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
   for (int kt = 0; kt < KT; kt += STAGES) {
     step(kt, IntC<0>{});
     if (kt + 1 < KT) step(kt + 1, IntC<1>{});
-    if (kt + 2 < KT) step(kt + 2, IntC<2>{});
-    if (kt + 3 < KT) step(kt + 3, IntC<3>{});
+    if (STAGES > 2 && kt + 2 < KT) step(kt + 2, IntC<2 % STAGES>{});
+    if (STAGES > 2 && kt + 3 < KT) step(kt + 3, IntC<3 % STAGES>{});
   }
 #undef AVEC_WAIT_VM
   __syncthreads();                            // every wave is done with the ring before the epilogue reuses the LDS
@@ -1747,6 +1750,15 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
     static const bool no_lean_tail = getenv("AVEC_NO_LEAN_KTAIL") != nullptr;
     if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && (g.K % 8 == 0 || (g.ktail && !no_lean_tail)) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
         arows * g.a.ld * 2 < (1ll << 32) && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
+      // two-stage ring for products with more than 512 tiles (the slots of the deep ring) and at most 6 K tiles: 3200 x 1024 x 256 + Swish 10.4 -> 8.2 us,
+      // 3200 x 768 x 256 8.9 -> 6.4 us, 1600 x 1440 x 360 11.7 -> 9.4 us; step 19.31 -> 19.18 ms (tools/gpu/r4_s2.sh; with 256: no further gain).  AVEC_NT_S2=0: off
+      static const int s2_min = getenv("AVEC_NT_S2") ? atoi(getenv("AVEC_NT_S2")) : 512;
+      if (s2_min > 0 && (long long)grid.x * grid.y > s2_min && !g.ktail && g.K <= 384) {
+        const size_t l2s = (size_t)2 * (BM + BN) * 128 > epi_lds ? (size_t)2 * (BM + BN) * 128 : epi_lds;
+        avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2>", BM, BN);
+        if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2>, l2s)) return r;
+        hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g); return 0;
+      }
       const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
       avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
