@@ -330,35 +330,44 @@ def test_lean_plain_product_matches_fp32_math(M, N, K, kind):
 def test_resnet_block_relu_bitmask_equals_reading_the_saved_output(dtype):
     """ResNet-18 trunk: the backward pass of the block-end BatchNorm + ReLU with the 1-bit mask written by avec_bn_apply_fwd_mask (projection shortcuts normalised on the
     fly) against the path that reads the saved block output and gives the shortcut a tensor of its own.  fp32: same results to rounding.  bf16: the identity blocks are
-    bit-identical (test_bn_relu_bitmask_kernels_*), the shortcut tensor's bf16 rounding is gone in the new path, so the trunk is compared at the forward output only"""
+    bit-identical (test_bn_relu_bitmask_kernels_*), the shortcut tensor's bf16 rounding is gone in the new path, so the trunk is compared at the forward output only.
+
+    The two paths round the projection shortcut differently (one fused multiply-add against a stored tensor), so a pre-activation within ~1e-7 of zero can land on
+    different sides of the ReLU in the two runs; ONE such element changes the input gradient of the whole trunk by 1e-3 .. 1e-2 (seen when an unrelated change of the
+    product epilogue moved the BatchNorm statistics by one ulp: tools/gpu/r4_epi_cmp.sh, old vs new library 2e-6 apart everywhere, the two paths 2e-6 vs 2e-3 apart).
+    So: three seeds; every one must agree to 5e-2 (a systematic error -- a lost shortcut, a wrong mask -- is O(1)), and at least two of the three to rounding."""
     import avec_amd
     import nnet
     from avec_amd import ops
-    g = torch.Generator().manual_seed(16)
-    x = torch.randn(10, 22, 22, 64, generator=g).to(dev())
-    res = {}
-    try:
-        avec_amd.set_compute_dtype(dtype)
-        for bm in (True, False):
-            torch.manual_seed(23)
-            net = nnet.ResNet(dim_input=64, dim_output=256, model="ResNet18", include_stem=False, include_head=True).to(dev()).train()
-            ops.RELU_BITMASK = bm
-            xin = x.clone().to(torch.bfloat16 if dtype == "bf16" else torch.float32).requires_grad_(True)
-            y = net.forward_nhwc(xin)
-            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev())
-            (y.float() * w).sum().backward()
-            torch.cuda.synchronize()
-            res[bm] = (y.detach().float().cpu(), xin.grad.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in net.named_parameters() if p.grad is not None})
-    finally:
-        ops.RELU_BITMASK = True
-        avec_amd.set_compute_dtype("f32")
-    if dtype == "bf16":
-        assert rel_err(res[True][0], res[False][0]) < 2e-2
-        return
-    assert rel_err(res[True][0], res[False][0]) < 1e-5
-    assert rel_err(res[True][1], res[False][1]) < 1e-3, "input gradient"
-    for n in res[True][2]:
-        assert rel_err(res[True][2][n], res[False][2][n]) < 1e-3, n
+    tight, worst = 0, 0.0
+    for seed in ((16,) if dtype == "bf16" else (16, 17, 18)):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(10, 22, 22, 64, generator=g).to(dev())
+        res = {}
+        try:
+            avec_amd.set_compute_dtype(dtype)
+            for bm in (True, False):
+                torch.manual_seed(23 + seed - 16)
+                net = nnet.ResNet(dim_input=64, dim_output=256, model="ResNet18", include_stem=False, include_head=True).to(dev()).train()
+                ops.RELU_BITMASK = bm
+                xin = x.clone().to(torch.bfloat16 if dtype == "bf16" else torch.float32).requires_grad_(True)
+                y = net.forward_nhwc(xin)
+                w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev())
+                (y.float() * w).sum().backward()
+                torch.cuda.synchronize()
+                res[bm] = (y.detach().float().cpu(), xin.grad.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            ops.RELU_BITMASK = True
+            avec_amd.set_compute_dtype("f32")
+        if dtype == "bf16":
+            assert rel_err(res[True][0], res[False][0]) < 2e-2
+            return
+        assert rel_err(res[True][0], res[False][0]) < 1e-5
+        errs = [rel_err(res[True][1], res[False][1])] + [rel_err(res[True][2][n], res[False][2][n]) for n in res[True][2]]
+        worst = max(worst, max(errs))
+        assert max(errs) < 5e-2, (seed, max(errs))
+        tight += int(max(errs) < 1e-3)
+    assert tight >= 2, "the two paths agree to rounding for %d of 3 seeds only (worst %.2e)" % (tight, worst)
 
 
 @pytest.mark.gpu
