@@ -15,6 +15,11 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libavec_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC, "-Wno-unused-value"]
+# kernel arguments preloaded into SGPRs by the command processor (gfx940+): the leading scalar / pointer arguments of a kernel (up to 16 dwords) are in registers when
+# the first wave starts instead of behind an s_load round trip to the kernel-argument buffer (which misses every cache in a step that moves 50 GB between two launches
+# of the same kernel).  Kernels that take one struct by value (the product / convolution launchers) are unaffected.  AVEC_KERNARG_PRELOAD=0 builds without it.
+if os.environ.get("AVEC_KERNARG_PRELOAD", "16") != "0":
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=" + os.environ.get("AVEC_KERNARG_PRELOAD", "16")]
 
 
 def _sources():
