@@ -911,7 +911,10 @@ __device__ __forceinline__ void glds16_v64(const void* gsrc, unsigned lds_dst_un
 // STAGES = 4: all of K <= 256 in flight, two workgroups per CU (64 KB).  STAGES = 2 (AVEC_NT_S2): 32 KB, four workgroups per CU -- for products whose 64 x 64 tiling
 // exceeds the 512 slots of the deep ring (3200 x 1024 x 256: 800 tiles) one round of workgroups that hide each other's DMA latency instead of two rounds.
 template <int BM, int BN, int STAGES = 4>
-__global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_ptr, const void* pa_w, long long pa_lda, long long pa_ldw, long long pa_M, int pa_N, int pa_K, int pa_ktail, GemmArgs g_unused) {
+  // The leading arguments repeat the fields of `g` that the operand DMAs need (13 dwords): with the kernel-argument preload of the build they are in SGPRs when the
+  // first wave starts, and the first tiles go out without waiting for the ~400-byte argument block (that block misses every cache between two
+  // launches of the same kernel; where it lives is worth 1 us per launch).  Everything else is read from `g` as before.
   typedef bf16 T;
   constexpr int RB = 128, KE = 64;
   static_assert(STAGES == 2 || STAGES == 4, "ring of 2 or 4 K tiles");
@@ -925,30 +928,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
   const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem, wslot = (unsigned)wave * 1024u;
-  const int K = g.K, KT = (K + KE - 1) / KE, KF = K / KE;
+  const int K = pa_K, KT = (K + KE - 1) / KE, KF = K / KE;
   // DMA plan: pass i, thread tid -> tile row tid/8 + 32 i, physical slot tid%8 carrying logical K-chunk (tid%8) ^ swz(row)
   unsigned aoff[NCA], boff[NCB]; int kca, kcb[NCB];
   unsigned lastrow = 0;                                              // bit i / bit 8 + i: DMA pass i of A / W fetches the LAST row of its matrix (K = 8n + 4 only, see below)
   kca = 0;
 #pragma unroll
   for (int i = 0; i < NCA; ++i) {
-    const int row = (tid >> 3) + i * 32; const long long m = m0 + row < g.M ? m0 + row : g.M - 1;
+    const int row = (tid >> 3) + i * 32; const long long m = m0 + row < pa_M ? m0 + row : pa_M - 1;
     const int kc = (tid & 7) ^ glds_swz<RB>(row);
-    aoff[i] = (unsigned)((row_info<MODE_PLAIN>(g.a, m, g.M).base + kc * 8) * 2);
+    aoff[i] = (unsigned)((m * pa_lda + kc * 8) * 2);                 // (plain rows only: strided row maps take the general kernel)
     if (i == 0) kca = kc;                                            // (rows 32 apart share the swizzle)
-    if (m == g.M - 1) lastrow |= 1u << i;
+    if (m == pa_M - 1) lastrow |= 1u << i;
   }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
-    const int row = (tid >> 3) + i * 32; const int n = n0 + row < g.N ? n0 + row : g.N - 1;
+    const int row = (tid >> 3) + i * 32; const int n = n0 + row < pa_N ? n0 + row : pa_N - 1;
     kcb[i] = (tid & 7) ^ glds_swz<RB>(row);
-    boff[i] = (unsigned)(((long long)n * g.ldw + kcb[i] * 8) * 2);
-    if (n == g.N - 1) lastrow |= 256u << i;
+    boff[i] = (unsigned)(((long long)n * pa_ldw + kcb[i] * 8) * 2);
+    if (n == pa_N - 1) lastrow |= 256u << i;
   }
   // K = 8n + 4 (the 180- / 540-wide audio stage): the chunk that holds elements K-4 .. K-1 also holds 4 elements of the next row -- zeroed in LDS once the last tile has
   // landed (step()); the last row of a matrix fetches that chunk 8 bytes early (nothing is read behind the matrix) and its upper half is moved down first
-  const bool ktail = g.ktail != 0;
-  const char* const Ab = (const char*)g.a.ptr; const char* const Wb = (const char*)g.W;
+  const bool ktail = pa_ktail != 0;
+  const char* const Ab = (const char*)pa_ptr; const char* const Wb = (const char*)pa_w;
   auto issue = [&](const int kt, auto stagec) {
     constexpr int S = decltype(stagec)::value;
     if (AVEC_ABL & 2) return;
@@ -987,6 +990,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(GemmArgs g) {
   issue(0, IntC<0>{});
   if (STAGES > 2 && KT > 1) issue(1, IntC<1 % STAGES>{});
   if (STAGES > 2 && KT > 2) issue(2, IntC<2 % STAGES>{});
+  // the argument block itself is read only now, through a pointer the compiler cannot see through: its scalar loads (and the wait for them, which the register
+  // allocator otherwise drags to the top of the kernel with an SGPR spill) stay behind the DMAs above
+  struct PlainKA { const void* a; const void* w; long long lda, ldw, M; int N, K, ktail; GemmArgs g; };
+  typedef const __attribute__((address_space(4))) char* kseg_t;
+  typedef const __attribute__((address_space(4))) GemmArgs* kgp_t;
+  kgp_t gp = (kgp_t)((kseg_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PlainKA, g));
+  asm volatile("" : "+s"(gp));
+  { const unsigned long long u = (unsigned long long)(uintptr_t)gp;      // (an asm output counts as divergent: say it is uniform, or the block is read by vector loads)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    gp = (kgp_t)(uintptr_t)(((unsigned long long)hi << 32) | lo); }
+  GemmArgs g;
+  { static_assert(sizeof(GemmArgs) % 8 == 0, "copied as 64-bit words");
+    typedef const __attribute__((address_space(4))) unsigned long long* kq_t;
+    const kq_t q = (kq_t)gp; unsigned long long buf[sizeof(GemmArgs) / 8];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(GemmArgs) / 8); ++i) buf[i] = q[i];      // constant address space + uniform pointer: scalar loads
+    __builtin_memcpy(&g, buf, sizeof(GemmArgs)); }
   auto step = [&](const int kt, auto stagec) {
     constexpr int S = decltype(stagec)::value;
     const int rem = KT - 1 - kt;                                     // tiles issued after kt: min(rem, STAGES - 2) may still be in flight
@@ -1748,7 +1768,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
     // the lean plain kernel: whole 16-byte K-chunks, 32-bit byte offsets into both operands
     const long long arows = g.a.step > 1 ? (g.M / (g.a.rows_out > 0 ? g.a.rows_out : 1) + 1) * (long long)g.a.rows_in : g.M;
     static const bool no_lean_tail = getenv("AVEC_NO_LEAN_KTAIL") != nullptr;
-    if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && (g.K % 8 == 0 || (g.ktail && !no_lean_tail)) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
+    if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && g.a.step <= 1 && (g.K % 8 == 0 || (g.ktail && !no_lean_tail)) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
         arows * g.a.ld * 2 < (1ll << 32) && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
       // two-stage ring for products with more than 512 tiles (the slots of the deep ring) and at most 6 K tiles: 3200 x 1024 x 256 + Swish 10.4 -> 8.2 us,
       // 3200 x 768 x 256 8.9 -> 6.4 us, 1600 x 1440 x 360 11.7 -> 9.4 us; step 19.31 -> 19.18 ms (tools/gpu/r4_s2.sh; with 256: no further gain).  AVEC_NT_S2=0: off
@@ -1757,12 +1777,12 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
         const size_t l2s = (size_t)2 * (BM + BN) * 128 > epi_lds ? (size_t)2 * (BM + BN) * 128 : epi_lds;
         avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2>", BM, BN);
         if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2>, l2s)) return r;
-        hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g); return 0;
+        hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
       }
       const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
       avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
-      hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g); return 0;
+      hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
     }
   }
   if constexpr (sizeof(T) == 2 && BM == 128 && (BN == 128 || BN == 64)) {
