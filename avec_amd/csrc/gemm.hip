@@ -1780,7 +1780,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
         hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
       }
       const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
-      avec_note_kernel("gemm_nt_plain_kernel<%d,%d>", BM, BN);
+      avec_note_kernel("gemm_nt_plain_kernel<%d,%d,4>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
       hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
     }
