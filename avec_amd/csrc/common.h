@@ -84,8 +84,10 @@ __device__ __forceinline__ DropKey drop_key(const unsigned long long* rng, uint3
   if (p > 0.f) {
     const uint64_t seed = rng[0] + 0x9e3779b97f4a7c15ull * rng[1];
     k.k0 = mix32((uint32_t)seed + stream * 0x9e3779b9u) ^ mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu);
-    const float t = p * 65536.f + 0.5f; k.thr = t >= 65535.f ? 65535u : (uint32_t)t;
-    k.scale = 1.f / (1.f - p);
+    // p is resolved to thr / 65536 and the scale follows the QUANTISED probability (E[mask * scale] = 1 exactly); p >= 1 drops everything with scale 0 like torch
+    // (thr = 65536 is above every 16-bit hash value) instead of letting the 1 / 65536 survivors through at 1 / (1 - p) = inf
+    const float t = p * 65536.f + 0.5f; k.thr = t >= 65536.f ? 65536u : (uint32_t)t;
+    k.scale = k.thr >= 65536u ? 0.f : 65536.f / (float)(65536u - k.thr);
   }
   return k;
 }

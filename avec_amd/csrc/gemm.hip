@@ -23,6 +23,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #ifndef AVEC_ABL
 #define AVEC_ABL 0
 #endif
+#ifndef AVEC_NT_XCD
+#define AVEC_NT_XCD 1
+#endif
 
 static constexpr int BKB = 128;      // bytes of K per LDS tile row
 static constexpr int LDS_ROW = 144;  // padded LDS row stride in bytes
@@ -415,6 +418,124 @@ __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT]
   }
 }
 
+
+// ---- register-direct epilogue for TRANSPOSED accumulators (round 5) ----
+// The staged epilogue above is 25-40 % of the shifted-window convolution's time (ablation, profiles/r05_shift_epilogue.txt: 43 / 76 of 140 / 189 us forward /
+// backward-data on the 128-channel stage): four passes of accumulators -> LDS -> barrier -> rolled row loop (with a dependent residual load per iteration) -> barrier.
+// Here the product is computed transposed (weights as the MFMA A operand, pixels as B): acc[i][j] is D^T of the 32 x 32 block, a lane owns ONE pixel (lane & 31 of
+// row block i) and the channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column block j.  Four consecutive channels pack into 8 bytes; v_permlane32_swap trades the
+// odd group of the lower half-wave for the even group of the upper one (csrc/conv3x3.hip does the same), after which a lane holds 8 consecutive channels: 16-byte
+// NHWC pieces straight from the registers -- no LDS staging, no barrier, every residual piece requested before the first store.  The residual gradient is added
+// in fp32 before the single rounding (its 16-byte pieces are swapped back to the accumulator layout first: the swap is an involution).  BatchNorm statistics:
+// per-register partial sums over the wave's row blocks, reduce-scatter over the half-wave's pixels (v_permlane16_swap for lane ^ 16, then rotations inside the
+// 16-lane rows), waves combined through LDS, one atomic per column per workgroup like the staged epilogue.
+typedef float f32x2_e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap_pair32(uint2& x, uint2& y) {
+  auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false); x.x = r0[0]; y.x = r0[1];
+  auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false); x.y = r1[0]; y.y = r1[1];
+}
+__device__ __forceinline__ float row_rot_add(float v) {       // sum over the 16 lanes of a row (every lane gets the total): rotations by 8, 4, 2, 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));     // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));     // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));     // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));     // row_ror:1
+  return v;
+}
+// row[i] / valid[i]: output row of this lane's pixel in row block i (clamped into the tensor when invalid); rrow[i]: its row in the residual tensor (`res` non-null);
+// full: (workgroup-uniform) every row of the tile is valid -- the statistics then need no per-row mask
+template <int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_tr(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, const long long (&row)[MT], const bool (&valid)[MT], const bf16* res,
+                                                 const long long (&rrow)[MT], const bool full, int n0, int tid, int lane, int wm, int wn) {
+  const Epi& e = g.e;
+  const int h = lane >> 5;
+  bf16* const out = (bf16*)e.out;
+  const float alpha = e.alpha;
+  float ssum[NT][16], ssq[NT][16];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cb = n0 + wn * (BN / 2) + j * 32 + h * 8;          // this lane's 8-channel piece of 16-channel block k: cb + 16 k
+    uint4 rp[MT][2];
+    if (res) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rp[i][k] = *(const uint4*)(res + rrow[i] * e.ldres + cb + 16 * k);
+    }
+    if (e.stats) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; ssum[j][r] += v; ssq[j][r] += v * v; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = valid[i] ? acc[i][j][r] : 0.f; ssum[j][r] += v; ssq[j][r] += v * v; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      uint2 G[4];
+      if (res) {
+        uint2 R[4] = {make_uint2(rp[i][0].x, rp[i][0].y), make_uint2(rp[i][0].z, rp[i][0].w), make_uint2(rp[i][1].x, rp[i][1].y), make_uint2(rp[i][1].z, rp[i][1].w)};
+        swap_pair32(R[0], R[1]); swap_pair32(R[2], R[3]);       // stored layout -> accumulator layout
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v0 = acc[i][j][4 * q] * alpha + __uint_as_float(R[q].x << 16), v1 = acc[i][j][4 * q + 1] * alpha + __uint_as_float(R[q].x & 0xffff0000u);
+          const float v2 = acc[i][j][4 * q + 2] * alpha + __uint_as_float(R[q].y << 16), v3 = acc[i][j][4 * q + 3] * alpha + __uint_as_float(R[q].y & 0xffff0000u);
+          G[q].x = f32x2_to_bf16x2(v0, v1); G[q].y = f32x2_to_bf16x2(v2, v3);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          G[q].x = f32x2_to_bf16x2(acc[i][j][4 * q] * alpha, acc[i][j][4 * q + 1] * alpha); G[q].y = f32x2_to_bf16x2(acc[i][j][4 * q + 2] * alpha, acc[i][j][4 * q + 3] * alpha);
+        }
+      }
+      swap_pair32(G[0], G[1]); swap_pair32(G[2], G[3]);
+      if (valid[i]) {
+        *(uint4*)(out + row[i] * e.ldo + cb) = make_uint4(G[0].x, G[0].y, G[1].x, G[1].y);
+        *(uint4*)(out + row[i] * e.ldo + cb + 16) = make_uint4(G[2].x, G[2].y, G[3].x, G[3].y);
+      }
+    }
+  }
+  if (e.stats) {
+    // reduce-scatter over the 32 pixels of the half-wave: lane ^ 16 by v_permlane16_swap (registers r and r + 8 trade rows: even rows end with the sums of register r,
+    // odd rows with those of r + 8, each over two rows), then the 16 lanes of a row by rotations
+    float* red = (float*)smem;                 // [wm][sum | sq][BN] partials, then [2][BN] totals (the ring is dead: the K loop ended with a barrier)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float (&v)[16] = t ? ssq[j] : ssum[j];
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 8]), false, false);
+          w[r] = row_rot_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+        }
+        if ((lane & 15) == 0) {
+          const int odd = (lane >> 4) & 1;       // odd rows hold registers 8 .. 15
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int R = r + 8 * odd, ch = wn * (BN / 2) + j * 32 + (R & 3) + 8 * (R >> 2) + 4 * h;
+            red[(wm * 2 + t) * BN + ch] = w[r];
+          }
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int t = tid / BN, c = tid % BN;
+      if (n0 + c < g.N) {
+        float* rep = e.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 2 * g.N;
+        atomicAdd(rep + t * g.N + n0 + c, red[(0 * 2 + t) * BN + c] + red[(1 * 2 + t) * BN + c]);
+      }
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int MODE, bool SRC_F32, bool A16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
@@ -747,7 +868,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 // fragment offsets are compile-time, every ds_read_b128 takes one of 18 + 2 precomputed addresses plus an immediate, the DMA sources are a scalar base + a
 // per-lane 32-bit offset fixed at entry, one M0 save / restore per DMA group.  Rows outside the tensor are clamped instead of redirected to a zero page: every tap
 // that could read them is masked (it lies outside its image), and tile rows / columns beyond M / N are never stored.
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, bool TR = false>      // TR: transposed product (weights as the MFMA A operand) + register-direct epilogue (conv_epilogue_tr)
 __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   typedef bf16 T;
   constexpr int RB = 64, KE = 32, STAGES = 3;
@@ -876,7 +997,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           if (AVEC_ABL & 1) asm volatile("" :: "v"(fa[q][i]), "v"(fb[q][j])); else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
+          if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[q][j]), __builtin_bit_cast(bf16x8_t, fa[q][i]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);          // (keeps this group's MFMAs above the next group's wait)
     }
@@ -892,7 +1014,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   }
 #undef AVEC_WAIT_VM
   __syncthreads();
-  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
+  if (TR) {
+    long long row[MT]; bool valid[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { row[i] = m0 + wm * (BM / 2) + i * 32 + (lane & 31); valid[i] = row[i] < g.M; if (!valid[i]) row[i] = g.M - 1; }
+    conv_epilogue_tr<BM, BN, MT, NT>(g, acc, smem, row, valid, (const bf16*)g.e.res, row, m0 + BM <= g.M, n0, tid, lane, wm, wn);
+  } else nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
 
@@ -925,7 +1052,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_pt
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: workgroup ids go round-robin to the 8 XCDs (each with its own L2), so in launch order every XCD pulls ALL of A and W (PMC: 3.4x the
+  // algorithmic bytes per launch).  XCD x takes a contiguous range of logical ids, column tile fastest: the tiles of one row block share their A rows in ONE L2.
+#if AVEC_NT_XCD
+  const int lid = xcd_logical((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const long long m0 = (long long)(lid / (int)gridDim.y) * BM; const int n0 = (lid % (int)gridDim.y) * BN;
+#else
   const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+#endif
   typedef __attribute__((address_space(3))) void* lptr_t;
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem, wslot = (unsigned)wave * 1024u;
   const int K = pa_K, KT = (K + KE - 1) / KE, KF = K / KE;
@@ -1067,7 +1201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_pt
 // tap's scalar offset, redirected to the zero page where the tap leaves the image).  The stride-2 and 1x1 layers of the ResNet (the general kernel spends ~110
 // instructions per K-step of 8 MFMAs on them).  Host-checked like the fast path of gemm_nt_glds_kernel (fast_conv); same LDS image, swizzle and epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int BN, int MODE>
+template <int BN, int MODE, bool TR = false>      // TR: transposed product + register-direct epilogue, as in conv3x3_shift_kernel
 __global__ __launch_bounds__(256, 2) void gemm_nt_conv_lean_kernel(GemmArgs g) {
   typedef bf16 T;
   constexpr int BM = 128, RB = 64, KE = 32, STAGES = 3, CPR = 4;
@@ -1184,7 +1318,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_conv_lean_kernel(GemmArgs g) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
+          if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[q][j]), __builtin_bit_cast(bf16x8_t, fa[q][i]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q][j]), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -1196,7 +1331,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_conv_lean_kernel(GemmArgs g) {
   }
 #undef AVEC_WAIT_VM
   __syncthreads();
-  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, cls);
+  if (TR) {
+    // parity-class order: the tile's rows are class-local indices; the output row is the pixel's; a class-0-only residual (res_cls0) is indexed class-locally
+    long long row[MT], rrow[MT]; bool valid[MT];
+    const long long Mc = perm ? pMc : g.M;
+    const bool use_res = g.e.res != nullptr && (!g.e.res_cls0 || cls == 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      long long mc = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+      valid[i] = mc < Mc; if (!valid[i]) mc = Mc - 1;
+      row[i] = mc;
+      if (perm) { long long img; int ih, iw; perm2_pixel(g.a, cls, mc, img, ih, iw); row[i] = (img * g.a.H + ih) * (long long)g.a.W + iw; }
+      rrow[i] = g.e.res_cls0 ? mc : row[i];
+    }
+    conv_epilogue_tr<BM, BN, MT, NT>(g, acc, smem, row, valid, use_res ? (const bf16*)g.e.res : nullptr, rrow, m0 + BM <= Mc, n0, tid, lane, wm, wn);
+  } else nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, cls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1723,6 +1872,14 @@ template <typename K> static int want_lds(K kern, size_t bytes) {
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// register-direct epilogue (conv_epilogue_tr, transposed product): bf16 output and residual in whole 16-byte pieces, nothing but alpha / residual / BatchNorm statistics
+// to fuse.  AVEC_NO_EPI_TR=1: the staged epilogue everywhere (A/B runs).
+static bool epi_tr_ok(const GemmArgs& g) {
+  static const bool off = getenv("AVEC_NO_EPI_TR") != nullptr;
+  const Epi& e = g.e;
+  return !off && !e.out_f32 && !e.out_pre && !e.bias && e.act == 0 && !(e.drop_p > 0.f) && !e.dact && !e.colsum && !e.bnb_y && g.N % 8 == 0 &&
+         e.ldo % 8 == 0 && aligned16(e.out) && (!e.res || (e.res_act && e.ldres % 8 == 0 && aligned16(e.res)));
+}
 
 template <typename T, int BM, int BN>
 static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream_t st) {
@@ -1789,6 +1946,13 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
     static const bool no_clean = getenv("AVEC_NO_LEAN_CONV") != nullptr;
     if (mode != MODE_PLAIN && g.fast_conv && a16 && !f32src && use_glds && !no_clean && g.a.C % 32 == 0 && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
       const size_t l2 = (size_t)3 * (BM + BN) * 64 > epi_lds ? (size_t)3 * (BM + BN) * 64 : epi_lds;
+      if (epi_tr_ok(g)) {
+        const size_t lt = (size_t)3 * (BM + BN) * 64;
+        avec_note_kernel("gemm_nt_conv_lean_kernel<%d,%d,tr>", BN, mode);
+        if (mode == MODE_CONV_FWD) { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD, true>, lt)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD, true>), grid, dim3(256), lt, st, g); }
+        else { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD, true>, lt)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD, true>), grid, dim3(256), lt, st, g); }
+        return 0;
+      }
       avec_note_kernel("gemm_nt_conv_lean_kernel<%d,%d>", BN, mode);
       if (mode == MODE_CONV_FWD) { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>), grid, dim3(256), l2, st, g); }
       else { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>), grid, dim3(256), l2, st, g); }
@@ -1847,7 +2011,15 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
   // e.g. the 512-channel stage (28 800 rows x 512): 900 tiles of 128 rows = 1.17 rounds (59 %), 452 of 256 rows = 0.88 round (88 %)
   const long long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128), t256 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
   const double e128 = (double)t128 / (double)(((t128 + 767) / 768) * 768), e256 = 1.08 * (double)t256 / (double)(((t256 + 511) / 512) * 512);
-  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && e256 > e128))) { if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD); }
+  const bool tr_ok = epi_tr_ok(g) && !g.e.res_cls0;
+#define ST(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64 + 512 + (BM / 64 - 1) * 2048; const size_t lds = ring; \
+    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
+    avec_note_kernel("conv3x3_shift_kernel<%d,%d,%d,tr>", BM, BN, MODE); if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE, true>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE, true>), grid, dim3(256), lds, st, g); return 0; } while (0)
+  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && e256 > e128))) {
+    if (tr_ok) { if (mode == MODE_CONV_FWD) ST(256, 128, MODE_CONV_FWD); else ST(256, 128, MODE_CONV_BWD); }
+    if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD);
+  }
+#undef ST
   if (g.N >= 128) { if (mode == MODE_CONV_FWD) S(128, 128, MODE_CONV_FWD); else S(128, 128, MODE_CONV_BWD); }
   if (mode == MODE_CONV_FWD) S(128, 64, MODE_CONV_FWD); else S(128, 64, MODE_CONV_BWD);
 #undef S

@@ -207,6 +207,7 @@ class Model(Module):
         batch_losses, batch_metrics, _, _ = self.forward_model(inputs, targets, compute_metrics=eval_training)
         (batch_losses["loss"] / accumulated_steps).backward()
         rt.advance_rng(self.device)
+        batch_losses = self._own_losses(batch_losses)
         acc_step += 1
         if acc_step < accumulated_steps:
             return batch_losses, batch_metrics, acc_step
@@ -294,12 +295,25 @@ class Model(Module):
         if dist_mode and torch.distributed.get_backend() == "nccl":
             torch.cuda.synchronize()
             time.sleep(0.6)
+        cap_err = None
         try:
             with torch.cuda.graph(graph, **gkw):        # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
                 static_losses = body()
         except Exception as e:
             if not (dist_mode and state["in_graph"] and peer.active() is not None):
                 raise
+            cap_err = e
+        if dist_mode and state["in_graph"] and peer.active() is not None:
+            # the fallback must be the SAME on every rank: a rank that keeps captured collectives beside one that issues them eagerly is a collective mismatch
+            flag = torch.tensor([0.0 if cap_err is None else 1.0], device=self.device)
+            torch.cuda.synchronize()
+            torch.distributed.all_reduce(flag)
+            torch.cuda.synchronize()
+            if cap_err is None and float(flag.item()) > 0:
+                cap_err = RuntimeError("another rank could not capture the collectives")
+        if cap_err is not None:
+            e = cap_err
+            ops.reset_backward_state()                  # the aborted capture left a half-run backward pass behind: queued weight gradients, hand-over tags, group counters
             # the collectives could not be captured on this stack: capture forward + backward only (peer-write SyncBatchNorm), all-reduce + Adam after each replay
             print("[avec_amd] rank %d: capture with in-graph RCCL collectives failed (%s: %s); capturing forward + backward only" % (self.rank, type(e).__name__, e), flush=True)
             state["in_graph"] = False
@@ -314,8 +328,9 @@ class Model(Module):
 
         def step(new_inputs=None, new_targets=None):
             replays[0] += 1
-            if dist_mode and replays[0] % 100 == 0:
-                peer.active().check()               # (synchronises) a lost rank: the guarded Adam launch skipped those steps, say so instead of training on
+            px = peer.active() if dist_mode else None       # None: SyncBatchNorm over RCCL (peer exchange off / refused / more than one node)
+            if px is not None and replays[0] % 100 == 0:
+                px.check()                          # (synchronises) a lost rank: the guarded Adam launch skipped those steps, say so instead of training on
             if new_inputs is not None:
                 for d, s_ in zip(static_in, new_inputs):
                     d.copy_(s_, non_blocking=True)
@@ -366,7 +381,8 @@ class Model(Module):
         lw = self.compiled_loss_weights
         const_w = isinstance(lw, ConstantScheduler) or (isinstance(lw, dict) and all(isinstance(v, ConstantScheduler) for v in lw.values())) \
             or (isinstance(lw, list) and all(isinstance(v, ConstantScheduler) for v in lw))
-        capturable = (not self.is_distributed) or peer.active() is not None or torch.distributed.get_backend() == "nccl"
+        capturable = (not self.is_distributed) or peer.active() is not None or \
+            (torch.distributed.get_backend() == "nccl" and os.environ.get("AVEC_GRAPH_ALLREDUCE", "1") != "0")
         if not const_w or self.grad_max_norm is not None or not capturable:
             return self.train_step(inputs, targets, precision=precision)[0]
         if bucket_frames and len(inputs) == 4 and inputs[0].dim() == 5 and isinstance(targets, (tuple, list)) and len(targets) == 2:
@@ -388,9 +404,19 @@ class Model(Module):
         cache[key] = step
         return step(inputs, targets)
 
+    @staticmethod
+    def _own_losses(batch_losses):
+        """the fused CTC launch leaves its means and the weighted total in the step's pre-zeroed scratch pool, which the next step (or graph replay) overwrites: hand
+        the caller values it can keep (ONE stacked copy; a captured step returns the pool views themselves -- static outputs refilled by every replay)"""
+        keys = list(batch_losses)
+        vals = torch.stack([batch_losses[k].detach().reshape(()).float() for k in keys]).unbind(0)
+        return dict(zip(keys, vals))
+
     def eval_step(self, inputs, targets, verbose=0):
         with torch.no_grad():
-            return self.forward_model(inputs, targets, verbose=verbose)
+            rt.reset_zero_pool(self.device)          # (the scratch pool hands out PRE-ZEROED accumulators: whatever earlier steps or replays of other shapes left there must go)
+            batch_losses, batch_metrics, batch_truths, batch_preds = self.forward_model(inputs, targets, verbose=verbose)
+            return self._own_losses(batch_losses), batch_metrics, batch_truths, batch_preds
 
     # -- checkpoints (nnet/model.py:499-544) -------------------------------------------------------
     def save(self, path, save_optimizer=True):

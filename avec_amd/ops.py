@@ -258,6 +258,18 @@ def _in_backward():
     return DEFER_WGRAD and torch._C._current_graph_task_id() != -1
 
 
+def reset_backward_state():
+    """forget everything a backward pass leaves between its nodes (queued parameter-gradient products, hand-over tables, position-group counters): called when a pass
+    was aborted (a graph capture that failed midway) before the step is run again"""
+    for q in _DEFER["queues"].values():
+        q.tn, q.ln, q.keep, q.flops, q.cw, q.cw_flops, q.cw64, q.cw64_flops = [], [], [], 0.0, [], 0.0, [], 0.0
+    _DEFER["task"] = -1
+    _PREP_READY["task"], _PREP_READY["m"] = -1, {}
+    _LN2_READY["task"], _LN2_READY["m"] = -1, {}
+    for ent in _POS_CACHE.values():
+        ent[1].de_all, ent[1].remaining = None, ent[1].L
+
+
 def _pending():
     st = torch.cuda.current_stream()
     q = _DEFER["queues"].get(st.cuda_stream)
@@ -473,7 +485,7 @@ def layernorm_bwd_pair(dy2, x2, mean2, rstd2, w2, b2, dres2, x1, mean1, rstd1, w
                        x1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), w1.data_ptr(), dx1.data_ptr(), _p(pt), alpha, drop_p, rng, sid, M, D, rt.stream())
     if _LN2_READY["task"] != task:
         _LN2_READY["task"], _LN2_READY["m"] = task, {}
-    _LN2_READY["m"][dx2.data_ptr()] = (dx1, ctx1)
+    _LN2_READY["m"][dx2.data_ptr()] = (dx1, ctx1, dx2, dx2._version)
     defer_ln_param_grads(dy2, False, x2, mean2, rstd2, w2, b2, M, D)
     return dx2
 
@@ -614,7 +626,9 @@ class LayerNormFn(torch.autograd.Function):
         x2, mean, rstd, w, b, M, D, shp, req = ctx.saved
         if _LN2_READY["task"] == torch._C._current_graph_task_id():
             r = _LN2_READY["m"].pop(dy.data_ptr(), None)
-            if r is not None and r[1] is ctx and dy.dtype == torch.float32 and dy.is_contiguous():      # the feed-forward module behind has done this LayerNorm's backward already
+            # the feed-forward module behind has done this LayerNorm's backward already -- valid only if dy still IS its dx2 (same storage, not accumulated into since:
+            # a second consumer of this norm's output makes autograd add its gradient in place, which bumps the version counter)
+            if r is not None and r[1] is ctx and dy.dtype == torch.float32 and dy.is_contiguous() and (dy is r[2] or dy._base is r[2]) and r[2]._version == r[3]:
                 defer_ln_param_grads(dy.reshape(M, D), True, x2, mean, rstd, w, b, M, D)
                 return r[0].view(shp), None, None, None, None
         dx = layernorm_bwd(_f32c(dy.reshape(M, D)), True, x2, mean, rstd, w, b, M, D, prep=req)
@@ -890,6 +904,8 @@ def _pos_group_entry(wp, Tp, D, device):
         if len(_POS_CACHE) > 64:
             for k in list(_POS_CACHE)[:32]:
                 _POS_CACHE.pop(k, None)
+    if ent[1].remaining != ent[1].L or ent[1].de_all is not None:      # a backward pass that raised midway left its counters behind: a forward pass starts clean
+        ent[1].de_all, ent[1].remaining = None, ent[1].L
     return ent[1], idx
 
 

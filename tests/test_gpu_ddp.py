@@ -158,3 +158,17 @@ def test_one_rank_rccl_group_takes_every_data_parallel_path(tmp_path, peer_excha
         d = ((r["exp_avg"].double() - ref).norm() / ref.norm()).item()
         assert d < 4e-3, (k, d)
         assert abs(r["loss"] - p["loss"]) < 1e-3 * abs(p["loss"]), (k, r["loss"], p["loss"])
+
+
+def test_one_rank_rccl_graphed_step_survives_the_periodic_peer_check_without_a_peer_exchange(tmp_path):
+    """Every 100th replay of a captured data-parallel step asks the peer exchange whether a rank was lost; with the exchange off (AVEC_PEER_SYNCBN=0: SyncBatchNorm over
+    RCCL, also what more than 8 ranks / several nodes / refused IPC give) there is no exchange object to ask -- 101 replays must run through (round-4 advisor finding)."""
+    out = str(tmp_path / "g.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29567", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AVEC_DIST_SINGLE="1",
+               AVEC_PEER_SYNCBN="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_graph_equiv.py"), "--out", out, "--mode", "graph", "--backend", "nccl", "--replays", "101"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    g = torch.load(out)
+    assert g["graphed"] and g["in_graph"] and not g["peer"] and g["step"] == 102, (g["graphed"], g["in_graph"], g["peer"], g["step"])
+    assert g["loss"] == g["loss"] and abs(g["loss"]) < 1e4

@@ -1,0 +1,139 @@
+"""GPU (-m gpu), round-5 parity cases.
+
+* the register-direct epilogue of the shifted-window convolution (transposed product, `conv_epilogue_tr` in csrc/gemm.hip): forward + BatchNorm statistics and
+  backward-data + residual gradient of the ResNet 3x3 layers (nnet/blocks.py:29-91) against torch.nn.functional.conv2d in fp32, on the 256-row tile the B = 32
+  step runs (forced through AVEC_SHIFT_BM, which the library reads once per process: subprocess), with ragged last tiles.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SHIFT_TR = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import torch.nn.functional as F
+import avec_amd
+from avec_amd import ops
+from avec_amd.lib import lib, ROWS_CONV_FWD, ROWS_CONV_BWD
+avec_amd.set_compute_dtype("bf16")
+d = torch.device("cuda:0"); adt = torch.bfloat16
+def last():
+    n = lib.raw("avec_last_kernel")(); return n if isinstance(n, str) else n.decode()
+for (Nimg, H, Cin, Cout) in [(33, 11, 128, 128), (61, 6, 256, 256), (70, 3, 512, 512), (29, 11, 128, 256), (3, 22, 64, 128)]:
+    g = torch.Generator().manual_seed(Nimg * 1000 + H)
+    x = torch.randn(Nimg, H, H, Cin, generator=g).to(adt)
+    Wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(adt)
+    M = Nimg * H * H
+    dy = torch.randn(M, Cout, generator=g).to(adt)
+    res = torch.randn(M, Cin, generator=g).to(adt)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, Wt.float(), stride=1, padding=1)
+    yr.backward(dy.float().reshape(Nimg, H, H, Cout).permute(0, 3, 1, 2))
+    ref = yr.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+    dref = xr.grad.permute(0, 2, 3, 1).reshape(M, Cin) + res.float()
+    W = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+    Wb = Wt.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous().to(d)
+    y = torch.full((M + 3, Cout), float("nan"), device=d, dtype=adt)               # (rows behind M must stay untouched)
+    st = torch.zeros(64 * 2 * Cout, device=d)
+    ops.gemm_nt(x.to(d), W, y, M, Cout, 9 * Cin, rows=ops.rows_conv(H, H, Cin, 3, 3, 1, 1, H, H), mode=ROWS_CONV_FWD, stats=st)
+    k1 = last()
+    dx = torch.full((M + 3, Cin), float("nan"), device=d, dtype=adt)
+    ops.gemm_nt(dy.to(d), Wb, dx, M, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, 1, 1, H, H), mode=ROWS_CONV_BWD, res=res.to(d), res_act=True)
+    k2 = last()
+    torch.cuda.synchronize()
+    tag = (Nimg, H, Cin, Cout)
+    assert k1.endswith(",tr>") and (Cin < 128 or k2.endswith(",tr>")), (tag, k1, k2)        # (64 output columns: the 128 x 64 tile keeps the staged epilogue)
+    assert torch.isnan(y[M:].float()).all() and torch.isnan(dx[M:].float()).all(), tag
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(y[:M], ref) < 4e-3, (tag, rel(y[:M], ref))
+    assert rel(dx[:M], dref) < 4e-3, (tag, rel(dx[:M], dref))
+    assert float((y[:M].float().cpu() - ref).abs().max()) < 0.02 * float(ref.abs().max()) + 1e-3, tag
+    assert float((dx[:M].float().cpu() - dref).abs().max()) < 0.02 * float(dref.abs().max()) + 1e-3, tag
+    s = st.view(64, 2, Cout).sum(0).cpu()
+    # per channel: a column permutation inside the statistics would keep the norm
+    assert float((s[0] - ref.sum(0)).abs().max()) < 2e-3 * float(ref.sum(0).abs().max()) + 2e-2, (tag, "sum")
+    assert float((s[1] - (ref * ref).sum(0)).abs().max()) < 2e-3 * float((ref * ref).sum(0).abs().max()), (tag, "sumsq")
+print("OK")
+''' % ROOT
+
+
+def test_shift_conv_register_direct_epilogue_matches_torch(tmp_path):
+    """forward + BatchNorm statistics / backward-data + residual (fp32 add before the single bf16 rounding) through conv3x3_shift_kernel<256,128,*,tr>: 4e-3 relative
+    L2 (bf16 output rounding is 2^-9 rms), every element within 2 %% of the largest, per-channel statistics within 2e-3"""
+    script = tmp_path / "run.py"
+    script.write_text(_SHIFT_TR)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, AVEC_SHIFT_BM="256"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,k", [(33, 11, 128, 256, 3), (20, 22, 64, 128, 3), (45, 6, 256, 512, 3), (20, 22, 64, 128, 1), (33, 11, 128, 256, 1)])
+def test_stride2_conv_register_direct_epilogue_matches_torch(Nimg, H, Cin, Cout, k):
+    """the stride-2 3x3 and the 1x1 / stride-2 shortcut convolutions of the ResNet stage boundaries (nnet/blocks.py:29-91) through gemm_nt_conv_lean_kernel<*,*,tr>:
+    forward + BatchNorm statistics; backward-data in parity-class order with a full-size residual gradient and with the class-0-only residual (`res_cls0`, the
+    shortcut's gradient on the subsampled grid) -- against torch conv2d in fp32: 4e-3 relative L2, every element within 2 % of the largest"""
+    import torch.nn.functional as F
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import lib, ROWS_CONV_FWD, ROWS_CONV_BWD
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d, adt = torch.device("cuda:0"), torch.bfloat16
+        last = lambda: (lambda n: n if isinstance(n, str) else n.decode())(lib.raw("avec_last_kernel")())
+        g = torch.Generator().manual_seed(Nimg * 100 + H + k)
+        pad = (k - 1) // 2
+        x = torch.randn(Nimg, H, H, Cin, generator=g).to(adt)
+        Wt = (torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)).to(adt)
+        OH = (H - 1) // 2 + 1
+        M = Nimg * OH * OH
+        dy = torch.randn(M, Cout, generator=g).to(adt)
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = F.conv2d(xr, Wt.float(), stride=2, padding=pad)
+        yr.backward(dy.float().reshape(Nimg, OH, OH, Cout).permute(0, 3, 1, 2))
+        ref = yr.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+        dref = xr.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+        W = Wt.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(d)
+        Wb = Wt.permute(1, 2, 3, 0).reshape(Cin, k * k * Cout).contiguous().to(d)
+        y = torch.full((M, Cout), float("nan"), device=d, dtype=adt)
+        st = torch.zeros(64 * 2 * Cout, device=d)
+        ops.gemm_nt(x.to(d), W, y, M, Cout, k * k * Cin, rows=ops.rows_conv(H, H, Cin, k, k, 2, pad, OH, OH), mode=ROWS_CONV_FWD, stats=st)
+        k1 = last()
+        rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+        torch.cuda.synchronize()
+        assert "lean" in k1 and k1.endswith(",tr>"), k1
+        assert rel(y, ref) < 4e-3, rel(y, ref)
+        assert float((y.float().cpu() - ref).abs().max()) < 0.02 * float(ref.abs().max()) + 1e-3
+        s = st.view(64, 2, Cout).sum(0).cpu()
+        assert float((s[0] - ref.sum(0)).abs().max()) < 2e-3 * float(ref.sum(0).abs().max()) + 2e-2
+        assert float((s[1] - (ref * ref).sum(0)).abs().max()) < 2e-3 * float((ref * ref).sum(0).abs().max())
+        if k == 3:
+            MI = Nimg * H * H
+            res = torch.randn(MI, Cin, generator=g).to(adt)
+            dx = torch.full((MI, Cin), float("nan"), device=d, dtype=adt)
+            ops.gemm_nt(dy.to(d), Wb, dx, MI, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, 2, 1, OH, OH), mode=ROWS_CONV_BWD, res=res.to(d), res_act=True)
+            k2 = last()
+            # class-0-only residual: rows (img, ih even, iw even) in class-local order
+            He = (H + 1) // 2
+            res0 = torch.randn(Nimg * He * He, Cin, generator=g).to(adt)
+            dx0 = torch.full((MI, Cin), float("nan"), device=d, dtype=adt)
+            ops.gemm_nt(dy.to(d), Wb, dx0, MI, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, 2, 1, OH, OH), mode=ROWS_CONV_BWD, res=res0.to(d), res_act=True, res_cls0=True)
+            k3 = last()
+            torch.cuda.synchronize()
+            if Cin >= 64:
+                assert k2.endswith(",tr>") and k3.endswith(",tr>"), (k2, k3)
+            want = dref + res.float()
+            assert rel(dx, want) < 4e-3, rel(dx, want)
+            assert float((dx.float().cpu() - want).abs().max()) < 0.02 * float(want.abs().max()) + 1e-3
+            full0 = torch.zeros(Nimg, H, H, Cin)
+            full0[:, 0::2, 0::2, :] = res0.float().reshape(Nimg, He, He, Cin)
+            want0 = dref + full0.reshape(MI, Cin)
+            assert rel(dx0, want0) < 4e-3, rel(dx0, want0)
+            assert float((dx0.float().cpu() - want0).abs().max()) < 0.02 * float(want0.abs().max()) + 1e-3
+    finally:
+        avec_amd.set_compute_dtype("f32")

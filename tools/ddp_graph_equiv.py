@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--mode", default="eager")
     ap.add_argument("--backend", default="gloo", help="gloo: both ranks on cuda:0; nccl (= RCCL): one GPU per rank")
+    ap.add_argument("--replays", type=int, default=2, help="graph mode: replays after the warm-up step")
     args = ap.parse_args()
     plain = args.backend == "none"               # no process group at all: the single-process reference of the one-rank RCCL runs
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -49,7 +50,7 @@ def main():
     graphed = args.mode == "graph"
     if graphed:
         step = model.make_graphed_train_step(inputs, targets, precision=torch.bfloat16, warmup=1)      # the warm-up pass is a real optimisation step
-        for _ in range(2):
+        for _ in range(args.replays):
             losses = step()
     else:
         for _ in range(3):
