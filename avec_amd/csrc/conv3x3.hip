@@ -8,7 +8,12 @@
 // are nine LDS offsets.  Per image: M = H*W pixels (padded to 512 = 8 waves x 64), N = 64, K = 576 -> 36 k-steps of v_mfma_f32_32x32x16_bf16.
 // The product is computed transposed (C^T = W . X^T): a lane then owns ONE pixel and groups of 4 consecutive channels, so the bf16 output leaves
 // the registers as 8-byte pieces of its NHWC row and the BatchNorm statistics are per-register sums reduced once at the end.
-// LDS: 81 920 (weights) + 73 728 (slab) = 155 648 B -> one workgroup per CU; the store of image n-1 overlaps the DMA latency of image n.
+// LDS: 81 920 (weights) + 73 728 (slab) = 155 648 B -> one workgroup per CU, so there is no room for a second slab.  Round 5: the slab of image n+1 is
+// PREFETCHED INTO REGISTERS (nine 16-byte pieces per lane, plain loads issued at the start of image n's MFMA phase) and written to the LDS slab by ds_write_b128
+// between the two barriers that separate the images: the HBM round trip of an image (62 KB per CU at the ~19 GB/s a CU gets when all 256 stream: the slab's
+// LDS-DMA used to be waited for with nothing to overlap, ~7 of the ~13 us per image) now runs under the 36 k-steps of the previous image.  The zero border is
+// written once.  The kernel is instantiated per (statistics, residual) pair: the forward launch carries no residual pieces, the backward one no statistics
+// registers -- which is where the 36 prefetch registers come from.
 // forward:   y[p][co]  = sum_{tap,ci} x[p + tap - 1][ci] * Wf[co][tap][ci]          (flip = 0, weight = forward shadow  [Cout][9][Cin])
 // backward:  dx[p][ci] = sum_{tap,co} dy[p - tap + 1][co] * Wb[ci][tap][co] (+ res)  (flip = 1, weight = backward shadow [Cin][9][Cout])
 #include "common.h"
@@ -17,6 +22,7 @@
 
 typedef __attribute__((ext_vector_type(16))) float c3_f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned c3_u32x4;
 
 #define C3_WPITCH 1280                      // bytes per weight row in LDS: 72 data chunks in 80 slots (5 groups of 16)
 #define C3_WBYTES (64 * C3_WPITCH)          // 81 920
@@ -36,6 +42,10 @@ __device__ __forceinline__ int c3_saddr(int pix, int c) { const int pr = pix >> 
 // lane -> pixel of a 32-pixel tile such that the two b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each own 16 consecutive pixels
 __device__ __forceinline__ int c3_lane_pixel(int l) { return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l; }
 
+#ifndef C3S_ABL
+#define C3S_ABL 0         // timing experiments on the slab kernel: 1 no MFMA, 2 no slab prefetch / ds_write, 4 no fragment reads, 8 no fold / pack / stores, 16 no output stores
+#endif
+template <bool STATS, bool RES>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem; char* Sl = smem + C3_WBYTES;
@@ -74,11 +84,287 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
   const int wrow[2] = {(lane & 31) * C3_WPITCH, (32 + (lane & 31)) * C3_WPITCH};
   const int wkey = lane & 15;                // (n & 15) for both n-tiles
 
-  float ssum[2][16], ssq[2][16];             // BatchNorm statistics of this lane's channels over its pixels, all images of the workgroup
+  float ssum[STATS ? 2 : 1][16], ssq[STATS ? 2 : 1][16];      // BatchNorm statistics of this lane's channels over its pixels, all images of the workgroup
+  if (STATS) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+  }
+
+  c3_f32x16 acc[2][2];                       // [n-tile j][m-tile i], C^T layout: column = pixel (lane & 31), rows = channels (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Results leave in two steps so that nobody waits for a store: right after the MFMAs of image n the accumulators are folded into the statistics, added to the
+  // residual and packed to bf16 (32 registers); those 8-byte pieces are stored at the START of image n+1's MFMA phase, after the wait for its slab, and
+  // complete under that phase.  The residual pieces of image n are requested at the start of its own MFMA phase and consumed after it.
+  // A lane owns channels {0-3, 8-11, 16-19, 24-27} (+4 for the upper half-wave) of its pixel: v_permlane32_swap trades the odd 4-channel group of the lower
+  // half-wave for the even group of the upper one, after which every lane holds 8 consecutive channels = one 16-byte piece per (n-tile, 16-channel block).
+  // Round 5: every global access of the image loop is inline asm with hand-counted waits.  Left to the compiler, the wait for the prefetched pieces (issued before
+  // the CONDITIONAL stores of the previous image) comes out as a drain of everything, store acknowledgements included: the in-kernel stamps showed 4.8 of 18 thousand
+  // cycles per image in that wait and 2.5 more where two 1 KB stores per tap throttled taps 1-4.  Issue order per image and wave (all 16-byte pieces per lane):
+  //   tap t = 0..3: next image's pieces 2t, 2t+1 | residual pieces 2t, 2t+1 (backward) | store t of the previous image;  tap 4: piece 8, store 4;  taps 5-7: stores 5-7
+  // so after tap 8 `s_waitcnt vmcnt(3)` covers every load and leaves the three youngest stores in flight (vmcnt counts in issue order; no stores in the first image: 0).
+  c3_u32x4 outp[2][2][2], resp[RES ? 2 : 1][2][2];
+  long long prev = -1;                       // image whose packed results are still in outp
+  auto swap_pair = [&](uint2& x, uint2& y) {   // (X, Y) = (group 2k, group 2k+1) <-> (channels 0-7 | 8-15 of the 16-block): an involution
+    auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false); x.x = r0[0]; y.x = r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false); x.y = r1[0]; y.y = r1[1];
+  };
+  const int chq = kh2 * 8;                   // this lane's 8-channel piece inside a 16-channel block after the swap
+  unsigned ldoff[9], zmask = 0u;             // byte offset of piece i inside an image (border slots read offset 0 and are zeroed on their way into the slab: bit i of zmask)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { ldoff[i] = soff[i] < 0 ? 0u : (unsigned)soff[i] * 2u; if (soff[i] < 0) zmask |= 1u << i; }
+  // invalid lanes (pixels beyond the image) were clamped to the last pixel: they compute and store ITS value again (same address, same bytes): no predicate on the stores
+  const unsigned stoff[2] = {(unsigned)pm[0] * 128u + (unsigned)chq * 2u, (unsigned)pm[1] * 128u + (unsigned)chq * 2u};
+// ("+v": the destination is the loop-carried register itself -- with "=v" the compiler loads into a temporary and COPIES it into the loop variable before the data lands)
+// hazards the compiler does not pad inside an asm string: a base SGPR fresh from the scalar ALU needs 5 states before a global_* reads it (s_nop 4 in front);
+// a 16-byte store reads its data registers for two more states (s_nop 1 behind it)
+#define C3_GLOAD(dst, voff, sbase, OFF) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(OFF))
+#define C3_GSTORE(voff, data, sbase, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase), "n"(OFF))
+  auto issue_stores = [&]() {
+    if (prev < 0 || (C3S_ABL & (8 | 16))) return;
+    bf16* yo = a.y + prev * HW * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!pvalid[i]) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *(c3_u32x4*)(yo + (long long)pm[i] * 64 + j * 32 + k * 16 + chq) = outp[j][i][k];
+    }
+  };
+
+  c3_u32x4 pf[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pf[i] = c3_u32x4{0u, 0u, 0u, 0u};
+  if (RES) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) resp[RES ? j : 0][i][k] = c3_u32x4{0u, 0u, 0u, 0u};
+  }
+  if ((long long)blockIdx.x < a.N && !(C3S_ABL & 2)) {
+    const bf16* x0 = a.x + (long long)blockIdx.x * HW * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C3_GLOAD(pf[i], ldoff[i], x0, 0);
+    asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(pf[i]));
+  }
+#ifdef C3S_TRACE
+  // phase stamps of workgroup C3S_TRACE_WG, wave 0 (STATS builds): a.stats + 8192 + 8 * image ordinal: loop top | after the slab is written | taps 0-4 | taps 5-8 | fold (core clock) | 100 MHz clock
+  int tr_k = 0;
+  float* const trbuf = STATS ? a.stats + 8192 : (float*)(a.y + (long long)a.N * HW * 64);      // (backward: behind the output tensor, which the trace script allocates longer)
+#define C3S_STAMP(slot) do { if (blockIdx.x == C3S_TRACE_WG && tid == 0 && tr_k < 16) { trbuf[8 * tr_k + (slot)] = (float)(clock64() & 0xffffff); if ((slot) == 0) trbuf[8 * tr_k + 6] = (float)(wall_clock64() & 0xffffff); } } while (0)
+#else
+#define C3S_STAMP(slot) do {} while (0)
+#endif
+  for (long long n = blockIdx.x; n < a.N; n += gridDim.x) {
+    C3S_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)");      // the youngest request is piece 8 (tap 8): everything has to have landed
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(pf[i]));
+    __syncthreads();                         // every wave is done reading the slab of the previous image (and the weights are in place)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (C3S_ABL & 2) break;
+      c3_u32x4 v = pf[i];
+      if (zmask & (1u << i)) v = c3_u32x4{0u, 0u, 0u, 0u};
+      *(c3_u32x4*)(Sl + ((wave + 8 * i) * 64 + lane) * 16) = v;
+    }
+    __syncthreads();
+    C3S_STAMP(1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    // 36 k-steps (9 taps x 4 chunks of 16 channels); the fragments of step s+1 are requested before the MFMAs of step s
+    // (the taps are unrolled: without an opaque input per image the compiler hoists every tap's loop-invariant fragment addresses out of the image loop and spills them)
+    int p0o[2] = {p0[0], p0[1]}, wkeyo = wkey;
+    asm volatile("" : "+v"(p0o[0]), "+v"(p0o[1]), "+v"(wkeyo));
+    auto tap_addr = [&](int tap, int& ax0, int& ax1, int& aw0, int& aw1, bool& z0, bool& z1) {
+      const int th = tap / 3, tw = tap - th * 3;
+      const int dh = (a.flip & 1) ? 2 - th : th, dw = (a.flip & 1) ? 2 - tw : tw;
+      const int d = dh * PW + dw;
+      ax0 = c3_saddr(p0o[0] + d, kh2); ax1 = c3_saddr(p0o[1] + d, kh2);
+      const int wt = (((tap >> 1) << 4) | ((((tap & 1) << 3) | kh2) ^ wkeyo)) << 4;
+      aw0 = wrow[0] + wt; aw1 = wrow[1] + wt;
+      z0 = z1 = false;
+    };
+    auto load4 = [&](int ax0, int ax1, int aw0, int aw1, bool z0, bool z1, int q, chunk16& fx0, chunk16& fx1, chunk16& fw0, chunk16& fw1) {
+      if (C3S_ABL & 4) { fx0.w[0] = fx0.w[1] = fx0.w[2] = fx0.w[3] = ax0 + q; fx1 = fx0; fw0 = fx0; fw1 = fx0; return; }
+      fx0 = *(const chunk16*)(Sl + (ax0 ^ (q << 5)));
+      fx1 = *(const chunk16*)(Sl + (ax1 ^ (q << 5)));
+      fw0 = *(const chunk16*)(Ws + (aw0 ^ (q << 5)));
+      fw1 = *(const chunk16*)(Ws + (aw1 ^ (q << 5)));
+    };
+    // (the loads are unconditional and sit in straight-line code: a conditional or a switch around an asm with an output makes the compiler load into a temporary
+    // and copy it into the loop-carried register before the data lands; the last image of a workgroup prefetches itself again)
+    const bool has_prev = prev >= 0 && !(C3S_ABL & (8 | 16)), has_next = n + gridDim.x < a.N;
+    const bf16* const yprev = a.y + (has_prev ? prev : 0) * HW * 64;
+    const bf16* const xnext = a.x + (has_next ? n + gridDim.x : n) * HW * 64;
+    const bf16* const rcur = RES ? a.res + n * HW * 64 : a.x;
+    auto one_tap = [&](int tap) {
+      int ax0, ax1, aw0, aw1; bool z0, z1;
+      tap_addr(tap, ax0, ax1, aw0, aw1, z0, z1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        chunk16 cx0, cx1, cw0, cw1;
+        load4(ax0, ax1, aw0, aw1, z0, z1, q, cx0, cx1, cw0, cw1);
+        if (C3S_ABL & 1) { asm volatile("" :: "v"(cx0.w[0]), "v"(cx0.w[3]), "v"(cx1.w[0]), "v"(cx1.w[3]), "v"(cw0.w[0]), "v"(cw0.w[3]), "v"(cw1.w[0]), "v"(cw1.w[3])); continue; }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw0), __builtin_bit_cast(c3_bf16x8, cx0), acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw0), __builtin_bit_cast(c3_bf16x8, cx1), acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx0), acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, cw1), __builtin_bit_cast(c3_bf16x8, cx1), acc[1][1], 0, 0, 0);
+      }
+    };
+    // piece k of a pixel tile: k = 4 i + 2 j + kk  ->  outp / resp [j][i][kk] at byte offset 64 j + 32 kk of the lane's row piece
+#define C3_RS(I, J, K) do { if (RES) C3_GLOAD(resp[RES ? (J) : 0][I][K], stoff[I], rcur, (J) * 64 + (K) * 32); } while (0)
+#define C3_ST(I, J, K) do { if (has_prev) C3_GSTORE(stoff[I], outp[J][I][K], yprev, (J) * 64 + (K) * 32); } while (0)
+#define C3_LD1(I) do { if (!(C3S_ABL & 2)) C3_GLOAD(pf[I], ldoff[I], xnext, 0); } while (0)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // one piece of the next image and one store of the previous one per tap (waited for at the top of the next image); backward: the eight residual pieces of
+      // THIS image in front of them in taps 0-3, waited for before the fold with everything issued from tap 4 on (5 pieces + 4 stores) still in flight
+      switch (tap) {
+        case 0: C3_LD1(0); C3_ST(0, 0, 0); break;
+        case 1: C3_LD1(1); C3_ST(0, 0, 1); break;
+        case 2: C3_LD1(2); C3_ST(0, 1, 0); break;
+        case 3: C3_LD1(3); C3_ST(0, 1, 1); break;
+        case 4: C3_LD1(4); C3_ST(1, 0, 0); break;
+        case 5: C3_RS(0, 0, 0); C3_RS(0, 0, 1); C3_RS(0, 1, 0); C3_RS(0, 1, 1); C3_RS(1, 0, 0); C3_RS(1, 0, 1); C3_RS(1, 1, 0); C3_RS(1, 1, 1); C3_LD1(5); C3_ST(1, 0, 1); break;
+        case 6: C3_LD1(6); C3_ST(1, 1, 0); break;
+        case 7: C3_LD1(7); C3_ST(1, 1, 1); break;
+        default: C3_LD1(8); break;
+      }
+      one_tap(tap);
+      if (tap == 4) C3S_STAMP(2);
+    }
+#undef C3_LD1
+#undef C3_RS
+#undef C3_ST
+    if (RES) { if (C3S_ABL & 2) asm volatile("s_waitcnt vmcnt(0)"); else if (has_prev) asm volatile("s_waitcnt vmcnt(7)"); else asm volatile("s_waitcnt vmcnt(4)"); }
+    if (RES) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(resp[RES ? j : 0][i][k]));
+    }
+    C3S_STAMP(3);
+    // fold + pack
+    if (C3S_ABL & 8) {
+      float t = 0.f;
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) t += acc[j][i][r];
+      if (t == 1234.5f) outp[0][0][0][0] = 1u;
+      asm volatile("" :: "v"(t));
+      prev = n; continue;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          uint2 rx = make_uint2(0u, 0u), ry = make_uint2(0u, 0u);
+          if (RES) { const c3_u32x4 rr = resp[RES ? j : 0][i][k]; rx = make_uint2(rr[0], rr[1]); ry = make_uint2(rr[2], rr[3]); swap_pair(rx, ry); }   // back to (group 2k, group 2k+1)
+          uint2 o[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int g = 2 * k + e;
+            float v[4] = {acc[j][i][g * 4 + 0], acc[j][i][g * 4 + 1], acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]};
+            if (STATS && pvalid[i]) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { ssum[j][g * 4 + t] += v[t]; ssq[j][g * 4 + t] += v[t] * v[t]; }
+            }
+            if (RES) {
+              const uint2 r = e ? ry : rx;
+              v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u); v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+            }
+            o[e] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+          }
+          swap_pair(o[0], o[1]);
+          outp[j][i][k] = c3_u32x4{o[0].x, o[0].y, o[1].x, o[1].y};
+        }
+    prev = n;
+    C3S_STAMP(4);
+#ifdef C3S_TRACE
+    ++tr_k;
+#endif
+  }
+  issue_stores();
+  if (STATS) {
+    // lanes sharing lane >> 5 hold the same channels for different pixels: butterfly over the 32 pixel lanes, then over the 8 waves through LDS
+    __syncthreads();
+    float* red = (float*)Sl;                 // [8 waves][2 (sum, sq)][64 channels]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = ssum[j][r], q = ssq[j][r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if ((lane & 31) == 0) {
+          const int ch = j * 32 + (r >> 2) * 8 + kh2 * 4 + (r & 3);
+          red[(wave * 2 + 0) * 64 + ch] = s; red[(wave * 2 + 1) * 64 + ch] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+      for (int w = 0; w < 8; ++w) t += red[w * 128 + tid];
+      float* rep = a.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 128;
+      atomicAdd(rep + tid, t);               // [sum 64 | sumsq 64]
+    }
+  }
+}
+
+// The backward-data launches (residual gradient added): same register-staged slab, but every global access left to the compiler -- the next image's nine pieces
+// requested in one go behind the barrier, the previous image's stores two per tap under taps 1-4, the eight residual pieces at tap 5.  Their residual pieces are
+// 16-byte fragments of 32 different 128-byte lines per instruction, and spread over the taps by hand (as in the forward kernel above) they cost more issue time than
+// the finer overlap gains: 189-210 us against 175 us in this form and 197 us with the slab by LDS-DMA (forward: 166 -> 149 us; profiles/r05_slab_phases.txt).
+__global__ __launch_bounds__(512) void conv3x3_c64_res_kernel(C3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ws = smem; char* Sl = smem + C3_WBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  // ---- weights -> LDS once (plain loads + ds_write: 9 chunks per thread) ----
+  for (int q = tid; q < 64 * 72; q += 512) {
+    const int n = q / 72, c = q - n * 72;
+    *(chunk16*)(Ws + n * C3_WPITCH + c3_wslot(n, c) * 16) = ldg16(a.w + (long long)n * 576 + c * 8);
+  }
+  // ---- slab DMA plan: piece q = wave + 8*i (i < 9) covers slots [q*64, q*64+64); slot s of pair-row pr holds logical chunk s ^ (pr & 15) ----
+  int soff[9];                               // element offset inside the image, or -1 = zero (border / beyond the slab)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, pr = S >> 4, c2 = (S & 15) ^ (pr & 7);
+    const int pix = pr * 2 + (c2 >> 3), ch = c2 & 7;          // slab pixel = 1 + y' * (W+1) + x: rows 0 and H+1 are zero, column W is the zero column shared by two rows
+    const int py = (pix - 1) / PW, px = (pix - 1) - py * PW;
+    const bool in = pix >= 1 && pix < NPIX && py >= 1 && py <= H && px < W;
+    soff[i] = in ? ((py - 1) * W + px) * 64 + ch * 8 : -1;
+  }
+  // ---- fragment addressing ----
+  // pixel operand (MFMA B): lane -> pixel row (lane & 31) of m-tile i, k-half lane >> 5;  weight operand (MFMA A): lane -> channel (lane & 31) of n-tile j
+  const int kh2 = lane >> 5;
+  int p0[2]; bool pvalid[2]; int pm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = wave * 64 + i * 32 + c3_lane_pixel(lane & 31);
+    pvalid[i] = m < HW; if (m >= HW) m = HW - 1;
+    pm[i] = m;
+    const int oy = m / W;
+    p0[i] = oy * PW + (m - oy * W);          // slab pixel of tap offset (0, 0); offset (dh, dw) adds dh*PW + dw
+  }
+  const int wrow[2] = {(lane & 31) * C3_WPITCH, (32 + (lane & 31)) * C3_WPITCH};
+  const int wkey = lane & 15;                // (n & 15) for both n-tiles
+
 
   c3_f32x16 acc[2][2];                       // [n-tile j][m-tile i], C^T layout: column = pixel (lane & 31), rows = channels (r&3) + 8*(r>>2) + 4*(lane>>5)
   // Results leave in two steps so that nobody waits for a store: right after the MFMAs of image n the accumulators are folded into the statistics, added to the
@@ -106,18 +392,27 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
     }
   };
 
+  // branch-free: border slots load element 0 of the image and are replaced by zeros on their way into the slab
+  chunk16 pf[9];
+  if ((long long)blockIdx.x < a.N) {
+    const bf16* x0 = a.x + (long long)blockIdx.x * HW * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) pf[i] = ldg16(x0 + (soff[i] < 0 ? 0 : soff[i]));
+  }
   for (long long n = blockIdx.x; n < a.N; n += gridDim.x) {
     __syncthreads();                         // every wave is done reading the slab of the previous image (and the weights are in place)
-    const bf16* xi = a.x + n * HW * 64;
-    {
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      const void* src = soff[i] >= 0 ? (const void*)(xi + soff[i]) : (const void*)c3_zero16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Sl + ((wave + 8 * i) * 64) * 16), 16, 0, 0);
+      chunk16 v = pf[i];
+      if (soff[i] < 0) v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0u;
+      *(chunk16*)(Sl + ((wave + 8 * i) * 64 + lane) * 16) = v;
     }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab; the stores of image n-2... n-1's MFMA phase are long done
     __syncthreads();
+    if (n + gridDim.x < a.N) {               // the next image's pieces: in flight under this image's 36 k-steps (wave-uniform branch)
+      const bf16* xn = a.x + (n + gridDim.x) * HW * 64;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pf[i] = ldg16(xn + (soff[i] < 0 ? 0 : soff[i]));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -197,10 +492,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
           for (int e = 0; e < 2; ++e) {
             const int g = 2 * k + e;
             float v[4] = {acc[j][i][g * 4 + 0], acc[j][i][g * 4 + 1], acc[j][i][g * 4 + 2], acc[j][i][g * 4 + 3]};
-            if (a.stats && pvalid[i]) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t) { ssum[j][g * 4 + t] += v[t]; ssq[j][g * 4 + t] += v[t] * v[t]; }
-            }
             if (a.res) {
               const uint2 r = e ? ry : rx;
               v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u); v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
@@ -213,30 +504,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
     prev = n;
   }
   issue_stores();
-  if (a.stats) {
-    // lanes sharing lane >> 5 hold the same channels for different pixels: butterfly over the 32 pixel lanes, then over the 8 waves through LDS
-    __syncthreads();
-    float* red = (float*)Sl;                 // [8 waves][2 (sum, sq)][64 channels]
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = ssum[j][r], q = ssq[j][r];
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if ((lane & 31) == 0) {
-          const int ch = j * 32 + (r >> 2) * 8 + kh2 * 4 + (r & 3);
-          red[(wave * 2 + 0) * 64 + ch] = s; red[(wave * 2 + 1) * 64 + ch] = q;
-        }
-      }
-    __syncthreads();
-    if (tid < 128) {
-      float t = 0.f;
-      for (int w = 0; w < 8; ++w) t += red[w * 128 + tid];
-      float* rep = a.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 128;
-      atomicAdd(rep + tid, t);               // [sum 64 | sumsq 64]
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -644,15 +911,23 @@ extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const voi
   static bool attr_set = false;
   const size_t lds = C3_WBYTES + C3_SBYTES;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { avec_set_error("conv3x3_c64: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    const void* kerns[3] = {(const void*)conv3x3_c64_kernel<false, false>, (const void*)conv3x3_c64_kernel<true, false>, (const void*)conv3x3_c64_res_kernel};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { avec_set_error("conv3x3_c64: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    }
     attr_set = true;
   }
   static const int wgs_env = getenv("AVEC_C3_WGS") ? atoi(getenv("AVEC_C3_WGS")) : 256;
   C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
   avec_note_kernel("conv3x3_c64_kernel");
-  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), lds, st, a);
+  // (statistics AND a residual in one launch would need 36 + 32 + 64 registers beside the accumulators: it spills, and a spilled register of an in-flight asm load is
+  // wrong code -- no caller needs the pair: forward launches carry statistics, backward-data launches the residual)
+  AVEC_CHECK_ARG(!(stats && res), "conv3x3_c64: statistics and a residual in the same launch are not supported");
+  if (stats) hipLaunchKernelGGL((conv3x3_c64_kernel<true, false>), dim3(grid), dim3(512), lds, st, a);
+  else if (res) hipLaunchKernelGGL(conv3x3_c64_res_kernel, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((conv3x3_c64_kernel<false, false>), dim3(grid), dim3(512), lds, st, a);
   AVEC_LAUNCH_CHECK();
   return 0;
 }
