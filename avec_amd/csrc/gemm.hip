@@ -536,6 +536,98 @@ __device__ __forceinline__ void conv_epilogue_tr(const GemmArgs& g, f32x16 (&acc
   }
 }
 
+// ---- register-direct epilogue of the 64 x 64 plain product (round 5): the conformer-sized launches ----
+// profiles/r04_small_gemm_anatomy.txt: of the 5.2 us such a launch lives, 1.7 go to staging 16 accumulators through LDS (16 ds_write_b32, barrier, float4 reads,
+// barrier) and 0.8 to the stores -- the K loop is 0.8.  With the product transposed (conv_epilogue_tr above) a lane owns ONE output row and, after a
+// v_permlane32_swap of four fp32 registers per 16-channel block, 2 x 8 consecutive columns of it: bias / activation / dropout / act'(z) / alpha / residual are applied
+// in registers in the order of nt_epilogue (same arithmetic, same dropout indices), every operand piece is requested before the first store, nothing touches LDS, no
+// barrier.  Column sums / BatchNorm statistics / the BatchNorm-backward fusion keep the staged epilogue (plain_tr_ok).
+__device__ __forceinline__ void swap4_f32(float (&x)[4], float (&y)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[t]), __float_as_uint(y[t]), false, false);
+    x[t] = __uint_as_float(r[0]); y[t] = __uint_as_float(r[1]);
+  }
+}
+__device__ __forceinline__ void plain_epilogue_tr(const GemmArgs& g, const f32x16& acc, const long long m0, const int n0, const int lane, const int wm, const int wn) {
+  const Epi& e = g.e;
+  const int h = lane >> 5;
+  long long row = m0 + wm * 32 + (lane & 31);
+  const bool rvalid = row < g.M; if (!rvalid) row = g.M - 1;
+  const DropKey dk = drop_key(e.rng, e.stream, e.drop_p);
+  float v[2][8]; bool cvalid[2]; int col[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float x[4], y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { x[t] = acc[8 * k + t]; y[t] = acc[8 * k + 4 + t]; }
+    swap4_f32(x, y);                          // (x, y) = (group 2k, group 2k + 1) of the accumulator layout -> columns +0..3 | +4..7 of this lane's piece
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { v[k][t] = x[t]; v[k][4 + t] = y[t]; }
+    col[k] = n0 + wn * 32 + 16 * k + 8 * h;
+    cvalid[k] = col[k] < g.N;                 // (N % 8 == 0: a piece is inside N or not at all)
+    if (!cvalid[k]) col[k] = g.N - 8;
+  }
+  // operand pieces, all requested up front
+  float4 bq[2][2]; uint4 zq[2], rb[2]; float4 rf[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (e.bias) { bq[k][0] = *(const float4*)(e.bias + col[k]); bq[k][1] = *(const float4*)(e.bias + col[k] + 4); }
+    if (e.dact) zq[k] = *(const uint4*)((const bf16*)e.dact_z + row * e.ldz + col[k]);
+    if (e.res) {
+      if (e.res_act) rb[k] = *(const uint4*)((const bf16*)e.res + row * e.ldres + col[k]);
+      else { rf[k][0] = *(const float4*)((const float*)e.res + row * e.ldres + col[k]); rf[k][1] = *(const float4*)((const float*)e.res + row * e.ldres + col[k] + 4); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float (&w)[8] = v[k];
+    if (e.bias) { w[0] += bq[k][0].x; w[1] += bq[k][0].y; w[2] += bq[k][0].z; w[3] += bq[k][0].w; w[4] += bq[k][1].x; w[5] += bq[k][1].y; w[6] += bq[k][1].z; w[7] += bq[k][1].w; }
+    const bool ok = rvalid && cvalid[k];
+    if (e.out_pre && ok)
+      *(uint4*)((bf16*)e.out_pre + row * e.ldpre + col[k]) = make_uint4(f32x2_to_bf16x2(w[0], w[1]), f32x2_to_bf16x2(w[2], w[3]), f32x2_to_bf16x2(w[4], w[5]), f32x2_to_bf16x2(w[6], w[7]));
+    if (e.act == 1) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = swishf_(w[c]);
+    } else if (e.act == 2) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = fmaxf(w[c], 0.f);
+    }
+    if (e.drop_p > 0.f) {                     // (N is even: the pair hashes of nt_epilogue's drop4)
+      const unsigned long long i0 = (unsigned long long)row * g.N + col[k];
+      float d0[4], d1[4]; drop4(dk, i0, d0); drop4(dk, i0 + 4, d1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { w[c] *= d0[c]; w[4 + c] *= d1[c]; }
+    }
+    if (e.dact) {
+      const uint32_t zz[4] = {zq[k].x, zq[k].y, zq[k].z, zq[k].w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float z = (c & 1) ? __uint_as_float(zz[c >> 1] & 0xffff0000u) : __uint_as_float(zz[c >> 1] << 16);
+        w[c] *= (e.dact == 1) ? dswishf_(z) : (z > 0.f ? 1.f : 0.f);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] *= e.alpha;
+    if (e.res) {
+      if (e.res_act) {
+        const uint32_t rr[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] += (c & 1) ? __uint_as_float(rr[c >> 1] & 0xffff0000u) : __uint_as_float(rr[c >> 1] << 16);
+      } else {
+        w[0] += rf[k][0].x; w[1] += rf[k][0].y; w[2] += rf[k][0].z; w[3] += rf[k][0].w; w[4] += rf[k][1].x; w[5] += rf[k][1].y; w[6] += rf[k][1].z; w[7] += rf[k][1].w;
+      }
+    }
+    if (ok) {
+      if (e.out_f32) {
+        float* o = (float*)e.out + row * e.ldo + col[k];
+        *(float4*)o = make_float4(w[0], w[1], w[2], w[3]); *(float4*)(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
+      } else
+        *(uint4*)((bf16*)e.out + row * e.ldo + col[k]) = make_uint4(f32x2_to_bf16x2(w[0], w[1]), f32x2_to_bf16x2(w[2], w[3]), f32x2_to_bf16x2(w[4], w[5]), f32x2_to_bf16x2(w[6], w[7]));
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int MODE, bool SRC_F32, bool A16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int VEC = Elt<T>::VEC;
@@ -1037,7 +1129,7 @@ __device__ __forceinline__ void glds16_v64(const void* gsrc, unsigned lds_dst_un
 }
 // STAGES = 4: all of K <= 256 in flight, two workgroups per CU (64 KB).  STAGES = 2 (AVEC_NT_S2): 32 KB, four workgroups per CU -- for products whose 64 x 64 tiling
 // exceeds the 512 slots of the deep ring (3200 x 1024 x 256: 800 tiles) one round of workgroups that hide each other's DMA latency instead of two rounds.
-template <int BM, int BN, int STAGES = 4>
+template <int BM, int BN, int STAGES = 4, bool TR = false>      // TR: transposed product + register-direct epilogue (plain_epilogue_tr)
 __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_ptr, const void* pa_w, long long pa_lda, long long pa_ldw, long long pa_M, int pa_N, int pa_K, int pa_ktail, GemmArgs g_unused) {
   // The leading arguments repeat the fields of `g` that the operand DMAs need (13 dwords): with the kernel-argument preload of the build they are in SGPRs when the
   // first wave starts, and the first tiles go out without waiting for the ~400-byte argument block (that block misses every cache between two
@@ -1178,6 +1270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_pt
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         if (AVEC_ABL & 1) asm volatile("" :: "v"(fa[q][i]), "v"(fb[q])); else
+        if (TR) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[q]), __builtin_bit_cast(bf16x8_t, fa[q][i]), acc[i][0], 0, 0, 0); else
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[q][i]), __builtin_bit_cast(bf16x8_t, fb[q]), acc[i][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1190,8 +1283,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_plain_kernel(const void* pa_pt
     if (STAGES > 2 && kt + 3 < KT) step(kt + 3, IntC<3 % STAGES>{});
   }
 #undef AVEC_WAIT_VM
-  __syncthreads();                            // every wave is done with the ring before the epilogue reuses the LDS
-  nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, 0);
+  if constexpr (TR) {
+    static_assert(BM == 64 && BN == 64, "register-direct epilogue: 64 x 64 tiles");
+    plain_epilogue_tr(g, acc[0][0], m0, n0, lane, wm, wn);
+  } else {
+    __syncthreads();                          // every wave is done with the ring before the epilogue reuses the LDS
+    nt_epilogue<T, BM, BN, MT, NT>(g, acc, smem, m0, n0, tid, lane, wm, wn, 0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1881,6 +1979,16 @@ static bool epi_tr_ok(const GemmArgs& g) {
          e.ldo % 8 == 0 && aligned16(e.out) && (!e.res || (e.res_act && e.ldres % 8 == 0 && aligned16(e.res)));
 }
 
+// register-direct epilogue of the plain 64 x 64 product: whole 8-column pieces, 16-byte aligned rows of every operand, no column reduction.  AVEC_NO_PLAIN_TR=1: off
+static bool plain_tr_ok(const GemmArgs& g) {
+  static const bool off = getenv("AVEC_NO_PLAIN_TR") != nullptr || getenv("AVEC_NO_EPI_TR") != nullptr;
+  const Epi& e = g.e;
+  const long long ob = e.out_f32 ? 4 : 2;
+  return !off && !e.colsum && !e.stats && !e.bnb_y && g.N % 8 == 0 && g.N >= 8 && aligned16(e.out) && (e.ldo * ob) % 16 == 0 &&
+         (!e.out_pre || (aligned16(e.out_pre) && e.ldpre % 8 == 0)) && (!e.bias || aligned16(e.bias)) && (!e.dact || (aligned16(e.dact_z) && e.ldz % 8 == 0)) &&
+         (!e.res || (aligned16(e.res) && (e.ldres * (e.res_act ? 2 : 4)) % 16 == 0));
+}
+
 template <typename T, int BM, int BN>
 static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream_t st) {
   GemmArgs g = g_in;
@@ -1930,13 +2038,26 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
       // two-stage ring for products with more than 512 tiles (the slots of the deep ring) and at most 6 K tiles: 3200 x 1024 x 256 + Swish 10.4 -> 8.2 us,
       // 3200 x 768 x 256 8.9 -> 6.4 us, 1600 x 1440 x 360 11.7 -> 9.4 us; step 19.31 -> 19.18 ms (tools/gpu/r4_s2.sh; with 256: no further gain).  AVEC_NT_S2=0: off
       static const int s2_min = getenv("AVEC_NT_S2") ? atoi(getenv("AVEC_NT_S2")) : 512;
+      const bool tr = plain_tr_ok(g);
       if (s2_min > 0 && (long long)grid.x * grid.y > s2_min && !g.ktail && g.K <= 384) {
         const size_t l2s = (size_t)2 * (BM + BN) * 128 > epi_lds ? (size_t)2 * (BM + BN) * 128 : epi_lds;
+        if (tr) {
+          const size_t lt = (size_t)2 * (BM + BN) * 128;
+          avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2,tr>", BM, BN);
+          if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2, true>, lt)) return r;
+          hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2, true>), grid, dim3(256), lt, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
+        }
         avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2>", BM, BN);
         if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2>, l2s)) return r;
         hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
       }
       const size_t l2 = (size_t)4 * (BM + BN) * 128 > epi_lds ? (size_t)4 * (BM + BN) * 128 : epi_lds;
+      if (tr) {
+        const size_t lt = (size_t)4 * (BM + BN) * 128;
+        avec_note_kernel("gemm_nt_plain_kernel<%d,%d,4,tr>", BM, BN);
+        if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 4, true>, lt)) return r;
+        hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 4, true>), grid, dim3(256), lt, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
+      }
       avec_note_kernel("gemm_nt_plain_kernel<%d,%d,4>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
       hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;

@@ -139,3 +139,79 @@ def test_stride2_conv_register_direct_epilogue_matches_torch(Nimg, H, Cin, Cout,
             assert float((dx0.float().cpu() - want0).abs().max()) < 0.02 * float(want0.abs().max()) + 1e-3
     finally:
         avec_amd.set_compute_dtype("f32")
+
+
+_PLAIN_TR = r'''
+import sys, os, torch
+sys.path.insert(0, %r)
+import avec_amd
+from avec_amd import ops, runtime as rt
+from avec_amd.lib import lib, ACT_NONE, ACT_RELU, ACT_SWISH
+avec_amd.set_compute_dtype("bf16")
+avec_amd.manual_seed(77)
+d = torch.device("cuda:0"); adt = torch.bfloat16
+def last():
+    n = lib.raw("avec_last_kernel")(); return n if isinstance(n, str) else n.decode()
+want_tr = os.environ.get("AVEC_NO_PLAIN_TR") is None
+out = {}
+swish = lambda t: t * torch.sigmoid(t)
+dswish = lambda t: torch.sigmoid(t) * (1 + t * (1 - torch.sigmoid(t)))
+# (M, N, K): ragged last row tile, column counts that are not multiples of 64 (partial column tiles, 8-column pieces), K with a partial last tile and K = 8n + 4
+for ci, (M, N, K) in enumerate([(3200, 256, 256), (3187, 360, 1440), (1600, 1440, 360), (130, 72, 200), (3200, 1024, 256), (777, 256, 180)]):
+    g = torch.Generator().manual_seed(100 + ci)
+    A = torch.randn(M, K, generator=g).to(adt); W = (torch.randn(N, K, generator=g) / K ** 0.5).to(adt)
+    bias = torch.randn(N, generator=g); resf = torch.randn(M, N, generator=g); resb = torch.randn(M, N, generator=g).to(adt); z = torch.randn(M, N, generator=g).to(adt)
+    prod = A.float() @ W.float().t()
+    Ad, Wd = A.to(d), W.to(d)
+    def run(tag, ref, **kw):
+        f32 = kw.get("out_f32", False)
+        o = torch.full((M + 2, N), float("nan"), device=d, dtype=torch.float32 if f32 else adt)
+        ops.gemm_nt(Ad, Wd, o, M, N, K, **kw)
+        k = last(); torch.cuda.synchronize()
+        assert ("plain" in k) and (k.endswith(",tr>") == want_tr), (tag, k)
+        assert torch.isnan(o[M:].float()).all(), tag
+        got = o[:M].float().cpu()
+        if ref is not None:
+            e = float((got - ref).norm() / ref.norm())
+            assert e < (1e-4 if f32 else 4e-3), (tag, M, N, K, e)
+            assert float((got - ref).abs().max()) < (2e-3 if f32 else 0.02) * float(ref.abs().max()) + 1e-3, (tag, M, N, K)
+        out["%%d_%%s" %% (ci, tag)] = got
+        return o
+    run("plain_bf16", prod)
+    run("bias_f32res_f32out", prod + bias + resf, bias=bias.to(d), res=resf.to(d), out_f32=True)
+    pre = torch.full((M, N), float("nan"), device=d, dtype=adt)
+    run("bias_swish_pre", swish(prod + bias), bias=bias.to(d), act=ACT_SWISH, out_pre=pre)
+    torch.cuda.synchronize()
+    assert float((pre.float().cpu() - (prod + bias)).norm() / (prod + bias).norm()) < 4e-3
+    out["%%d_pre" %% ci] = pre.float().cpu()
+    run("relu_alpha_bf16res", 0.5 * torch.relu(prod) + resb.float(), act=ACT_RELU, alpha=0.5, res=resb.to(d), res_act=True)
+    run("dswish_f32out", prod * dswish(z.float()), dact_z=z.to(d), dact=1, out_f32=True)
+    run("drelu", prod * (z.float() > 0).float(), dact_z=z.to(d), dact=2)
+    # dropout: the mask is a function of (seed, stream id, element index) only -> identical in both epilogues; against the reference: kept elements are scaled by 1 / (1 - p)
+    o = run("dropout", None, bias=bias.to(d), drop_p=0.25, sid=5, out_f32=True)
+    got = o[:M].float().cpu(); full = prod + bias
+    kept = got != 0
+    assert 0.70 < float(kept.float().mean()) < 0.80
+    assert float((got[kept] - full[kept] / 0.75).abs().max()) < 2e-3 * float(full.abs().max()) + 1e-3
+torch.save(out, sys.argv[1])
+print("OK")
+''' % ROOT
+
+
+def test_plain_product_register_direct_epilogue(tmp_path):
+    """gemm_nt_plain_kernel<64,64,*,tr> (transposed product + plain_epilogue_tr: the conformer's Linear / pointwise-convolution launches, nnet/layers.py:31-60) against
+    fp32 math on the same bf16 operands for every fused epilogue it takes (bias, Swish / ReLU, pre-activation copy, dropout, act'(z), alpha, fp32 and bf16 residual,
+    fp32 and bf16 output; ragged row tiles, partial column tiles, partial last K tile, K = 8n + 4): 4e-3 relative L2 for bf16 outputs, 1e-4 for fp32 outputs -- and
+    against the staged epilogue of the same kernel (AVEC_NO_PLAIN_TR=1, read once per process: two subprocesses): same arithmetic in the same order, so every
+    output, dropout masks included, is bit-identical"""
+    script = tmp_path / "run.py"
+    script.write_text(_PLAIN_TR)
+    res = {}
+    for name, env in (("tr", {}), ("staged", {"AVEC_NO_PLAIN_TR": "1"})):
+        f = tmp_path / (name + ".pt")
+        r = subprocess.run([sys.executable, str(script), str(f)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "OK" in r.stdout, name + ": " + r.stdout[-1500:] + r.stderr[-3000:]
+        res[name] = torch.load(f)
+    assert set(res["tr"]) == set(res["staged"])
+    for k in res["tr"]:
+        assert torch.equal(res["tr"][k], res["staged"][k]), (k, float((res["tr"][k] - res["staged"][k]).abs().max()))
