@@ -297,7 +297,7 @@ def _launch_pending(q, part=None):
             chunk = q.tn[i:i + TN_GROUP_MAX]
             lib.gemm_tn_grouped(BF16, (TnItem * len(chunk))(*chunk), len(chunk), rt.stream())
         if ev is not None:
-            KERNEL_TIMER.stop(ev, (1, ROWS_PLAIN), q.flops)
+            KERNEL_TIMER.stop(ev, (1, ROWS_PLAIN), q.flops, sum(2.0 * it.M * (it.I + it.J) + 4.0 * it.I * it.J for it in q.tn))      # P, Q once (bf16) + dW once (fp32)
         q.tn, q.flops = [], 0.0
     if q.ln and part in (None, "ln"):
         for i in range(0, len(q.ln), LN_GROUP_MAX):

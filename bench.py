@@ -261,6 +261,16 @@ def main():
         eager_ms = 1000 * (time.perf_counter() - te0) / timed_steps      # eager, single-stream, event-instrumented step: an upper bound of the eager fallback's cost
         ops.KERNEL_TIMER.enabled = False
         rt.set_branch_streams(os.environ.get("AVEC_BRANCH_STREAMS", "1") != "0")
+        # what a capture fallback would cost: the same step as plain launches, two streams, no instrumentation (the data-parallel path drops to this on every rank when
+        # one rank cannot capture)
+        for _ in range(2):
+            model.train_step(inputs, targets, precision=precision)
+        barrier()
+        te1 = time.perf_counter()
+        for _ in range(timed_steps):
+            model.train_step(inputs, targets, precision=precision)
+        barrier()
+        eager2_ms = 1000 * (time.perf_counter() - te1) / timed_steps
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -289,7 +299,12 @@ def main():
                                    "batch %d/GPU, audio 63840 samples (400 mel frames), video 100x88x88, 20 labels; dropout 0.1 + SpecAugment on" % args.batch,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "step_path": step_path, "fallback": fallback, "syncbn_exchange": ("peer-write kernels over xGMI" if (world > 1 and peer.active() is not None) else ("torch.distributed" if world > 1 else None)), "params": 61738836, "loss": round(loss, 4),
                        "model_mfma_util": round(value * GFLOP_PER_UTT / 1e3 / peak, 5),
-                       "eager_instrumented_ms_per_step": (round(eager_ms, 2) if not args.no_kernel_timing else None)},
+                       "eager_instrumented_ms_per_step": (round(eager_ms, 2) if not args.no_kernel_timing else None),
+                       "eager_two_stream_ms_per_step": (round(eager2_ms, 2) if not args.no_kernel_timing else None),
+                       "notes": "parity: every module against fixtures generated from the reference (tests/golden); the mel front-end is pinned to a restatement of "
+                                "torchaudio's documented MelSpectrogram defaults only (torchaudio is not part of /root/reference: tests/golden/ref_shims.py). "
+                                "roofline.rows come from the eager single-stream leg (event pairs cannot be recorded inside a graph): grouped weight-gradient launches "
+                                "are cut by queue length there (7 launches) and by stream in the graph (8)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
