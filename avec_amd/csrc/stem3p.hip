@@ -13,6 +13,7 @@
 // input rows it needs are fetched by LDS-DMA (global_load_lds, 16 B per lane) into rows of [8 zero px | W px | 8 zero px] -- every chunk is 16-byte aligned on both
 // sides, the left / right zero padding is a chunk sourced from a zero page.  Reduction order k = (kd, kh, slot), slot 0 = zero weight, slot 1..7 = kw 0..6: the 8
 // operand elements of output pixel ow are the 8 consecutive staged pixels 2*ow - 4 .. 2*ow + 3 (four aligned 32-bit LDS reads), weights live in registers.
+#include <type_traits>
 #include "vec.h"
 #include "avec_hip.h"
 
@@ -607,6 +608,289 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_kernel(const bf16* __restric
   }
 }
 
+template <int PITCH_CT>
+__global__ __launch_bounds__(512) void stem3p_wgrad_roles_kernel(const bf16* __restrict__ vb, const bf16* __restrict__ wsh, const float* __restrict__ bias, const bf16* __restrict__ dpm,
+                                                            const unsigned char* __restrict__ idx, const float* __restrict__ ss, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dstats, const float* count_ptr, float count, float* dw, float* dgamma, float* dbeta,
+                                                            S3P G, S3W Q, ColWs ws, int abl) {
+  extern __shared__ __attribute__((aligned(16))) char s3[];
+  char* const slab = s3;                                            // [6 slots][SLOT]: rows of pitch bytes, SH rows per frame
+  char* const dpl = slab + 6 * Q.SLOT;                              // [2][DPB]: pooled gradients (masked) of the band's pn + 1 pooled rows, [row][pw][64] bf16
+  char* const ixl = dpl + 2 * Q.DPB;                                // [2][IXB]: their window slots, [row][pw][64] u8
+  char* const tiles = ixl + 2 * Q.IXB;                              // [2][128 px][64 ch] bf16, chunk c of row m at slot c ^ (4 * ((m >> 1) & 1))
+  const int pitch = PITCH_CT ? PITCH_CT : G.pitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, pl = lane & 31;
+  // Round 5: two wave ROLES instead of eight waves walking through conv -> barrier -> stage 2 -> barrier -> product together (ablation: the three parts take 272 / 314 /
+  // 247 us of 1002 and ADD UP -- the barriers serialise an MFMA phase, a VALU phase and another MFMA phase).  Waves 0-3 (producers) each own 32 pixels of a tile over
+  // all 64 channels: recomputed convolution (both weight halves in registers) -> z^T rows in LDS -> stage 2 on their OWN rows (a wave-local dependency: no barrier);
+  // waves 4-7 (consumers) each own 64 taps x 64 channels of the weight gradient and multiply the tile the producers finished one barrier ago.  One barrier per tile;
+  // a SIMD holds one wave of each role, so the producers' VALU phase runs under the consumers' MFMAs.
+  const bool producer = wave < 4;
+  const int pgp = wave & 3;                                         // producer: pixel group; consumer: tap group pair
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)s3;
+  if (blockIdx.x == 0 && dgamma && tid < S3P_C) { atomicAdd(dgamma + tid, dstats[S3P_C + tid]); atomicAdd(dbeta + tid, dstats[tid]); }
+  if (tid < S3P_C) {
+    float* const cst0 = (float*)(ixl + 2 * Q.IXB + 2 * 16384);
+    const float inv_n0 = 1.f / (count_ptr ? *count_ptr : count);
+    const float rs = ss[3 * S3P_C + tid];
+    cst0[tid] = gamma[tid] * rs; cst0[64 + tid] = dstats[tid] * inv_n0; cst0[128 + tid] = dstats[S3P_C + tid] * inv_n0 * rs; cst0[192 + tid] = ss[2 * S3P_C + tid] - (bias ? bias[tid] : 0.f);
+  }
+  __syncthreads();
+  // Each role's state lives inside ITS instantiation of the main loop: declared at kernel scope, the producers' 144 weight registers and the consumers' 64
+  // accumulators are both live everywhere (the compiler cannot tell that `wave < 4` is the same condition at every use) and spill.
+  auto role_main = [&](auto prodc) {
+  constexpr bool PROD = decltype(prodc)::value;
+  // ---- conv part: weights of all 64 channels (MFMA A operand: row = channel) ----
+  chunk16 wf[18][2];
+  if constexpr (PROD) {
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[s][j] = ldg16(wsh + (long long)(32 * j + pl) * 288 + (2 * s + g) * 8);
+  }
+  // ---- wgrad part: accumulators (this lane's tap x 64 channels), transposed-read offsets of the dz tile ----
+  f32x16 acc[2][2];                                                 // consumer: [tap group][channel half]
+  if constexpr (!PROD) {
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tg][j][r] = 0.f;
+  }
+  int tkd[2], toff[2];                                              // tap -> frame offset kd and byte offset inside a frame slot (row kh, element kw + 1 behind the 8-byte left pad, rows 2 g, 2 g + 1 of the step)
+#pragma unroll
+  for (int tg = 0; tg < 2; ++tg) { const int k = 64 * pgp + 32 * tg + pl; const int r = k / 7 > 34 ? 34 : k / 7; tkd[tg] = r / 7; toff[tg] = (r % 7) * pitch + (k % 7 + 1) * 2 + 8 + g * 4 * pitch; }
+  int eoff[8];                                                      // (generic pitch) offsets of the lane's 8 pixels inside a step
+#pragma unroll
+  for (int e = 0; e < 8; ++e) eoff[e] = (e >> 2) * 2 * pitch + (e & 3) * 4;
+  const int g4 = lane >> 4, t16 = lane & 15;
+  int offb[2][2];
+#pragma unroll
+  for (int hh2 = 0; hh2 < 2; ++hh2) {
+    const int row = 8 * (g4 >> 1) + 4 * hh2 + (t16 >> 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int cb = 32 * j + 16 * (g4 & 1); offb[j][hh2] = row * 128 + ((((cb >> 3) + ((t16 & 3) >> 1)) ^ (4 * ((row >> 1) & 1))) << 4) + (t16 & 1) * 8; }
+  }
+  // ---- stage-2 constants of this thread's 8 channels: dz = A (dr - B - (acc - mu') Cc),  mu' = mean - bias ----
+  const int cg = tid & 7;
+  // (the four per-channel constants live in LDS -- cst[4][64] behind the tiles, written once by the first 64 threads -- and are fetched at the start of every stage 2:
+  // 32 registers the convolution part, which holds 144 weight registers, does not have)
+  float* const cst = (float*)(tiles + 2 * 16384);
+  const int trow = 32 * pgp + pl;                                   // conv part: this lane's row of a tile = step 2 pgp + (pl >> 4), k = pl & 15
+  const int tsw = 4 * ((trow >> 1) & 1);
+  const int ck = pl & 15, crho = ck >> 2, ckap = ck & 3, cstep = 2 * pgp + (pl >> 4);
+  // stage 2: task u of wave w handles the 8 tile rows of parity class c (row parity rp, column parity cp) in steps 2 q, 2 q + 1; the classes of a wave's two tasks are
+  // complementary ((0,0) + (1,1): 1 + 4 candidate windows, (0,1) + (1,0): 2 + 2), so every wave does about the same work and the window loops are wave-uniform
+  const int ncg = G.OW >> 2;
+
+  // one frame slot: chunk q = tid (SLOT = 512 chunks >= SH * CPR) <- input row ir0 + q / CPR of frame `itf`, chunk q % CPR (zero page: padding chunks, rows outside the frame)
+  auto dma_frame = [&](long long clip, int itf, int ir0, int slot) {
+    const int row = tid / G.CPR, j = tid - row * G.CPR; const int ih = ir0 + row;
+    const bool ok = row < G.SH && itf >= 0 && itf < G.T3 && ih >= 0 && ih < G.H && j >= 1 && j <= G.CPR - 2;
+    const void* sp = ok ? (const void*)(vb + ((clip * G.T3 + itf) * (long long)G.H + ih) * G.W + (j - 1) * 8) : (const void*)s3p_zero16;
+    s3p_glds16(sp, lds0 + slot * Q.SLOT + wave * 1024);
+  };
+  // the band's pooled rows ph0 .. ph0 + pn of frame cf: contiguous in memory; rows beyond PH come from the zero page
+  auto dma_pooled = [&](long long cf, int ph0, int buf) {
+    const int nrow = G.pn + 1;
+    const long long dp0 = ((cf * G.PH + ph0) * (long long)G.PW) * S3P_C;     // element offset of the first pooled pixel (bf16 / u8 alike)
+    const int valid_px = (min(G.PH, ph0 + nrow) - ph0) * G.PW;
+    for (int q0 = wave * 64; q0 < Q.DPB / 16; q0 += 512) {          // 8 chunks of 16 B per pooled pixel
+      const int q = q0 + lane;
+      const void* sp = (q >> 3) < valid_px ? (const void*)(dpm + dp0 + (long long)q * 8) : (const void*)s3p_zero16;
+      s3p_glds16(sp, lds0 + 6 * Q.SLOT + buf * Q.DPB + q0 * 16);
+    }
+    for (int q0 = wave * 64; q0 < Q.IXB / 16; q0 += 512) {          // 4 chunks per pooled pixel
+      const int q = q0 + lane;
+      const void* sp = (q >> 2) < valid_px ? (const void*)(idx + dp0 + (long long)q * 16) : (const void*)s3p_zero16;
+      s3p_glds16(sp, lds0 + 6 * Q.SLOT + 2 * Q.DPB + buf * Q.IXB + q0 * 16);
+    }
+  };
+
+  for (long long unit = blockIdx.x; unit < Q.units; unit += gridDim.x) {
+    const int chunk = (int)(unit % Q.NCH); const int band = (int)((unit / Q.NCH) % G.NB); const long long clip = unit / ((long long)Q.NCH * G.NB);
+    const int f0 = chunk * Q.CH, f1 = min(G.T3, f0 + Q.CH);
+    const int ph0 = band * G.pn; const int pnb = min(G.pn, G.PH - ph0);
+    const int cr0 = 2 * ph0, cr1 = min(G.OH - 1, 2 * (ph0 + pnb) - 1);
+    const int ncr = cr1 - cr0 + 1, NS = ((ncr + 3) >> 2) * ncg, ntile = (NS + 7) >> 3;
+    const int ir0 = 2 * cr0 - 3;
+    __syncthreads();                                                // the previous unit is done with every buffer (nothing is in flight: it ended with vmcnt(0))
+#pragma unroll 1
+    for (int d = -2; d <= 2; ++d) { int sl = (f0 + d) % 6; if (sl < 0) sl += 6; dma_frame(clip, f0 + d, ir0, sl); }
+    dma_pooled(clip * G.T3 + f0, ph0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int f = f0; f < f1; ++f) {
+      const long long cf = clip * G.T3 + f;
+      const int pb = (f - f0) & 1;
+      if (f + 1 < f1 && !(abl & 8)) { dma_frame(clip, f + 3, ir0, (f + 3) % 6); dma_pooled(cf + 1, ph0, pb ^ 1); }      // one frame ahead (their buffers were last read in frame f - 1)
+      int fb[5];                                                    // byte offset of the slot of frame f + kd - 2
+#pragma unroll
+      for (int kd = 0; kd < 5; ++kd) { int sl = (f + kd - 2) % 6; if (sl < 0) sl += 6; fb[kd] = sl * Q.SLOT; }
+      const char* dpb = dpl + pb * Q.DPB; const char* ixb = ixl + pb * Q.IXB;
+
+      auto conv_tile = [&](int t) {                                 // raw z^T of tile t -> tiles[t & 1]
+        int S = 8 * t + cstep; if (S >= NS) S = 0;
+        const int R = S / ncg, Cg = S - R * ncg;
+        const char* pix = slab + (2 * (4 * R + crho)) * pitch + 4 * (4 * Cg + ckap) + 8;
+        f32x16 z[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { z[0][r] = 0.f; z[1][r] = 0.f; }
+        chunk16 fa[18];
+        auto ldfrag = [&](int s) {
+          const int ra = 2 * s > 34 ? 34 : 2 * s, rb_ = 2 * s + 1 > 34 ? 34 : 2 * s + 1;
+          const int offA = fb[ra / 7] + (ra % 7) * pitch, offB = fb[rb_ / 7] + (rb_ % 7) * pitch;
+          const uint32_t* rp = (const uint32_t*)(pix + (g ? offB : offA));
+          chunk16 fr; fr.w[0] = rp[0]; fr.w[1] = rp[1]; fr.w[2] = rp[2]; fr.w[3] = rp[3]; return fr;
+        };
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fa[s] = ldfrag(s);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+          if (s + 4 < 18) fa[s + 4] = ldfrag(s + 4);
+          asm volatile("" ::: "memory");
+          asm volatile("" : "+v"(fa[s].w[0]), "+v"(fa[s].w[1]), "+v"(fa[s].w[2]), "+v"(fa[s].w[3]));      // (the use stays below the requests of step s + 4)
+          z[0] = s3p_mma(wf[s][0], fa[s], z[0]);
+          z[1] = s3p_mma(wf[s][1], fa[s], z[1]);
+        }
+        char* tw = tiles + (t & 1) * 16384 + trow * 128;
+#pragma unroll
+        for (int chh = 0; chh < 2; ++chh)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)                               // channels 32 chh + 8 a + 4 g .. + 3 = half g of chunk 4 chh + a
+            *(uint2*)(tw + (((4 * chh + a) ^ tsw) << 4) + 8 * g) = make_uint2(f32x2_to_bf16x2(z[chh][4 * a], z[chh][4 * a + 1]), f32x2_to_bf16x2(z[chh][4 * a + 2], z[chh][4 * a + 3]));
+      };
+
+      auto stage2 = [&](int t) {                                    // tiles[t & 1]: z -> dz in place (rows beyond the band: zero)
+        char* tb = tiles + (t & 1) * 16384;
+        float cA[8], cB[8], cC[8], cMu[8];
+        { const float4* c4 = (const float4*)(cst + cg * 8);
+          const float4 a0 = c4[0], a1 = c4[1], b0 = c4[16], b1 = c4[17], c0 = c4[32], c1 = c4[33], m0 = c4[48], m1 = c4[49];
+          cA[0] = a0.x; cA[1] = a0.y; cA[2] = a0.z; cA[3] = a0.w; cA[4] = a1.x; cA[5] = a1.y; cA[6] = a1.z; cA[7] = a1.w;
+          cB[0] = b0.x; cB[1] = b0.y; cB[2] = b0.z; cB[3] = b0.w; cB[4] = b1.x; cB[5] = b1.y; cB[6] = b1.z; cB[7] = b1.w;
+          cC[0] = c0.x; cC[1] = c0.y; cC[2] = c0.z; cC[3] = c0.w; cC[4] = c1.x; cC[5] = c1.y; cC[6] = c1.z; cC[7] = c1.w;
+          cMu[0] = m0.x; cMu[1] = m0.y; cMu[2] = m0.z; cMu[3] = m0.w; cMu[4] = m1.x; cMu[5] = m1.y; cMu[6] = m1.z; cMu[7] = m1.w; }
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {                               // the four parity classes of this producer's own 32 rows (steps 2 pgp, 2 pgp + 1)
+          const int c = u; const int rp = c >> 1, cp = c & 1;       // (wave-uniform)
+          const int q = pgp;
+          const int j = lane >> 3;
+          const int s = 2 * q + (j >> 2), rho = rp + 2 * ((j >> 1) & 1), kap = cp + 2 * (j & 1);
+          const int row = 16 * s + 4 * rho + kap;
+          const int S = 8 * t + s; const int R = S / ncg, Cg = S - R * ncg;
+          const int hl = 4 * R + rho, w = 4 * Cg + kap; const int h = cr0 + hl;
+          const bool pv = S < NS && hl < ncr;
+          char* zp_ = tb + row * 128 + ((cg ^ (4 * ((row >> 1) & 1))) << 4);
+          float o[8];
+          if (pv) {
+            // candidate windows: rows oh = h >> 1 (slot kh = 1 + rp) and, for odd h, oh + 1 (kh = 0); likewise for columns
+            const int ohA = h >> 1, owA = w >> 1;
+            float dr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dr[e] = 0.f;
+            for (int a = 0; a <= rp; ++a)
+              for (int b = 0; b <= cp; ++b) {
+                const int oh = ohA + a, ow_ = owA + b;
+                const bool ok = oh < G.PH && ow_ < G.PW;
+                const unsigned slotq = (unsigned)((a ? 0 : 1 + rp) * 3 + (b ? 0 : 1 + cp));
+                const int lp = ok ? ((oh - ph0) * G.PW + ow_) : 0;
+                const uint2 sel = *(const uint2*)(ixb + lp * 64 + cg * 8);
+                const uint4 gq = *(const uint4*)(dpb + lp * 128 + cg * 16); const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const unsigned sq = ((e < 4 ? sel.x : sel.y) >> (8 * (e & 3))) & 255u;
+                  const float gv = (e & 1) ? __uint_as_float(gw[e >> 1] & 0xffff0000u) : __uint_as_float(gw[e >> 1] << 16);
+                  if (ok && sq == slotq) dr[e] += gv;
+                }
+              }
+            const uint4 tz = *(const uint4*)zp_; const uint32_t wv[4] = {tz.x, tz.y, tz.z, tz.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float zl = __uint_as_float(wv[e] << 16), zh = __uint_as_float(wv[e] & 0xffff0000u);
+              o[2 * e] = cA[2 * e] * (dr[2 * e] - cB[2 * e] - (zl - cMu[2 * e]) * cC[2 * e]);
+              o[2 * e + 1] = cA[2 * e + 1] * (dr[2 * e + 1] - cB[2 * e + 1] - (zh - cMu[2 * e + 1]) * cC[2 * e + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+          }
+          *(uint4*)zp_ = make_uint4(f32x2_to_bf16x2(o[0], o[1]), f32x2_to_bf16x2(o[2], o[3]), f32x2_to_bf16x2(o[4], o[5]), f32x2_to_bf16x2(o[6], o[7]));
+        }
+      };
+
+      auto wgrad_tile = [&](int t) {                                // D += A^T x dz of tiles[t & 1]
+        const char* tb = tiles + (t & 1) * 16384;
+        const char* gb[2] = {slab + fb[tkd[0]] + toff[0], slab + fb[tkd[1]] + toff[1]};      // this lane's taps (and row pair 2 g) at pixel (0, 0) of the band
+        const int S0 = 8 * t; int R = S0 / ncg, Cg = S0 - R * ncg;  // (wave-uniform: scalar registers)
+        uint32_t gl[2][2][8];
+        auto gather = [&](int s, uint32_t (&o)[2][8]) {
+          int Rs = R, Cs = Cg + s; while (Cs >= ncg) { Cs -= ncg; ++Rs; }
+          const int so = Rs * 8 * pitch + Cs * 16;
+#pragma unroll
+          for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[tg][e] = *(const unsigned short*)(gb[tg] + so + (PITCH_CT ? (e >> 2) * 2 * PITCH_CT + (e & 3) * 4 : eoff[e]));
+        };
+        const int nst = min(8, NS - S0);
+        gather(0, gl[0]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {                               // 16 pixels per step: this lane's 8 = rows 2 g, 2 g + 1 x 4 columns
+          if (s < nst) {
+            const char* db = tb + (16 * s) * 128;
+            const chunk16 fb0 = s3p_tr8(db + offb[0][0], db + offb[0][1]), fb1 = s3p_tr8(db + offb[1][0], db + offb[1][1]);
+            if (s + 1 < 8 && s + 1 < nst) gather(s + 1, gl[(s + 1) & 1]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(gl[s & 1][tg][e]));      // (packing stays below the next step's requests: one LDS round trip per step, not per pair)
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+              chunk16 fa2;
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) fa2.w[e >> 1] = gl[s & 1][tg][e] | (gl[s & 1][tg][e + 1] << 16);
+              acc[tg][0] = s3p_mma(fa2, fb0, acc[tg][0]); acc[tg][1] = s3p_mma(fa2, fb1, acc[tg][1]);
+            }
+          }
+        }
+      };
+
+      auto produce = [&](int t) {
+        if (!(abl & 1)) conv_tile(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's own rows: stage 2 reads what the same wave just wrote
+        if (!(abl & 2)) stage2(t);
+      };
+      if constexpr (PROD) produce(0);
+      S3P_BAR();
+      for (int t = 0; t < ntile; ++t) {
+        if constexpr (PROD) { if (t + 1 < ntile) produce(t + 1); }
+        else { if (!(abl & 4)) wgrad_tile(t); }
+        S3P_BAR();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next frame's slab slot and pooled band have landed
+      S3P_BAR();
+    }
+  }
+  // D[k][c] -> dw[c][245] (fp32): through the workspace partial ([64][245] per workgroup) or atomics
+  {
+    float* mine = ws.partial ? ws_slot(ws, 0, blockIdx.x, gridDim.x, S3P_C * 245) : nullptr;
+    if constexpr (!PROD) {
+#pragma unroll
+      for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = 64 * pgp + 32 * tg + (r & 3) + 8 * (r >> 2) + 4 * g, c = 32 * j + pl;
+            if (k < 245) { if (mine) mine[c * 245 + k] = acc[tg][j][r]; else atomicAdd(dw + c * 245 + k, acc[tg][j][r]); }
+          }
+    }
+  }
+  };
+  if (producer) role_main(std::integral_constant<bool, true>{}); else role_main(std::integral_constant<bool, false>{});
+}
+
 // BatchNorm-backward statistics over the pooled domain with the ReLU mask taken from the pooled winner itself: live = scale * zp + shift > 0.
 //   dstats[c] += sum d, dstats[C + c] += sum d * (zp - mean) * rstd,  d = live ? dp : 0;  dp is overwritten with d (the routing of stem3p_dz_kernel then needs no mask)
 __global__ __launch_bounds__(256) void stem3p_reduce_kernel(bf16* __restrict__ dp, const bf16* __restrict__ zp, const float* __restrict__ ss, float* dstats, long long P, int C, ColWs ws) {
@@ -722,7 +1006,24 @@ extern "C" int avec_stem3p_wgrad(const void* video_bf16, const void* w_shadow, c
   ColWs ws = avec_reduce_ws((size_t)nb * S3P_C * 245, st);
   avec_note_kernel("stem3p_wgrad_kernel");
   static const int abl = getenv("AVEC_S3W_ABL") ? atoi(getenv("AVEC_S3W_ABL")) : 0;      // kernel ablation (measurement only): 1 no conv part, 2 no stage 2, 4 no weight-gradient part, 8 no DMA prefetch
-  if (G.pitch == 208)      // (W = 88: the gather offsets of a step are instruction immediates)
+  static const bool roles = getenv("AVEC_S3W_ROLES") == nullptr || atoi(getenv("AVEC_S3W_ROLES")) != 0;      // producer / consumer wave roles (round 5); 0: the eight-wave lockstep kernel
+  if (roles) {
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute((const void*)stem3p_wgrad_roles_kernel<208>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem3p_wgrad_roles_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { avec_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+      attr2 = true;
+    }
+    const size_t lw2 = lw + 1024;             // + the stage-2 constant table
+    AVEC_CHECK_ARG(lw2 <= 160 * 1024, "stem3p_wgrad: LDS");
+    if (G.pitch == 208)
+      hipLaunchKernelGGL(stem3p_wgrad_roles_kernel<208>, dim3(nb), dim3(512), lw2, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
+                         dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
+    else
+      hipLaunchKernelGGL(stem3p_wgrad_roles_kernel<0>, dim3(nb), dim3(512), lw2, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
+                         dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
+  } else if (G.pitch == 208)      // (W = 88: the gather offsets of a step are instruction immediates)
     hipLaunchKernelGGL(stem3p_wgrad_kernel<208>, dim3(nb), dim3(512), lw, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
                        dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
   else
