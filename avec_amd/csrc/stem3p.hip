@@ -425,6 +425,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_kernel(const bf16* __restric
   // stage 2: task u of wave w handles the 8 tile rows of parity class c (row parity rp, column parity cp) in steps 2 q, 2 q + 1; the classes of a wave's two tasks are
   // complementary ((0,0) + (1,1): 1 + 4 candidate windows, (0,1) + (1,0): 2 + 2), so every wave does about the same work and the window loops are wave-uniform
   const int ncg = G.OW >> 2;
+  const unsigned ncg_m = ((1u << 20) + (unsigned)ncg - 1u) / (unsigned)ncg;      // S / ncg = (S * ncg_m) >> 20 for the step indices of a band (S < 4096, ncg <= 64: exact) -- a per-lane integer division is ~35 VALU instructions
 
   // one frame slot: chunk q = tid (SLOT = 512 chunks >= SH * CPR) <- input row ir0 + q / CPR of frame `itf`, chunk q % CPR (zero page: padding chunks, rows outside the frame)
   auto dma_frame = [&](long long clip, int itf, int ir0, int slot) {
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_kernel(const bf16* __restric
 
       auto conv_tile = [&](int t) {                                 // raw z^T of tile t -> tiles[t & 1]
         int S = 8 * t + cstep; if (S >= NS) S = 0;
-        const int R = S / ncg, Cg = S - R * ncg;
+        const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
         const char* pix = slab + (2 * (4 * R + crho)) * pitch + 4 * (4 * Cg + ckap) + 8;
         f32x16 z;
 #pragma unroll
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_kernel(const bf16* __restric
           const int j = lane >> 3;
           const int s = 2 * q + (j >> 2), rho = rp + 2 * ((j >> 1) & 1), kap = cp + 2 * (j & 1);
           const int row = 16 * s + 4 * rho + kap;
-          const int S = 8 * t + s; const int R = S / ncg, Cg = S - R * ncg;
+          const int S = 8 * t + s; const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
           const int hl = 4 * R + rho, w = 4 * Cg + kap; const int h = cr0 + hl;
           const bool pv = S < NS && hl < ncr;
           char* zp_ = tb + row * 128 + ((cg ^ (4 * ((row >> 1) & 1))) << 4);
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_roles_kernel(const bf16* __r
   // stage 2: task u of wave w handles the 8 tile rows of parity class c (row parity rp, column parity cp) in steps 2 q, 2 q + 1; the classes of a wave's two tasks are
   // complementary ((0,0) + (1,1): 1 + 4 candidate windows, (0,1) + (1,0): 2 + 2), so every wave does about the same work and the window loops are wave-uniform
   const int ncg = G.OW >> 2;
+  const unsigned ncg_m = ((1u << 20) + (unsigned)ncg - 1u) / (unsigned)ncg;      // S / ncg = (S * ncg_m) >> 20 for the step indices of a band (S < 4096, ncg <= 64: exact) -- a per-lane integer division is ~35 VALU instructions
 
   // one frame slot: chunk q = tid (SLOT = 512 chunks >= SH * CPR) <- input row ir0 + q / CPR of frame `itf`, chunk q % CPR (zero page: padding chunks, rows outside the frame)
   auto dma_frame = [&](long long clip, int itf, int ir0, int slot) {
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_roles_kernel(const bf16* __r
 
       auto conv_tile = [&](int t) {                                 // raw z^T of tile t -> tiles[t & 1]
         int S = 8 * t + cstep; if (S >= NS) S = 0;
-        const int R = S / ncg, Cg = S - R * ncg;
+        const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
         const char* pix = slab + (2 * (4 * R + crho)) * pitch + 4 * (4 * Cg + ckap) + 8;
         f32x16 z[2];
 #pragma unroll
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(512) void stem3p_wgrad_roles_kernel(const bf16* __r
           const int j = lane >> 3;
           const int s = 2 * q + (j >> 2), rho = rp + 2 * ((j >> 1) & 1), kap = cp + 2 * (j & 1);
           const int row = 16 * s + 4 * rho + kap;
-          const int S = 8 * t + s; const int R = S / ncg, Cg = S - R * ncg;
+          const int S = 8 * t + s; const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
           const int hl = 4 * R + rho, w = 4 * Cg + kap; const int h = cr0 + hl;
           const bool pv = S < NS && hl < ncr;
           char* zp_ = tb + row * 128 + ((cg ^ (4 * ((row >> 1) & 1))) << 4);
