@@ -49,40 +49,6 @@ int col_finalize(const ColWs& ws, unsigned colblocks, unsigned nslots, int NV, i
 // =============================================================================================
 // LayerNorm: x fp32 [M][D]; one wave per row.   (nn.LayerNorm(eps=1e-6): nnet/modules.py:278,302,373; nnet/blocks.py:267)
 // =============================================================================================
-// x + sum of partial outputs (csrc/chain.hip) as the LayerNorm input: one wave per row, the row (D <= 512) stays in registers; also stores the materialised sum
-template <typename TO>
-__global__ __launch_bounds__(256) void ln_fwd_sum_kernel(const float* __restrict__ x, const float* __restrict__ parts, int nparts, long long pstride, float* __restrict__ xsum,
-                                                         const float* __restrict__ g, const float* __restrict__ b, TO* __restrict__ y, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, long long M, int D, float eps) {
-  const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  float v[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; ld4<float>(x + row * D + (c < D ? c : D - 4), v[i]); }
-  for (int s = 0; s < nparts; ++s) {
-    float t[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; ld4<float>(parts + s * pstride + row * D + (c < D ? c : D - 4), t[i]); }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) for (int e = 0; e < 4; ++e) v[i][e] += t[i][e];
-  }
-  float sm = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) { st4<float>(xsum + row * D + c, v[i]); sm += v[i][0] + v[i][1] + v[i][2] + v[i][3]; } }
-  const float mu = wave_sum(sm) / D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int c = lane * 4 + i * 256; if (c < D) for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; } }
-  const float rs = rsqrtf(wave_sum(q) / D + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = lane * 4 + i * 256; if (c >= D) break;
-    float gg[4], bb[4], o[4]; ld4<float>(g + c, gg); ld4<float>(b + c, bb);
-    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gg[e] + bb[e];
-    st4<TO>(y + row * D + c, o);
-  }
-}
 template <typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                      TO* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long long M, int D, float eps) {
@@ -188,11 +154,10 @@ extern "C" int avec_layernorm_fwd(int dtype, const float* x, const float* gamma,
 // Optional second output (avec_layernorm_bwd_prep): prep = act(palpha * dropmask * dx) -- what the module in front of this one would compute from dx with a
 // grad_prep launch of its own at the start of ITS backward (out = res + alpha * Dropout(.): nnet/blocks.py:292-301).
 struct LnPrep { void* out; float alpha, p; const unsigned long long* rng; unsigned stream; int f32; };
-struct LnParts { int n; long long stride; float* sum; };      // dy = sum of n fp32 partial gradients [n][M][D] (csrc/chain.hip); `sum` receives the total (fp32)
 template <typename TG, int NG>
 __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
-                                                          const float* __restrict__ dres, long long M, int D, LnPrep pr, LnParts pt) {
+                                                          const float* __restrict__ dres, long long M, int D, LnPrep pr) {
   const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float mu = mean[row], rs = rstd[row];
@@ -209,18 +174,6 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const TG* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) { d[i][e] = 0.f; v[i][e] = mu; o[i][e] = 0.f; gg[i][e] = 0.f; }
     }
-  }
-  if (pt.n > 1) {                                   // (TG = float) the remaining partial gradients, then the total for the parameter-gradient launch
-    for (int s = 1; s < pt.n; ++s)
-#pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (c < D) { float t[4]; ld4<float>((const float*)dy + s * pt.stride + row * D + c, t); for (int e = 0; e < 4; ++e) d[i][e] += t[e]; }
-      }
-  }
-  if (pt.sum) {
-#pragma unroll
-    for (int i = 0; i < NG; ++i) { const int c = lane * 4 + i * 256; if (c < D) st4<float>(pt.sum + row * D + c, d[i]); }
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -416,13 +369,13 @@ extern "C" int avec_layernorm_param_grads_grouped(int dtype, const avec_ln_item_
 }
 
 static int layernorm_bwd_impl(int dtype, const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
-                              float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, const LnPrep& pr, hipStream_t st, LnParts pt = LnParts{0, 0, nullptr}) {
+                              float* dx, const float* dres, float* dgamma, float* dbeta, long long M, int D, const LnPrep& pr, hipStream_t st) {
   AVEC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && (!dgamma == !dbeta), "layernorm_bwd: null pointer");
   AVEC_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1536, "layernorm_bwd: D=%d must be a multiple of 4 and <= 1536", D);
   AVEC_CHECK_ARG(!pr.out || (!dgamma && (pr.p <= 0.f || pr.rng)), "layernorm_bwd_prep: the second output comes with the dx-only kernel (dgamma == NULL); dropout needs rng");
   if (!dgamma) {        // input gradient only (parameter gradients deferred to avec_layernorm_param_grads_grouped)
     const dim3 grid((unsigned)((M + 3) / 4)); const bool f32in = dy_f32 || dtype == AVEC_F32;
-#define AVEC_LN_ROWS(TG, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<TG, NG>), grid, dim3(256), 0, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, M, D, pr, pt)
+#define AVEC_LN_ROWS(TG, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<TG, NG>), grid, dim3(256), 0, st, (const TG*)dy, x, mean, rstd, gamma, dx, dres, M, D, pr)
     if (D <= 512) { if (f32in) AVEC_LN_ROWS(float, 2); else AVEC_LN_ROWS(bf16, 2); }
     else { if (f32in) AVEC_LN_ROWS(float, 6); else AVEC_LN_ROWS(bf16, 6); }
 #undef AVEC_LN_ROWS
@@ -452,23 +405,6 @@ extern "C" int avec_layernorm_bwd_prep(int dtype, const void* dy, int dy_f32, co
   AVEC_CHECK_ARG(prep, "layernorm_bwd_prep: null prep buffer");
   LnPrep pr; pr.out = prep; pr.alpha = prep_alpha; pr.p = prep_drop_p; pr.rng = rng; pr.stream = rng_stream; pr.f32 = dtype == AVEC_F32;
   return layernorm_bwd_impl(dtype, dy, dy_f32, x, mean, rstd, gamma, dx, dres, nullptr, nullptr, M, D, pr, st);
-}
-
-extern "C" int avec_layernorm_bwd_sum(int dtype, const float* dyparts, int nparts, float* dysum, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                      float* dx, const float* dres, void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream,
-                                      long long M, int D, hipStream_t st) {
-  AVEC_CHECK_ARG(dyparts && nparts >= 1 && dysum, "layernorm_bwd_sum: bad arguments");
-  LnPrep pr; pr.out = prep; pr.alpha = prep_alpha; pr.p = prep ? prep_drop_p : 0.f; pr.rng = rng; pr.stream = rng_stream; pr.f32 = dtype == AVEC_F32;
-  return layernorm_bwd_impl(dtype, dyparts, 1, x, mean, rstd, gamma, dx, dres, nullptr, nullptr, M, D, pr, st, LnParts{nparts, M * (long long)D, dysum});
-}
-extern "C" int avec_layernorm_fwd_sum(int dtype, const float* x, const float* xparts, int nparts, float* xsum, const float* gamma, const float* beta, void* y, int y_f32,
-                                      float* mean, float* rstd, long long M, int D, float eps, hipStream_t st) {
-  AVEC_CHECK_ARG(x && xparts && nparts >= 1 && xsum && gamma && beta && y && mean && rstd, "layernorm_fwd_sum: null pointer");
-  AVEC_CHECK_ARG(M > 0 && D >= 4 && D % 4 == 0 && D <= 512, "layernorm_fwd_sum: D=%d must be a multiple of 4 and <= 512", D);
-  dim3 grid((unsigned)((M + 3) / 4));
-  if (y_f32 || dtype == AVEC_F32) hipLaunchKernelGGL(ln_fwd_sum_kernel<float>, grid, dim3(256), 0, st, x, xparts, nparts, M * (long long)D, xsum, gamma, beta, (float*)y, mean, rstd, M, D, eps);
-  else hipLaunchKernelGGL(ln_fwd_sum_kernel<bf16>, grid, dim3(256), 0, st, x, xparts, nparts, M * (long long)D, xsum, gamma, beta, (bf16*)y, mean, rstd, M, D, eps);
-  AVEC_LAUNCH_CHECK(); return 0;
 }
 
 // =============================================================================================

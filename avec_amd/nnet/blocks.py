@@ -59,10 +59,10 @@ class ConformerBlock(nn.Module):
         self.stride = conv_stride
 
     def forward(self, x, mask=None):
-        x = self.ff_module1.residual_forward(x, 0.5, lazy_out=True)          # (consumed by the attention module: sums the partial outputs of the split-F kernel itself)
+        x = self.ff_module1.residual_forward(x, 0.5)
         x = self.self_att_module(x, mask=mask, add_residual=True)
         x = self.conv_module.residual_forward(x, None if isinstance(self.conv_res, nn.Identity) else self.conv_res)
-        x = self.ff_module2.residual_forward(x, 0.5, lazy_out=isinstance(self.norm, nn.LayerNorm))
+        x = self.ff_module2.residual_forward(x, 0.5)
         if isinstance(self.norm, nn.LayerNorm):
             x = normalizations.torch_layer_norm_forward(self.norm, x, getattr(self, "_next_ln", None))
         return x

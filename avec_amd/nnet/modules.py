@@ -76,13 +76,12 @@ class FeedForwardModule(nn.Module):
         self.drop_rate, self.inner_dropout = drop_rate, inner_dropout
         self.sid1, self.sid2 = rt.new_stream_id(), rt.new_stream_id()
 
-    def residual_forward(self, x, alpha, lazy_out=False):
-        """x + alpha * FFN(x) in one fused sequence (the macaron half-step of nnet/blocks.py:292,301).
-        lazy_out: the caller hands the result to a consumer that sums the partial outputs of the split-F kernel itself (ops._lazy_of)."""
+    def residual_forward(self, x, alpha):
+        """x + alpha * FFN(x) in one fused sequence (the macaron half-step of nnet/blocks.py:292,301)."""
         ln, l1, l2 = self.layers[0], self.layers[1], self.layers[4]
         p = self.drop_rate if self.training else 0.0
         assert self.inner_dropout or p == 0.0
-        return ops.FeedForwardFn.apply(x, ln.weight, ln.bias, l1.weight, l1.bias, l2.weight, l2.bias, ln.eps, alpha, p, self.sid1, self.sid2, lazy_out)
+        return ops.FeedForwardFn.apply(x, ln.weight, ln.bias, l1.weight, l1.bias, l2.weight, l2.bias, ln.eps, alpha, p, self.sid1, self.sid2)
 
     def forward(self, x):
         return self.residual_forward(x, 1.0) - x

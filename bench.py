@@ -91,7 +91,7 @@ def pmc_traffic(family):
     if not family or path is None:
         return None
     if family.startswith("conv3x3"):
-        ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith("conv3x3_c64_kernel") or k.startswith("wgrad3x3_c64_kernel")]
+        ks = [v for k, v in json.load(open(path))["kernels"].items() if "conv3x3_c64_kernel" in k or k.startswith("conv3x3_c64_res_kernel") or k.startswith("wgrad3x3_c64")]
         n = sum(v["launches"] for v in ks)
         return round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0)) for v in ks) / n) if n else None
     want_tn = family.startswith("gemm_tn")
@@ -117,7 +117,7 @@ def pmc_traffic_kernel(kernel):
     path = pmc_summary_path()
     if not kernel or path is None:
         return None
-    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace("__hip_bfloat16", "bf16")
+    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace(",tr>", ",1>").replace("__hip_bfloat16", "bf16")
     want = norm(kernel)
     for name, v in json.load(open(path))["kernels"].items():
         if norm(name).split("(")[0] == want:

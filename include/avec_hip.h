@@ -33,7 +33,7 @@ extern "C" {
 
 #define AVEC_F32 0
 #define AVEC_BF16 1
-#define AVEC_ABI_VERSION 2      /* 2: avec_epilogue_t grew (bnb_*, res_cls0); avec_struct_size() handshake */
+#define AVEC_ABI_VERSION 3      /* 2: avec_epilogue_t grew (bnb_*, res_cls0); avec_struct_size() handshake.  3: the row-resident module chains (avec_ffn_chain_*, avec_ln_gemm, avec_layernorm_*_sum) were removed */
 #define AVEC_STAT_REPLICAS 64   /* `stats` buffers handed to avec_gemm_nt hold this many [2N] replicas (block b adds to replica b % 64) */
 
 int avec_version(void);
@@ -147,47 +147,6 @@ typedef struct {
   const long long* strides6;
 } avec_tn_batched_t;
 int avec_gemm_tn_batched_multi(int dtype, const avec_tn_batched_t* items, int n, hipStream_t stream);
-
-/* ---- row-resident module chains, split over the hidden width (avec_amd/csrc/chain.hip; bf16 mode) ------------------------------------
- * FeedForwardModule.forward (nnet/modules.py:257-289) with its residual (nnet/blocks.py:292,301) as ONE launch per direction:
- *   y = x + alpha * Drop2(W2 Drop1(Swish(W1 LN(x) + b1)) + b2)
- * Workgroup (64-row tile, 256-column slice s of the hidden width F) runs LayerNorm -> product with its W1 slice -> Swish / dropout -> PARTIAL product with its W2
- * slice, and stores the partial result: yparts = [S][M][D] fp32, S = avec_chain_slices(F), y = x + sum_s yparts[s] (slice 0 carries b2).  The sum is taken by the
- * consumer while it loads its input: avec_ln_gemm / avec_layernorm_fwd_sum (forward), avec_layernorm_bwd_sum (backward) -- fp32 atomics into one tensor were measured
- * at ~0.4 M atomic operations per microsecond (8 us per module at M = 3200).  The hidden activation never reaches memory in the forward pass; z = W1 LN(x) + b1 is kept
- * in the kernel's own accumulator order (`zbuf`, avec_ffn_chain_zbuf_bytes) for the backward kernel.
- * w1 = [F][D], w2 = [D][F] (bf16, row-major, strides ldw*); the backward pass takes the transposes w2t = [F][D], w1t = [D][F] (the "bwd shadows").
- * forward also writes mean, rstd [M] and h0 = LN(x) [M][D] (bf16); backward: dacc = alpha * mask2 * dy [M][D], dz [M][F], h1 = Drop1(Swish(z)) [M][F] (bf16,
- * row-major: the operands of dW2 = dacc^T h1, db2, dW1 = dz^T h0, db1 via avec_gemm_tn_grouped) and dh0parts = [S][M][D] fp32 with dh0 = sum_s dh0parts[s].
- * 64 <= D <= 384, D % 8 == 0, F % 8 == 0, M * max(D, F) < 2^32 (avec_chain_supported). */
-int avec_chain_supported(long long M, int D, int N);
-int avec_chain_slices(int N);
-/* measurement aid: dev16 != NULL -> the chain kernels write s_memtime stamps (entry, operand ready, product A done, middle done, copies done, product B done, end) of their
- * first and of their last workgroup into dev16[0..7] / dev16[8..15]; NULL switches it off */
-int avec_chain_debug_stamps(unsigned long long* dev16);
-long long avec_ffn_chain_zbuf_bytes(long long M, int F);
-int avec_ffn_chain_fwd(const float* x, const float* ln_g, const float* ln_b, float eps, const void* w1, long long ldw1, const float* b1,
-                       const void* w2, long long ldw2, const float* b2, float alpha, float drop_p, const unsigned long long* rng,
-                       unsigned sid1, unsigned sid2, float* yparts, float* mean, float* rstd, void* h0, void* zbuf,
-                       long long M, int D, int F, hipStream_t stream);
-int avec_ffn_chain_bwd(const float* dy, const void* w2t, long long ldw2t, const void* w1t, long long ldw1t, const void* zbuf,
-                       float alpha, float drop_p, const unsigned long long* rng, unsigned sid1, unsigned sid2,
-                       void* dacc, void* dz, void* h1, float* dh0parts, long long M, int D, int F, hipStream_t stream);
-/* LayerNorm folded into the product that consumes it (the Q|K|V projection of nnet/modules.py:320-339, the first pointwise convolution of nnet/modules.py:372-374):
- * out[M][N] (bf16, row stride ldo) = LN(xt) W^T + bias, W = [N][D] bf16, xt = x + sum_{s < nparts} xparts[s][M][D] (nparts = 0: xt = x); with nparts > 0 the
- * materialised xt is also stored to xsum [M][D] (the later residual add and the backward pass need it).  Also writes mean, rstd [M] and, when h0 != NULL,
- * h0 = LN(xt) [M][D] bf16 (the operand of the weight-gradient product).  Same dims as above with N in place of F. */
-int avec_ln_gemm(const float* x, const float* xparts, int nparts, float* xsum, const float* ln_g, const float* ln_b, float eps, const void* w, long long ldw,
-                 const float* bias, void* out, long long ldo, float* mean, float* rstd, void* h0, long long M, int D, int N, hipStream_t stream);
-/* LayerNorm over a lazily summed input / gradient (the consumers of the partial outputs above):
- *   fwd:  xt = x + sum_s xparts[s];  xsum = xt;  y = LN(xt) (act, or fp32 when y_f32);  mean, rstd
- *   bwd:  dyt = sum_s dyparts[s] (fp32 [S][M][D]);  dysum = dyt (fp32: the operand of avec_layernorm_param_grads_grouped);  dx = dres + LN'(dyt) [+ prep output as
- *         avec_layernorm_bwd_prep when prep != NULL] */
-int avec_layernorm_fwd_sum(int dtype, const float* x, const float* xparts, int nparts, float* xsum, const float* gamma, const float* beta, void* y, int y_f32,
-                           float* mean, float* rstd, long long M, int D, float eps, hipStream_t stream);
-int avec_layernorm_bwd_sum(int dtype, const float* dyparts, int nparts, float* dysum, const float* x, const float* mean, const float* rstd, const float* gamma,
-                           float* dx, const float* dres, void* prep, float prep_alpha, float prep_drop_p, const unsigned long long* rng, unsigned rng_stream,
-                           long long M, int D, hipStream_t stream);
 
 /* ---- SyncBatchNorm statistic exchange by peer writes over xGMI (avec_amd/csrc/peer.hip) ----------
  * all-reduce(sum) of a short fp32 vector (the (2C+1)-float / 2C-float vectors of nnet/normalizations.py:172-249) between the GPUs of one node

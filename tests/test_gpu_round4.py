@@ -201,152 +201,6 @@ def test_bench_config_graphed_step_matches_oracle():
 
 
 # ----------------------------------------------------------------------------------------------
-# row-resident module chains (csrc/chain.hip): the feed-forward module as one launch per direction, LayerNorm inside the consuming product
-# ----------------------------------------------------------------------------------------------
-def _ffn_reference(x, mod, alpha):
-    """fp64 torch math of FeedForwardModule + residual (nnet/modules.py:257-289, nnet/blocks.py:292) with the fp32 master weights, dropout off"""
-    ln, l1, l2 = mod.layers[0], mod.layers[1], mod.layers[4]
-    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in (("g", ln.weight), ("b", ln.bias), ("w1", l1.weight), ("b1", l1.bias), ("w2", l2.weight), ("b2", l2.bias))}
-    xr = x.detach().double().cpu().requires_grad_(True)
-    h = torch.nn.functional.layer_norm(xr, (xr.shape[-1],), p["g"], p["b"], 1e-6)
-    z = h @ p["w1"].t() + p["b1"]
-    y = xr + alpha * ((z * torch.sigmoid(z)) @ p["w2"].t() + p["b2"])
-    return xr, p, y
-
-
-def _ffn_both_ways(mod, x, wgt, alpha):
-    """the module through the chain kernels and through the three-launch sequence on the same rng state -> {chain?: (y, dx, param grads)}"""
-    from avec_amd import ops
-    ln, l1, l2 = mod.layers[0], mod.layers[1], mod.layers[4]
-    names = {"g": ln.weight, "b": ln.bias, "w1": l1.weight, "b1": l1.bias, "w2": l2.weight, "b2": l2.bias}
-    res = {}
-    keep = ops.FFN_CHAIN
-    try:
-        for chain in (True, False):
-            ops.FFN_CHAIN = chain
-            for prm in mod.parameters():
-                prm.grad = None
-            xg = x.clone().requires_grad_(True)
-            y = mod.residual_forward(xg, alpha)
-            (y * wgt).sum().backward()
-            torch.cuda.synchronize()
-            res[chain] = (y.detach().clone(), xg.grad.clone(), {k: v.grad.clone() for k, v in names.items()})
-    finally:
-        ops.FFN_CHAIN = keep
-    return res
-
-
-@pytest.mark.parametrize("B,T,D,F", [(32, 100, 256, 1024), (32, 50, 360, 1440), (3, 37, 256, 1024), (2, 50, 360, 1440), (5, 33, 64, 256), (2, 70, 320, 1280), (1, 7, 128, 200)])
-def test_ffn_chain_matches_fp64_and_unfused(B, T, D, F):
-    """the one-launch feed-forward module (forward, input gradient, all six parameter gradients) against fp64 math on the fp32 masters; its error must be of the
-    size of the three-launch bf16 path's own error (relative L2: <= 2 x that + 3e-3, and < 3e-2 absolutely); dropout off; ragged tiles, partial last slices"""
-    import avec_amd
-    import nnet
-    avec_amd.set_compute_dtype("bf16")
-    torch.manual_seed(D + T)
-    mod = nnet.FeedForwardModule(D, F, 0.0, "Swish", True).to(dev()).train()
-    for prm in mod.parameters():
-        prm.data.add_(0.05 * torch.randn_like(prm))
-    x = torch.randn(B, T, D, device=dev())
-    wgt = torch.randn(B, T, D, device=dev())
-    xr, pr, yr = _ffn_reference(x, mod, 0.5)
-    (yr * wgt.double().cpu()).sum().backward()
-    res = _ffn_both_ways(mod, x, wgt, 0.5)
-    l2e = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
-    err = {c: {"y": l2e(r[0], yr.detach()), "dx": l2e(r[1], xr.grad), **{k: l2e(v, pr[k].grad) for k, v in r[2].items()}} for c, r in res.items()}
-    for k in err[True]:
-        assert err[True][k] < 2.0 * err[False][k] + 3e-3, (k, err[True][k], err[False][k])
-        assert err[True][k] < 3e-2, (k, err[True][k])
-
-
-def test_ffn_chain_dropout_masks_equal_the_unfused_path():
-    """dropout ON (p = 0.1 at both sites): the chain kernels draw the masks from the same (rng stream, element index) pairs as the three-launch sequence, forward and
-    backward -- so the two paths agree element for element up to bf16 rounding (a wrong mask would show as O(1) differences on ~10 % of the elements)"""
-    import avec_amd
-    import nnet
-    avec_amd.set_compute_dtype("bf16")
-    avec_amd.manual_seed(99)
-    torch.manual_seed(3)
-    B, T, D, F, p = 16, 100, 256, 1024, 0.1
-    mod = nnet.FeedForwardModule(D, F, p, "Swish", True).to(dev()).train()
-    x = torch.randn(B, T, D, device=dev())
-    wgt = torch.randn(B, T, D, device=dev())
-    res = _ffn_both_ways(mod, x, wgt, 0.5)
-    yc, dxc, gc = res[True]
-    yu, dxu, gu = res[False]
-    # the residual y - x vanishes exactly where site 2 dropped: identical zero pattern
-    zc, zu = (yc - x) == 0, (yu - x) == 0
-    assert abs(zu.float().mean().item() - p) < 5e-3
-    assert (zc ^ zu).float().mean().item() < 1e-4
-    l2e = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
-    assert l2e(yc, yu) < 1e-2 and l2e(dxc, dxu) < 2e-2, (l2e(yc, yu), l2e(dxc, dxu))
-    for k in gc:
-        assert l2e(gc[k], gu[k]) < 2e-2, (k, l2e(gc[k], gu[k]))
-
-
-@pytest.mark.parametrize("M,D,N", [(3200, 256, 768), (1600, 360, 1080), (3200, 256, 512), (1600, 360, 720), (77, 64, 72), (130, 320, 264)])
-def test_ln_gemm_matches_torch(M, D, N):
-    """avec_ln_gemm (LayerNorm inside the consuming product) against fp64 layer_norm + matmul on the bf16-rounded weights: output 1.5e-2 of its max-norm (bf16 operands),
-    statistics 1e-5, h = LN(x) within bf16 rounding"""
-    import avec_amd
-    from avec_amd import ops
-    avec_amd.set_compute_dtype("bf16")
-    g = torch.Generator().manual_seed(M + N)
-    x = (torch.randn(M, D, generator=g) * 1.7 + 0.3).to(dev())
-    lw, lb = (1.0 + 0.1 * torch.randn(D, generator=g)).to(dev()), (0.1 * torch.randn(D, generator=g)).to(dev())
-    W = (torch.randn(N, D, generator=g) / D ** 0.5).to(dev()).bfloat16()
-    bias = (0.1 * torch.randn(N, generator=g)).to(dev())
-    out, h, mean, rstd = ops.ln_gemm(x, lw, lb, 1e-6, W, D, bias, M, D, N)
-    torch.cuda.synchronize()
-    xd = x.double().cpu()
-    hr = torch.nn.functional.layer_norm(xd, (D,), lw.double().cpu(), lb.double().cpu(), 1e-6)
-    ref = hr @ W.double().cpu().t() + bias.double().cpu()
-    assert rel_err(mean.cpu(), xd.mean(1)) < 1e-5 and rel_err(rstd.cpu(), 1.0 / (xd.var(1, unbiased=False) + 1e-6).sqrt()) < 1e-5
-    assert rel_err(h.float().cpu(), hr) < 1e-2
-    assert rel_err(out.float().cpu(), ref) < 1.5e-2, rel_err(out.float().cpu(), ref)
-
-
-@pytest.mark.parametrize("B,T,D", [(4, 100, 256), (3, 50, 360), (2, 37, 256)])
-def test_conformer_block_with_chain_kernels_matches_launch_sequence(B, T, D):
-    """a whole ConformerBlock (bf16, dropout off): the split-F feed-forward kernels with their lazily summed outputs (consumed by the LayerNorm + Q|K|V launch and by the
-    block's final LayerNorm) against the per-layer launch sequence -- outputs 1e-2, input and parameter gradients 3e-2 (relative L2; both are bf16 paths)"""
-    import avec_amd
-    import nnet
-    from avec_amd import ops
-    avec_amd.set_compute_dtype("bf16")
-    torch.manual_seed(T + D)
-    att = {"class": "RelPos1dMultiHeadAttention", "params": dict(num_heads=4, attn_drop_rate=0.0, num_pos_embeddings=10000, weight_init="default", bias_init="default")}
-    blk = _nodrop(nnet.ConformerBlock(dim_model=D, dim_expand=D, ff_ratio=4, drop_rate=0.0, att_params=att, conv_stride=1,
-                                      conv_params={"class": "Conv1d", "params": {"padding": "same", "kernel_size": 15}})).to(dev()).train()
-    x = torch.randn(B, T, D, device=dev())
-    wgt = torch.randn(B, T, D, device=dev())
-    lens = torch.tensor([T, max(T - 9, 1), max(T // 2, 1), T][:B], dtype=torch.int64, device=dev())
-    from avec_amd.nnet.modules import LengthMask
-    res = {}
-    keep = (ops.FFN_CHAIN, ops.LN_GEMM)
-    try:
-        for mode in (True, False):
-            ops.FFN_CHAIN = ops.LN_GEMM = mode
-            for prm in blk.parameters():
-                prm.grad = None
-            xg = x.clone().requires_grad_(True)
-            y = blk(xg, mask=LengthMask(lens))
-            (y * wgt).sum().backward()
-            ops.flush_param_grads(all_streams=True)
-            torch.cuda.synchronize()
-            res[mode] = (y.detach().clone(), xg.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters() if v.grad is not None})
-    finally:
-        ops.FFN_CHAIN, ops.LN_GEMM = keep
-    l2e = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-20)).item()
-    assert l2e(res[True][0], res[False][0]) < 1e-2, l2e(res[True][0], res[False][0])
-    assert l2e(res[True][1], res[False][1]) < 3e-2, l2e(res[True][1], res[False][1])
-    for k, gref in res[False][2].items():
-        if k.endswith(("key_layer.bias", "pos_layer.bias", "conv_module.layers.3.bias")) or gref.abs().max() < 1e-6 * max(1.0, float(res[False][1].abs().max())):
-            continue                                                  # (analytically zero gradients -- softmax shift invariance, a bias in front of training-mode BatchNorm: rounding noise on both sides)
-        assert l2e(res[True][2][k], gref) < 3e-2, (k, l2e(res[True][2][k], gref))
-
-
-# ----------------------------------------------------------------------------------------------
 # two consecutive LayerNorms per launch (avec_layernorm_fwd2 / _bwd2, ops.LN_PAIR)
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -14,7 +14,7 @@ from avec_amd import ops, runtime as rt  # noqa: E402
 from avec_amd import lib as libmod  # noqa: E402
 
 TR = {"on": False, "names": [], "buf": None}
-SKIP = {"stamp", "version", "last_error", "struct_size", "set_reduce_workspace", "set_zero_page", "chain_debug_stamps"}
+SKIP = {"stamp", "version", "last_error", "struct_size", "set_reduce_workspace", "set_zero_page"}
 
 
 def install():
