@@ -39,6 +39,7 @@ def main():
         mb = M * C * 2 / 1e6
         nset = max(2, int(900 / (4 * mb)) + 1)
         bufs = [[torch.randn(M, C, device=dev).bfloat16() for _ in range(5)] for _ in range(nset)]        # y, res / out, a, dout, dy
+        masks = [torch.randint(0, 256, (M * C // 8,), device=dev, dtype=torch.uint8) for _ in range(nset)]
         ss = torch.randn(4 * C, device=dev)
         ss[3 * C:] = ss[3 * C:].abs() + 0.5
         gamma = torch.randn(C, device=dev)
@@ -53,6 +54,10 @@ def main():
                                                                          bufs[i][4].data_ptr(), None, None, None, M, C, st())),
             ("bwd apply (out mask, + dres)", 5, lambda i: lib.bn_bwd_apply(rt.dt(), bufs[i][3].data_ptr(), bufs[i][0].data_ptr(), bufs[i][2].data_ptr(), ss.data_ptr(), gamma.data_ptr(), dstats.data_ptr(), None, float(M), 2,
                                                                            bufs[i][4].data_ptr(), bufs[i][1].data_ptr(), None, None, M, C, st())),
+            ("apply fwd (+res, relu, bit mask)", 3, lambda i: lib.bn_apply_fwd_mask(rt.dt(), bufs[i][0].data_ptr(), ss.data_ptr(), bufs[i][1].data_ptr(), None, bufs[i][2].data_ptr(), masks[i].data_ptr(), M, C, st())),
+            ("bwd reduce (bit mask)", 2, lambda i: lib.bn_bwd_reduce_mask(rt.dt(), bufs[i][3].data_ptr(), bufs[i][0].data_ptr(), masks[i].data_ptr(), ss.data_ptr(), dstats.data_ptr(), M, C, st())),
+            ("bwd apply (bit mask, + dres)", 4, lambda i: lib.bn_bwd_apply_mask(rt.dt(), bufs[i][3].data_ptr(), bufs[i][0].data_ptr(), masks[i].data_ptr(), ss.data_ptr(), gamma.data_ptr(), dstats.data_ptr(), None, float(M),
+                                                                                bufs[i][4].data_ptr(), bufs[i][1].data_ptr(), None, None, M, C, st())),
         ]
         for name, passes, fn in cases:
             us = timed(fn, nset)
