@@ -205,6 +205,10 @@ class VisualEfficientConformerEncoder(nn.Module):
         return self.forward_back(self.forward_front(x), lengths)
 
 
+def audio_first_env():
+    return os.environ.get("AVEC_AUDIO_FIRST", "0") == "1"
+
+
 class AudioVisualEfficientConformerEncoder(nn.Module):
     """nnet/networks.py:514-579"""
 
@@ -231,8 +235,17 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             # the two encoders are independent: the audio branch runs on a second stream beside the visual one (runtime.branch_stream)
             main = torch.cuda.current_stream()
             rt.stream()                                   # default reduction workspace registered before the fork
-            rt.ensure_shadows_fresh(self)
-            side.wait_stream(main)
+            # weight shadows: the visual front-end's on this stream (the stem starts at once), the other 80 % on the audio stream beside the stem's forward
+            # pass (a persistent kernel that leaves the HBM idle); this stream waits for them in front of the visual back-end.  AVEC_SHADOW_SPLIT=0: one launch
+            arena = rt.arena_of(self)
+            sh_ev = None
+            split = arena is not None and not audio_first_env() and os.environ.get("AVEC_SHADOW_SPLIT", "1") != "0"
+            if split:
+                side.wait_stream(main)
+                sh_ev = arena.ensure_fresh_split(arena.prefix_blocks(self.video_encoder.front_end), side)
+            else:
+                rt.ensure_shadows_fresh(self)
+                side.wait_stream(main)
             for t in (audio, audio_len):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(side)
@@ -240,7 +253,7 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             # path) goes first, the ~400 short audio kernels are submitted while it runs, the visual conformer stack follows.  The autograd engine replays
             # nodes newest-first, so the backward order is: visual conformer stack, audio encoder, ResNet / stem -- the audio submissions again hide
             # behind running work instead of delaying the critical branch.  AVEC_AUDIO_FIRST=1 restores the old order (audio encoder first).
-            audio_first = os.environ.get("AVEC_AUDIO_FIRST", "0") == "1"
+            audio_first = audio_first_env()
             if audio_first:
                 with torch.cuda.stream(side):
                     audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
@@ -252,6 +265,8 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
                     ops.stamp("a_start:f")
                     audio, audio_len, a_inter = self.audio_encoder(audio, audio_len)
                     audio = ops.mark(audio, "a_enc")
+                if sh_ev is not None:
+                    main.wait_event(sh_ev)
                 video, video_len, v_inter = self.video_encoder.forward_back(feats, video_len)
                 video = ops.mark(video, "v_back")
             main.wait_stream(side)

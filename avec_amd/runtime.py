@@ -467,6 +467,42 @@ class ParamArena:
             if getattr(self, "_fp8", None) is not None:          # e4m3 weight shadows follow the masters too (avec_amd/fp8.py)
                 self._fp8.refresh()
 
+    def prefix_blocks(self, module):
+        """Workgroups of the shadow refresh that belong to `module`'s weights when those lead the shadow table (the visual front-end of the audio-visual
+        encoder does), else 0: ensure_fresh_split() refreshes that prefix on the current stream and the rest on another one."""
+        ids = {id(p) for p in module.parameters()}
+        blocks, inside = 0, True
+        for p in self.params:
+            sh = getattr(p, "_avec_shadow", None)
+            if sh is None:
+                continue
+            if id(p) in ids:
+                if not inside:
+                    return 0
+                blocks += _shadow_blocks(sh)
+            else:
+                inside = False
+        return blocks
+
+    def ensure_fresh_split(self, first_blocks, side):
+        """ensure_fresh() with the refresh cut in two: shadow blocks [0, first_blocks) on the current stream (their consumer follows at once), the rest on
+        `side` (which must already wait for the current stream).  Returns the event the current stream has to wait for before it reads any other shadow,
+        or None when nothing was stale.  The fp8 shadows and a dtype change take the one-launch path."""
+        if self._shadow_dtype != compute_dtype() or getattr(self, "_fp8", None) is not None or not (0 < first_blocks < self.total_blocks):
+            self.ensure_fresh()
+            return None
+        if not self.dirty:
+            return None
+        lib.shadow_refresh_range(dt(), self.master.data_ptr(), self.shadow.data_ptr(), self.table.data_ptr(), self.n_entries, 0, first_blocks, stream())
+        with torch.cuda.stream(side):
+            lib.shadow_refresh_range(dt(), self.master.data_ptr(), self.shadow.data_ptr(), self.table.data_ptr(), self.n_entries, first_blocks,
+                                     self.total_blocks - first_blocks, stream())
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.dirty = False
+        self.refresh_count = getattr(self, "refresh_count", 0) + 1
+        return ev
+
     def mark_dirty(self):
         """The master weights changed outside the Adam kernel: refresh the shadows before the next GEMM.  Called automatically by load_state_dict
         (model or sub-module) and by check_versions(); call it by hand after editing weights through `.data` (which leaves no trace)."""
