@@ -89,22 +89,22 @@ __global__ __launch_bounds__(64) void ctc_kernel(const float* __restrict__ logit
 
 // LDS-resident variant (used when 3*T*S + T + 4*V floats fit in 64 KB): 256 threads per utterance.
 //   phase 1  frame log-normalisers, one frame per wave, then log p(ext[s] | t) for every (t, s) in parallel
-//   phase 2  alpha (threads 0..127) and beta (threads 128..255) recursions run concurrently, one barrier per frame, LDS only
+//   phase 2  alpha (wave 0) and beta (wave 1) recursions run concurrently and wave-synchronously (no workgroup barrier per frame), LDS only
 //   phase 3  gradient rows, one frame per wave (occupancy scatter into a per-wave LDS histogram)
 __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
                                              const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
                                              int B, int T, int V, int Lmax, int blank, int zero_inf, int b, float* total = nullptr, float wtot = 0.f) {
   extern __shared__ float sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = blockDim.x, NW = NT >> 6;      // 256 or 1024 threads (CTC_WAVES of the launch)
   const int Smax = 2 * Lmax + 1;
   float* lpe = sm; float* alpha = lpe + T * Smax; float* beta = alpha + T * Smax; float* lnorm = beta + T * Smax;
-  float* occ = lnorm + T; int* ext = (int*)(occ + 4 * V);
+  float* occ = lnorm + T; int* ext = (int*)(occ + NW * V);
   const int Tb = min((int)in_lens[b], T), L = min((int)tgt_lens[b], Lmax), S = 2 * L + 1;
   const float* lg = logits + (long long)b * T * V;
   float* gr = grad ? grad + (long long)b * T * V : nullptr;
-  for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
+  for (int s = tid; s < S; s += NT) ext[s] = (s & 1) ? (int)targets[(long long)b * Lmax + (s >> 1)] : blank;
   // frame log-normalisers: four frames per wave in flight (each is a load -> max -> exp -> sum chain of its own)
-  for (int t0 = wv * 4; t0 < Tb; t0 += 16) {
+  for (int t0 = wv * 4; t0 < Tb; t0 += 4 * NW) {
     float mx[4], se[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int t = min(t0 + q, Tb - 1); mx[q] = -INFINITY; for (int v = lane; v < V; v += 64) mx[q] = fmaxf(mx[q], lg[t * V + v]); }
@@ -120,15 +120,17 @@ __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, c
     }
   }
   __syncthreads();
-  for (int i = tid; i < Tb * S; i += 256) { const int t = i / S, s = i - t * S; lpe[t * Smax + s] = lg[t * V + ext[s]] - lnorm[t]; }
+  for (int i = tid; i < Tb * S; i += NT) { const int t = i / S, s = i - t * S; lpe[t * Smax + s] = lg[t * V + ext[s]] - lnorm[t]; }
   __syncthreads();
   float ll = -INFINITY;
   if (Tb > 0) {
-    const bool fw = tid < 128; const int s0 = fw ? tid : tid - 128;
-    for (int k = 0; k < Tb; ++k) {
+    // wave 0 runs the forward recursion, wave 1 the backward one, each on its own rows: LDS operations of one wave complete in order, so a step needs no workgroup
+    // barrier (it was ~1 us per frame with 128 threads per direction and __syncthreads; the fence keeps the compiler from moving a row's reads above its writes)
+    const bool fw = wv == 0; const int s0 = lane;
+    if (wv < 2) for (int k = 0; k < Tb; ++k) {
       if (fw) {
         const int t = k; float* an = alpha + t * Smax; const float* ap = an - Smax;
-        for (int s = s0; s < S; s += 128) {
+        for (int s = s0; s < S; s += 64) {
           float a;
           if (t == 0) a = (s < 2) ? 0.f : -INFINITY;
           else {
@@ -140,7 +142,7 @@ __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, c
         }
       } else {
         const int t = Tb - 1 - k; float* bc = beta + t * Smax; const float* bn = bc + Smax;
-        for (int s = s0; s < S; s += 128) {
+        for (int s = s0; s < S; s += 64) {
           float bv;
           if (k == 0) bv = (s >= S - 2) ? 0.f : -INFINITY;
           else {
@@ -151,8 +153,10 @@ __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, c
           bc[s] = bv + lpe[t * Smax + s];
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
     const float* al = alpha + (Tb - 1) * Smax;
     ll = al[S - 1]; if (S > 1) ll = logaddexpf_(ll, al[S - 2]);
   } else if (L == 0) ll = 0.f;
@@ -161,19 +165,19 @@ __device__ __forceinline__ void ctc_lds_body(const float* __restrict__ logits, c
   if (inf && zero_inf) loss = 0.f;
   if (tid == 0) { nll[b] = loss; if (mean_out) atomicAdd(mean_out, loss / B); if (total) atomicAdd(total, wtot * loss / B); }
   if (!gr) return;
-  for (int i = tid; i < (T - Tb) * V; i += 256) gr[(long long)Tb * V + i] = 0.f;
-  if (inf || Tb == 0) { for (int i = tid; i < Tb * V; i += 256) gr[i] = 0.f; return; }
+  for (int i = tid; i < (T - Tb) * V; i += NT) gr[(long long)Tb * V + i] = 0.f;
+  if (inf || Tb == 0) { for (int i = tid; i < Tb * V; i += NT) gr[i] = 0.f; return; }
   // gradient rows: one frame per wave per pass; the occupancy histogram is private to the wave and LDS operations of one wave complete in order,
   // so the passes need no workgroup barrier
   float* oc = occ + wv * V;
-  for (int t = wv; t < Tb; t += 4) {
+  for (int t = wv; t < Tb; t += NW) {
     for (int v = lane; v < V; v += 64) oc[v] = 0.f;
     for (int s = lane; s < S; s += 64) atomicAdd(oc + ext[s], __expf(alpha[t * Smax + s] + beta[t * Smax + s] - lpe[t * Smax + s] - ll));
     for (int v = lane; v < V; v += 64) gr[t * V + v] = __expf(lg[t * V + v] - lnorm[t]) - oc[v];
   }
 }
 
-__global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
+__global__ __launch_bounds__(1024) void ctc_lds_kernel(const float* __restrict__ logits, const long long* __restrict__ in_lens, const long long* __restrict__ targets,
                                                       const long long* __restrict__ tgt_lens, float* __restrict__ nll, float* __restrict__ mean_out, float* __restrict__ grad,
                                                       int B, int T, int V, int Lmax, int blank, int zero_inf) {
   ctc_lds_body(logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_inf, blockIdx.x);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void ctc_lds_kernel(const float* __restrict__ 
 #define AVEC_CTC_MAX_HEADS 8
 struct CtcHeads { const float* logits[AVEC_CTC_MAX_HEADS]; const long long* in_lens[AVEC_CTC_MAX_HEADS]; float* nll[AVEC_CTC_MAX_HEADS]; float* mean_out[AVEC_CTC_MAX_HEADS];
                   float* grad[AVEC_CTC_MAX_HEADS]; int T[AVEC_CTC_MAX_HEADS]; float w[AVEC_CTC_MAX_HEADS]; float* total; };
-__global__ __launch_bounds__(256) void ctc_lds_multi_kernel(CtcHeads h, const long long* __restrict__ targets, const long long* __restrict__ tgt_lens,
+__global__ __launch_bounds__(1024) void ctc_lds_multi_kernel(CtcHeads h, const long long* __restrict__ targets, const long long* __restrict__ tgt_lens,
                                                             int B, int V, int Lmax, int blank, int zero_inf) {
   const int head = blockIdx.x / B, b = blockIdx.x - head * B;
   ctc_lds_body(h.logits[head], h.in_lens[head], targets, tgt_lens, h.nll[head], h.mean_out[head], h.grad[head], B, h.T[head], V, Lmax, blank, zero_inf, b, h.total, h.w[head]);
@@ -272,6 +276,20 @@ __global__ __launch_bounds__(256) void ctc_alpha_lds_kernel(const float* __restr
 
 extern "C" long long avec_ctc_workspace_floats(int B, int T, int Lmax) { return (long long)B * ((long long)T * (2 * Lmax + 1) + T); }
 
+// Waves per utterance of the all-LDS kernels: the log-normaliser and gradient phases work frame by frame, one frame per wave and pass -- 16 waves when their
+// occupancy histograms still fit the 64 KB (each is V floats), else 4.  AVEC_CTC_WAVES=4: the round-1 shape
+static int ctc_waves(size_t lds4, int V) {
+  static const int want = getenv("AVEC_CTC_WAVES") ? atoi(getenv("AVEC_CTC_WAVES")) : 16;
+  if (want < 16 || lds4 + (size_t)12 * V * 4 > 128 * 1024) return 4;
+  static bool attr_set = false, attr_ok = false;           // (more than 64 KB of dynamic LDS has to be asked for once per kernel)
+  if (!attr_set) {
+    attr_set = true;
+    attr_ok = hipFuncSetAttribute((const void*)ctc_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+              hipFuncSetAttribute((const void*)ctc_lds_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    if (!attr_ok) (void)hipGetLastError();
+  }
+  return (attr_ok || lds4 + (size_t)12 * V * 4 <= 64 * 1024) ? 16 : 4;
+}
 extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,
                              float* grad, float* workspace, int B, int T, int V, int Lmax, int blank, int zero_infinity, hipStream_t st) {
   AVEC_CHECK_ARG(logits && in_lens && targets && tgt_lens && nll && workspace, "ctc_loss: null pointer");
@@ -279,7 +297,8 @@ extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, cons
   const size_t Smax = 2 * (size_t)Lmax + 1;
   const size_t lds_fast = (3 * (size_t)T * Smax + T + 4 * (size_t)V + Smax) * 4;
   if (lds_fast <= 64 * 1024) {
-    hipLaunchKernelGGL(ctc_lds_kernel, dim3(B), dim3(256), lds_fast, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_infinity);
+    const int nw = ctc_waves(lds_fast, V);
+    hipLaunchKernelGGL(ctc_lds_kernel, dim3(B), dim3(64 * nw), lds_fast + (size_t)(nw - 4) * V * 4, st, logits, in_lens, targets, tgt_lens, nll, mean_out, grad, B, T, V, Lmax, blank, zero_infinity);
     AVEC_LAUNCH_CHECK(); return 0;
   }
   const size_t lds_alpha = ((size_t)T * Smax + T + 3 * Smax) * 4;
@@ -315,7 +334,8 @@ extern "C" int avec_ctc_loss_multi(int n_heads, const float* const* logits, cons
     if (need > lds) lds = need;
   }
   AVEC_CHECK_ARG(lds <= 64 * 1024, "ctc_loss_multi: a head does not fit the all-LDS kernel (use avec_ctc_loss per head)");
-  hipLaunchKernelGGL(ctc_lds_multi_kernel, dim3((unsigned)(n_heads * B)), dim3(256), lds, st, h, targets, tgt_lens, B, V, Lmax, blank, zero_infinity);
+  const int nw = ctc_waves(lds, V);
+  hipLaunchKernelGGL(ctc_lds_multi_kernel, dim3((unsigned)(n_heads * B)), dim3(64 * nw), lds + (size_t)(nw - 4) * V * 4, st, h, targets, tgt_lens, B, V, Lmax, blank, zero_infinity);
   AVEC_LAUNCH_CHECK(); return 0;
 }
 extern "C" int avec_ctc_loss_multi_fits(int T, int V, int Lmax) { const size_t S = 2 * (size_t)Lmax + 1; return (3 * (size_t)T * S + T + 4 * (size_t)V + S) * 4 <= 64 * 1024; }
