@@ -375,6 +375,28 @@ extern "C" int avec_scale_by_scalar(const float* g, const float* scalar_dev, flo
   AVEC_LAUNCH_CHECK(); return 0;
 }
 
+// the same for up to AVEC_CTC_MAX_HEADS tensors with their own factors in ONE launch (backward of the multi-head CTC loss: blockIdx.y = tensor)
+struct ScaleMulti { const float* g[AVEC_CTC_MAX_HEADS]; float* out[AVEC_CTC_MAX_HEADS]; long long n[AVEC_CTC_MAX_HEADS]; float mul[AVEC_CTC_MAX_HEADS]; };
+__global__ __launch_bounds__(256) void scale_by_scalar_multi_kernel(ScaleMulti m, const float* __restrict__ s) {
+  const int k = blockIdx.y;
+  const float f = (s ? *s : 1.f) * m.mul[k];
+  const float* __restrict__ g = m.g[k]; float* __restrict__ out = m.out[k]; const long long n = m.n[k];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = g[i] * f;
+}
+extern "C" int avec_scale_by_scalar_multi(int n_tensors, const float* const* g, float* const* out, const long long* numel, const float* mul, const float* scalar_dev, hipStream_t st) {
+  AVEC_CHECK_ARG(n_tensors >= 1 && n_tensors <= AVEC_CTC_MAX_HEADS && g && out && numel && mul, "scale_by_scalar_multi: bad arguments (%d tensors)", n_tensors);
+  ScaleMulti m; long long nmax = 0;
+  for (int i = 0; i < AVEC_CTC_MAX_HEADS; ++i) {
+    const int k = i < n_tensors ? i : 0;
+    AVEC_CHECK_ARG(g[k] && out[k] && numel[k] > 0, "scale_by_scalar_multi: null / empty tensor %d", k);
+    m.g[i] = g[k]; m.out[i] = out[k]; m.n[i] = numel[k]; m.mul[i] = mul[k];
+    if (numel[k] > nmax) nmax = numel[k];
+  }
+  long long nb = (nmax + 255) / 256; if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(scale_by_scalar_multi_kernel, dim3((unsigned)nb, (unsigned)n_tensors), dim3(256), 0, st, m, scalar_dev);
+  AVEC_LAUNCH_CHECK(); return 0;
+}
+
 // argmax over the last dim (greedy CTC decoding, nnet/decoders.py:97-120): first maximal index, like torch.argmax
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long long* __restrict__ out, long long M, int V) {
   const int lane = threadIdx.x & 63; const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -1325,7 +1325,7 @@ class CTCLossFn(torch.autograd.Function):
 class CTCLossMultiFn(torch.autograd.Function):
     """n CTC heads over the same batch and labels in one launch (avec_ctc_loss_multi): apply(blank, zero_infinity, targets, target_len, weights, logits_0, len_0, ...)
     -> (sum_i weights[i] * loss_i, loss_0, ..., loss_{n-1}); the individual batch-mean losses are returned for logging (not differentiable), the weighted sum
-    carries the gradient: backward is one scaling launch per head.  Same arithmetic per head as CTCLossFn (the kernel body is shared)."""
+    carries the gradient: backward is one scaling launch for all heads.  Same arithmetic per head as CTCLossFn (the kernel body is shared)."""
 
     @staticmethod
     def forward(ctx, blank, zero_infinity, targets, target_len, weights, *flat):
@@ -1349,6 +1349,7 @@ class CTCLossMultiFn(torch.autograd.Function):
                            arr_p([means[i:].data_ptr() for i in range(n)]), arr_p([g.data_ptr() if g is not None else None for g in grads]),
                            tg.data_ptr(), tl.data_ptr(), (ctypes.c_float * n)(*[float(x) for x in weights]), means[n:].data_ptr(), B, V, Lmax, blank, int(zero_infinity), rt.stream())
         total = means[n]
+        ctx.set_materialize_grads(False)                     # (the n logging outputs never receive a gradient: no zero-filled scalars made for them in backward)
         ctx.saved = (grads, B, n, [float(x) for x in weights])
         ctx.keep = (logits, ils, tg, tl, nll)
         outs = tuple(means[i] for i in range(n))
@@ -1359,14 +1360,17 @@ class CTCLossMultiFn(torch.autograd.Function):
     def backward(ctx, dtotal, *_unused):
         grads, B, n, weights = ctx.saved
         out = [None, None, None, None, None]
+        if dtotal is None:
+            return tuple(out + [None, None] * n)
         dt = dtotal.float().contiguous()
+        live = [i for i in range(n) if grads[i] is not None]
+        outs = {i: torch.empty_like(grads[i]) for i in live}
+        if live:                                             # one scaling launch for all heads
+            k = len(live)
+            lib.scale_by_scalar_multi(k, (ctypes.c_void_p * k)(*[grads[i].data_ptr() for i in live]), (ctypes.c_void_p * k)(*[outs[i].data_ptr() for i in live]),
+                                      (ctypes.c_longlong * k)(*[grads[i].numel() for i in live]), (ctypes.c_float * k)(*[weights[i] / B for i in live]), dt.data_ptr(), rt.stream())
         for i in range(n):
-            if grads[i] is None:
-                out += [None, None]
-                continue
-            o = torch.empty_like(grads[i])
-            lib.scale_by_scalar(grads[i].data_ptr(), dt.data_ptr(), weights[i] / B, o.data_ptr(), grads[i].numel(), rt.stream())
-            out += [o, None]
+            out += [outs.get(i), None]
         return tuple(out)
 
 

@@ -392,6 +392,9 @@ int avec_ctc_loss_multi(int n_heads, const float* const* logits, const long long
                         const long long* targets, const long long* tgt_lens, const float* weights, float* total, int B, int V, int Lmax, int blank, int zero_infinity, hipStream_t stream);
 /* (weights: n_heads host floats, total: optional device scalar, += sum_i weights[i] * mean loss of head i -- the weighted total of nnet/model.py:275-287 out of the same launch) */
 int avec_scale_by_scalar(const float* g, const float* scalar_dev, float mul, float* out, long long n, hipStream_t stream);
+/* out[k] = g[k] * (*scalar_dev) * mul[k] for n_tensors <= 8 tensors in one launch (arrays of host pointers / sizes / factors): the backward of avec_ctc_loss_multi's
+ * weighted total, nnet/model.py:275-287 */
+int avec_scale_by_scalar_multi(int n_tensors, const float* const* g, float* const* out, const long long* numel, const float* mul, const float* scalar_dev, hipStream_t stream);
 /* losses.SoftmaxCrossEntropy (nnet/losses.py:258-290; the LRW word classifier): per-row cross entropy of fp32 logits [M][V] against int64 targets,
  * rows with target == ignore_index give 0; mean_out (optional) += loss/M; grad (optional) = softmax - onehot */
 int avec_softmax_ce(const float* logits, const long long* targets, long long ignore_index, float* loss, float* mean_out, float* grad, long long M, int V, hipStream_t stream);
