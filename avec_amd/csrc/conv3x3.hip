@@ -528,6 +528,9 @@ __device__ __forceinline__ void c3_glds16(const void* gsrc, unsigned lds_dst_uni
 }
 typedef __attribute__((ext_vector_type(2))) unsigned c3_u32x2;
 __device__ __forceinline__ c3_u32x2 c3_lds_tr(unsigned lds_addr) { c3_u32x2 v; asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
+#ifndef C3W_ABL
+#define C3W_ABL 0         // timing experiments on the 64-channel weight gradient (tools/build_abl_c3w.sh): 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no final atomics
+#endif
 #define C3W_KROWS 512                       // reduction rows per image: H*(W+1) <= 512
 #define C3W_DBYTES (C3W_KROWS * 128)        // 65 536: dy image with the slab's row pitch
 
@@ -583,25 +586,38 @@ __device__ __forceinline__ void c3w_body(const C3WArgs& a, const int bid, const 
   for (long long n = bid; n < a.N; n += nwg) {
     __syncthreads();                         // every wave is done with the previous image
     const bf16* xi = a.x + n * HW * 64; const bf16* di = a.dy + n * HW * 64;
+    if (!(C3W_ABL & 2)) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c3_glds16(xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16, xs0 + (wave + 8 * i) * 1024);
+      for (int i = 0; i < 9; ++i) c3_glds16(xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16, xs0 + (wave + 8 * i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) c3_glds16(doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16, ds0 + (wave + 8 * i) * 1024);
+      for (int i = 0; i < 8; ++i) c3_glds16(doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16, ds0 + (wave + 8 * i) * 1024);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (compiler-scheduled reads, two steps unrolled: for this 4-5 MFMA step the hand-made ladder of wgrad3x3_wide_kernel measured 20 % slower)
 #pragma unroll 2
     for (int s = 0; s < C3W_KROWS / 16; ++s) {
       const int so = s * 2048;
-      const chunk16 fa = c3_tr_read8(Ds + offa[0] + so, Ds + offa[1] + so);
-      chunk16 fb[5];
+      chunk16 fa, fb[5];
+      if (!(C3W_ABL & 4)) {
+        fa = c3_tr_read8(Ds + offa[0] + so, Ds + offa[1] + so);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = c3_tr_read8(Xs + offb[j][0] + so, Xs + offb[j][1] + so);
-      if (five) fb[4] = c3_tr_read8(Xs + offb[4][0] + so, Xs + offb[4][1] + so);
+        for (int j = 0; j < 4; ++j) fb[j] = c3_tr_read8(Xs + offb[j][0] + so, Xs + offb[j][1] + so);
+        if (five) fb[4] = c3_tr_read8(Xs + offb[4][0] + so, Xs + offb[4][1] + so);
+      } else {
+        fa.w[0] = fa.w[1] = fa.w[2] = fa.w[3] = (unsigned)(so + lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[j], 0, 0, 0);
-      if (five) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[4]), acc[4], 0, 0, 0);
+        for (int j = 0; j < 5; ++j) fb[j].w[0] = fb[j].w[1] = fb[j].w[2] = fb[j].w[3] = (unsigned)(so * (j + 2) + lane);
+      }
+      if (!(C3W_ABL & 1)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[j], 0, 0, 0);
+        if (five) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[4]), acc[4], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { if (j == 4 && !five) break; acc[j][0] += __uint_as_float(fa.w[0] ^ fb[j].w[0]); acc[j][1] += __uint_as_float(fa.w[3] ^ fb[j].w[3]); }
+      }
     }
   }
 #pragma unroll
@@ -611,7 +627,7 @@ __device__ __forceinline__ void c3w_body(const C3WArgs& a, const int bid, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cohalf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cihalf * 32 + (lane & 31);
-      atomicAdd(a.dw + (long long)co * 576 + tap * 64 + ci, acc[j][r]);
+      if (!(C3W_ABL & 8) || acc[j][r] == 123.456f) atomicAdd(a.dw + (long long)co * 576 + tap * 64 + ci, acc[j][r]);
     }
   }
 }
