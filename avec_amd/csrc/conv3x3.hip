@@ -631,13 +631,125 @@ __device__ __forceinline__ void c3w_body(const C3WArgs& a, const int bid, const 
     }
   }
 }
-__global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) { c3w_body(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// Round 5: the same product with the next image ROLLING into the slab behind the k-steps.  In-kernel cycle counts of c3w_body (C3W_ABL 64, profiles/r05_c64_wgrad_ablation.txt):
+// 42 % of the kernel is the wait for the image's LDS-DMA (at 6.3 TB/s over the chip -- the rate is fine, nothing runs under it), 58 % the 32 k-steps.  A second pair of
+// buffers does not fit (139 KB), but k-step s only reads dy rows [16 s, 16 s + 16) and slab rows [16 s, 16 s + 16 + 2 (W+1) + 2): after the g-th group of 8 steps the rows
+// below 128 (g + 1) are dead, and the next image's rows can land there.  Four batches per image -- rows [128 g, 128 g + 128) of both regions, the last one the slab's
+// rows [384, 576) -- each issued at the barrier behind the group that frees its rows and awaited (counted vmcnt, batches land in issue order) two to three groups later:
+//   barrier before G0(n): needs b0(n), b1(n)   [b2(n) may be in flight: vmcnt(4)]   then issues b3(n)     (rows >= 384 were read by G3 of the previous image)
+//   barrier before G1(n): needs b2(n)          [b3(n): vmcnt(5)]                    then issues b0(n+1)
+//   barrier before G2(n): needs b3(n)          [b0(n+1): vmcnt(4)]                  then issues b1(n+1)
+//   barrier before G3(n): needs nothing new                                         then issues b2(n+1)
+// Every piece is issued by every wave whatever its lanes hold (border lanes fetch the shared zero chunk), so the counts are the same for all waves.
+template <int V> struct C3I { static constexpr int value = V; };
+__device__ __forceinline__ void c3w_roll_body(const C3WArgs& a, const int bid, const int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem; char* Ds = smem + C3_SBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, PW = W + 1, HW = H * W, NPIX = (H + 2) * PW + 1;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int xoff[9], doff[8];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+    const int py = (row - 1) / PW, px = (row - 1) - py * PW;
+    const bool in = row >= 1 && row < NPIX && py >= 1 && py <= H && px < W;
+    xoff[i] = in ? ((py - 1) * W + px) * 64 + c * 8 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int S = (wave + 8 * i) * 64 + lane, row = S >> 3, c = (S & 7) ^ (4 * ((row >> 1) & 1));
+    const int oy = row / PW, ox = row - oy * PW;
+    doff[i] = (oy < H && ox < W) ? (oy * W + ox) * 64 + c * 8 : -1;
+  }
+  const int cohalf = (wave >> 1) & 1, cihalf = wave & 1, tap0 = wave >> 2;
+  const bool five = wave < 4;
+  const int g4 = lane >> 4, t = lane & 15;
+  int offa[2], offb[5][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int krow = 8 * (g4 >> 1) + 4 * h + (t >> 2);
+    const int cbA = cohalf * 32 + 16 * (g4 & 1), cbB = cihalf * 32 + 16 * (g4 & 1);
+    offa[h] = krow * 128 + ((((cbA >> 3) + ((t & 3) >> 1)) ^ (4 * ((krow >> 1) & 1))) << 4) + (t & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tap = j < 4 ? tap0 + 2 * j : 8;
+      const int rowd = krow + (tap / 3) * PW + (tap % 3);
+      offb[j][h] = rowd * 128 + ((((cbB >> 3) + ((t & 3) >> 1)) ^ (4 * ((rowd >> 1) & 1))) << 4) + (t & 1) * 8;
+    }
+  }
+  c3_f32x16 acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const unsigned xs0 = (unsigned)(uintptr_t)(lptr_t)Xs, ds0 = (unsigned)(uintptr_t)(lptr_t)Ds;
+  auto batch = [&](auto gc, const long long n) {          // batch G of image n: slab pieces [2G, 2G + 2) (G = 3: [6, 9)) and dy pieces [2G, 2G + 2) of this wave
+    constexpr int G = decltype(gc)::value;
+    const bf16* xi = a.x + n * HW * 64; const bf16* di = a.dy + n * HW * 64;
+#pragma unroll
+    for (int i = 2 * G; i < (G == 3 ? 9 : 2 * G + 2); ++i) c3_glds16(xoff[i] >= 0 ? (const void*)(xi + xoff[i]) : (const void*)c3_zero16, xs0 + (wave + 8 * i) * 1024);
+#pragma unroll
+    for (int i = 2 * G; i < 2 * G + 2; ++i) c3_glds16(doff[i] >= 0 ? (const void*)(di + doff[i]) : (const void*)c3_zero16, ds0 + (wave + 8 * i) * 1024);
+  };
+  auto group = [&](auto gc) {                              // k-steps [8G, 8G + 8)
+    constexpr int G = decltype(gc)::value;
+#pragma unroll 2
+    for (int s = 8 * G; s < 8 * G + 8; ++s) {
+      const int so = s * 2048;
+      const chunk16 fa = c3_tr_read8(Ds + offa[0] + so, Ds + offa[1] + so);
+      chunk16 fb[5];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = c3_tr_read8(Xs + offb[j][0] + so, Xs + offb[j][1] + so);
+      if (five) fb[4] = c3_tr_read8(Xs + offb[4][0] + so, Xs + offb[4][1] + so);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[j]), acc[j], 0, 0, 0);
+      if (five) acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa), __builtin_bit_cast(c3_bf16x8, fb[4]), acc[4], 0, 0, 0);
+    }
+  };
+  long long n = bid;
+  if (n < a.N) { batch(C3I<0>{}, n); batch(C3I<1>{}, n); batch(C3I<2>{}, n); }
+  for (; n < a.N; n += nwg) {
+    const long long nx = n + nwg; const bool more = nx < a.N;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads();
+    batch(C3I<3>{}, n);
+    group(C3I<0>{});
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); __syncthreads();
+    if (more) batch(C3I<0>{}, nx);
+    group(C3I<1>{});
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (more) batch(C3I<1>{}, nx);
+    group(C3I<2>{});
+    __syncthreads();
+    if (more) batch(C3I<2>{}, nx);
+    group(C3I<3>{});
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j == 4 && !five) break;
+    const int tap = j < 4 ? tap0 + 2 * j : 8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cohalf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cihalf * 32 + (lane & 31);
+      atomicAdd(a.dw + (long long)co * 576 + tap * 64 + ci, acc[j][r]);
+    }
+  }
+}
+#ifndef C3W_ROLL
+#define C3W_ROLL 1        // 0: one image per iteration, its DMA awaited with nothing under it (c3w_body)
+#endif
+__global__ __launch_bounds__(512) void wgrad3x3_c64_kernel(C3WArgs a) { if (C3W_ROLL) c3w_roll_body(a, (int)blockIdx.x, (int)gridDim.x); else c3w_body(a, (int)blockIdx.x, (int)gridDim.x); }
 // several 64-channel layers' weight gradients as ONE grid: the workgroups are shared out evenly, the final atomics (256 x 36 864 sums per launch) are paid once
 struct C3WGroup { C3WArgs it[AVEC_WGRAD_GROUP_MAX]; int first[AVEC_WGRAD_GROUP_MAX + 1]; int n; };
 __global__ __launch_bounds__(512) void wgrad3x3_c64_grouped_kernel(C3WGroup grp) {
   int i = 0;
   while (i + 1 < grp.n && (int)blockIdx.x >= grp.first[i + 1]) ++i;
-  c3w_body(grp.it[i], (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i]);
+  if (C3W_ROLL) c3w_roll_body(grp.it[i], (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i]);
+  else c3w_body(grp.it[i], (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
