@@ -535,6 +535,10 @@ __device__ __forceinline__ c3_u32x2 c3_lds_tr(unsigned lds_addr) { c3_u32x2 v; a
 #define C3W_DBYTES (C3W_KROWS * 128)        // 65 536: dy image with the slab's row pitch
 
 struct C3WArgs { const bf16* x; const bf16* dy; float* dw; int N, H, W; };
+#if C3W_ABL & 64
+__device__ float c3w_dbg[128];               // per workgroup (first 16): cycles of wave 0 in the four waits of an image and in the k-step groups
+extern "C" int avec_c3w_debug(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c3w_dbg), sizeof(float) * 128); }
+#endif
 
 // bid / nwg: this workgroup's index among the nwg workgroups that share the product
 __device__ __forceinline__ void c3w_body(const C3WArgs& a, const int bid, const int nwg) {
@@ -712,22 +716,37 @@ __device__ __forceinline__ void c3w_roll_body(const C3WArgs& a, const int bid, c
   };
   long long n = bid;
   if (n < a.N) { batch(C3I<0>{}, n); batch(C3I<1>{}, n); batch(C3I<2>{}, n); }
+#if C3W_ABL & 64
+  unsigned long long tw[4] = {0, 0, 0, 0}, tg = 0;
+#define C3W_T0 const unsigned long long c_0 = __builtin_readcyclecounter();
+#define C3W_TW(k) { const unsigned long long c_1 = __builtin_readcyclecounter(); tw[k] += c_1 - c_0; }
+#define C3W_TG0 const unsigned long long c_2 = __builtin_readcyclecounter();
+#define C3W_TG1 { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[3][15])); tg += __builtin_readcyclecounter() - c_2; }
+#else
+#define C3W_T0
+#define C3W_TW(k)
+#define C3W_TG0
+#define C3W_TG1
+#endif
   for (; n < a.N; n += nwg) {
     const long long nx = n + nwg; const bool more = nx < a.N;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads();
+    { C3W_T0 asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads(); C3W_TW(0) }
     batch(C3I<3>{}, n);
-    group(C3I<0>{});
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); __syncthreads();
+    { C3W_TG0 group(C3I<0>{}); C3W_TG1 }
+    { C3W_T0 asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); __syncthreads(); C3W_TW(1) }
     if (more) batch(C3I<0>{}, nx);
-    group(C3I<1>{});
-    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    { C3W_TG0 group(C3I<1>{}); C3W_TG1 }
+    { C3W_T0 if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads(); C3W_TW(2) }
     if (more) batch(C3I<1>{}, nx);
-    group(C3I<2>{});
-    __syncthreads();
+    { C3W_TG0 group(C3I<2>{}); C3W_TG1 }
+    { C3W_T0 __syncthreads(); C3W_TW(3) }
     if (more) batch(C3I<2>{}, nx);
-    group(C3I<3>{});
+    { C3W_TG0 group(C3I<3>{}); C3W_TG1 }
   }
+#if C3W_ABL & 64
+  if (tid == 0 && bid < 16) { for (int k = 0; k < 4; ++k) c3w_dbg[bid * 8 + k] = (float)tw[k]; c3w_dbg[bid * 8 + 4] = (float)tg; }
+#endif
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     if (j == 4 && !five) break;

@@ -26,6 +26,15 @@ def main():
     us = timed(lambda: lib.wgrad3x3_c64_grouped(arr, len(items), rt.stream()))
     byt = 4 * 2 * N * H * W * C * 2
     print("%s grouped 4 layers  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s (algorithmic)   %s" % (os.environ.get("AVEC_LIB_PATH", "default"), us, flops / us / 1e6, byt / us / 1e6, lib.raw("avec_last_kernel")().decode()))
+    try:
+        import ctypes, numpy as np
+        f = lib.raw("avec_c3w_debug")
+        out = (ctypes.c_float * 128)()
+        f(out)
+        v = np.array(out[:]).reshape(16, 8).mean(0)
+        print("  in-kernel cycles of wave 0 (mean of 16 workgroups): waits before G0 %.0f  G1 %.0f  G2 %.0f  G3 %.0f   k-step groups %.0f" % (v[0], v[1], v[2], v[3], v[4]))
+    except Exception:
+        pass
     if not os.environ.get("AVEC_LIB_PATH"):
         xf, dyf = keep[0][0].float(), keep[0][1].float().view(N, H, W, C)
         ref = torch.nn.grad.conv2d_weight(xf[:64].permute(0, 3, 1, 2), (C, C, 3, 3), dyf[:64].permute(0, 3, 1, 2), padding=1)      # [co][ci][kh][kw]

@@ -5,7 +5,7 @@ mkdir -p tools/_bin
 python -m avec_amd.build > /dev/null
 OTHERS=$(ls avec_amd/csrc/_obj/*.o | grep -v "/conv3x3.o")
 for n in "$@"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iavec_amd/csrc -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -DC3W_ABL=$n -c avec_amd/csrc/conv3x3.hip -o tools/_bin/c3w_abl_$n.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iavec_amd/csrc -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -DC3W_ABL=$n $C3W_EXTRA -c avec_amd/csrc/conv3x3.hip -o tools/_bin/c3w_abl_$n.o &
 done
 wait
 for n in "$@"; do

@@ -15,7 +15,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
 
-template <int MODE, int NT, int UNIT>
+__device__ __attribute__((aligned(64))) unsigned char zero16[64];
+template <int MODE, int NT, int UNIT, int PAT = 0>
 __global__ __launch_bounds__(NT) void stream_kernel(const char* __restrict__ buf, long long slice, unsigned* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PER = UNIT / (NT * 16);                       // 16-byte pieces per thread and unit
@@ -26,9 +27,17 @@ __global__ __launch_bounds__(NT) void stream_kernel(const char* __restrict__ buf
   uint4 acc = {0, 0, 0, 0};
   if (MODE == 0) {
     auto issue = [&](int u) {
-      const char* src = base + (long long)u * UNIT + lane * 16;
+      const long long uoff = PAT == 4 ? ((long long)u * gridDim.x + blockIdx.x) * UNIT - (long long)blockIdx.x * slice : (long long)u * UNIT;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) glds16(src + (wave + (NT / 64) * i) * 1024, lds0 + (u & 1) * UNIT + (wave + (NT / 64) * i) * 1024);
+      for (int i = 0; i < PER; ++i) {
+        const int piece = wave + (NT / 64) * i;
+        const int row = piece * 8 + (lane >> 3); int c = lane & 7;
+        if (PAT == 1 || PAT == 2) c ^= 4 * ((row >> 1) & 1);
+        const char* src = base + uoff + (long long)row * 128 + c * 16;
+        if (PAT == 3 && (i & 1)) src += slice * (gridDim.x / 2) ;           // second stream: the other half of the buffer (workgroups use the first half only)
+        if (PAT == 2 && row % 23 == 22) src = (const char*)zero16;
+        glds16(src, lds0 + (u & 1) * UNIT + piece * 1024);
+      }
     };
     issue(0);
     for (int u = 0; u < units; ++u) {
@@ -66,15 +75,15 @@ __global__ __launch_bounds__(NT) void stream_kernel(const char* __restrict__ buf
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
 }
 
-template <int MODE, int NT, int UNIT>
+template <int MODE, int NT, int UNIT, int PAT = 0>
 void run(const char* name, const char* buf, long long bytes, unsigned* sink, int wgs) {
-  const long long slice = bytes / wgs / UNIT * UNIT;
+  const long long slice = (PAT == 3 ? bytes / 2 : bytes) / wgs / UNIT * UNIT;
   const size_t lds = MODE == 2 ? 0 : 2 * UNIT;
-  CK(hipFuncSetAttribute((const void*)stream_kernel<MODE, NT, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)stream_kernel<MODE, NT, UNIT, PAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((stream_kernel<MODE, NT, UNIT>), dim3(wgs), dim3(NT), lds, 0, buf, slice, sink);
+    hipLaunchKernelGGL((stream_kernel<MODE, NT, UNIT, PAT>), dim3(wgs), dim3(NT), lds, 0, buf, slice, sink);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (rep == 1) printf("%-58s %4d wg x %4d thr, unit %3d KB: %8.1f us  %6.2f TB/s  (%5.1f GB/s per workgroup)\n", name, wgs, NT, UNIT / 1024, ms * 1e3, slice * wgs / ms / 1e9, slice / ms / 1e6);
@@ -89,6 +98,10 @@ int main(int argc, char** argv) {
   run<0, 1024, 65536>("LDS-DMA, 16 waves, 2 x 64 KB ring", buf, bytes, sink, 256);
   run<0, 256, 32768>("LDS-DMA, 4 waves, 2 x 32 KB ring, 2 wg / CU", buf, bytes, sink, 512);
   run<0, 256, 16384>("LDS-DMA, 4 waves, 2 x 16 KB ring, 4 wg / CU", buf, bytes, sink, 1024);
+  run<0, 512, 65536, 1>("LDS-DMA, 8 waves: chunks of odd row pairs XOR-swizzled", buf, bytes, sink, 256);
+  run<0, 512, 65536, 2>("LDS-DMA, 8 waves: swizzled + every 23rd row from a zero chunk", buf, bytes, sink, 256);
+  run<0, 512, 65536, 3>("LDS-DMA, 8 waves: two streams, alternating pieces", buf, bytes, sink, 256);
+  run<0, 512, 65536, 4>("LDS-DMA, 8 waves: units strided over the workgroups", buf, bytes, sink, 256);
   run<1, 512, 65536>("loads -> VGPR -> ds_write, 8 waves, 64 KB units", buf, bytes, sink, 256);
   run<1, 1024, 65536>("loads -> VGPR -> ds_write, 16 waves, 64 KB units", buf, bytes, sink, 256);
   run<1, 256, 32768>("loads -> VGPR -> ds_write, 4 waves, 32 KB units, 2 wg / CU", buf, bytes, sink, 512);
