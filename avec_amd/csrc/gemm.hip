@@ -973,7 +973,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_shift_kernel(GemmArgs g) {
   char* const Bring = smem; char* const Awin = smem + STAGES * BTILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.x * BM; const int n0 = blockIdx.y * BN;
+  // Tile order (g.pTs[0] = 1 for this kernel, which has no parity classes: XCD-aware).  In launch order (row tile fastest, workgroups dealt round-robin to the 8 XCDs) the column tiles of a row tile run a
+  // whole grid column apart, on any XCD: every one re-fetches its window from the fabric (stage 3: 2 x, stage 4: 4 x the activation), and every XCD streams every weight
+  // tile.  Here XCD x takes a contiguous range of logical ids; inside a group of two column tiles the column is the fastest index, so a window is fetched by ONE L2 (the
+  // partner tile follows on the same XCD) and the two weight tiles of the group (<= 2.4 MB) stay resident in it.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  if (g.pTs[0] && gridDim.y > 1 && !(gridDim.y & 1)) {
+    const int lid = xcd_logical((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int per = (int)gridDim.x * 2, cg = lid / per, rem = lid - cg * per;
+    bx = rem >> 1; by = cg * 2 + (rem & 1);
+  }
+  const long long m0 = (long long)bx * BM; const int n0 = by * BN;
   const int Wd = g.a.W, H = g.a.H, C = g.a.C, halo = Wd + 1;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -2122,7 +2132,8 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
   const RowSrc& a = g_in.a;
   if (off || mode == MODE_PLAIN || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW || a.W > 31 || a.C % 32 != 0) return 1;
   if (!aligned16(a.ptr) || !aligned16(g_in.W) || g_in.ldw % 8 != 0 || g_in.M * a.C >= (1ll << 31) || (long long)g_in.N * g_in.ldw >= (1ll << 31) || g_in.N < 64) return 1;
-  GemmArgs g = g_in; g.perm2 = 0;
+  static const bool xcd_order = getenv("AVEC_SHIFT_XCD") ? atoi(getenv("AVEC_SHIFT_XCD")) != 0 : true;
+  GemmArgs g = g_in; g.perm2 = 0; g.pTs[0] = xcd_order ? 1 : 0;        // (no parity classes here: pTs[0] is this kernel's tile-order switch)
 #define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64 + 512 + (BM / 64 - 1) * 2048, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
     avec_note_kernel("conv3x3_shift_kernel<%d,%d,%d>", BM, BN, MODE); if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE>), grid, dim3(256), lds, st, g); return 0; } while (0)
