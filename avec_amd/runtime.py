@@ -146,7 +146,7 @@ def branch_stream():
 # would each cost a fill launch.  They are carved out of one buffer that a training step zeroes ONCE at its start (Model.train_step / the
 # captured graph body); allocations only move forward inside a step, so nothing handed out is reused before the next reset.  Outside a
 # training step (evaluation, direct op calls) the pool is never reset: once exhausted, plain torch.zeros takes over.
-_ZPOOL = {"buf": {}, "off": {}, "floats": 128 << 20}       # 512 MB: also the atomically accumulated outputs of the split-F module kernels (csrc/chain.hip); only what a step used is re-zeroed
+_ZPOOL = {"buf": {}, "off": {}, "floats": 128 << 20}       # 512 MB of address space; only what a step used (its high-water mark: ~0.36 GB at the bench shape, mostly the skewed dS matrices of the attention backward) is re-zeroed
 
 
 def zeros_scratch(n, device):
