@@ -1,0 +1,661 @@
+// Device-side pieces shared by the MFMA product / convolution kernels (gemm.hip, conv_s2.hip): operand row maps, the argument block, the staged and the
+// register-direct epilogues, LDS-DMA helpers.  Split out of gemm.hip in round 6 so that a new kernel family compiles as its own translation unit.
+#pragma once
+// MFMA GEMM family for gfx950 (CDNA4, wave64).
+//
+//   gemm_nt :  C[m][n] = epi( sum_k A[m][k] * W[n][k] )          (Linear fwd / dX, conv fwd / bwd-data)
+//   gemm_tn :  O[i][j] += sum_m P[m][i] * Q[m][j]                 (weight gradients, split over m, fp32 atomics)
+//
+// A / Q operands come from "row loaders": plain row-major (optional strided row remap, optional fp32->bf16
+// conversion while staging) and NHWC implicit-GEMM im2col (forward, and transposed = backward-data).
+// One LDS image serves both dtypes: each tile row holds 128 bytes of K (64 bf16 / 32 fp32) + 16 bytes padding
+// (row stride 144 B = 9 x 16 B => ds_read_b128 conflict-free).  Two LDS buffers: the global loads of tile k+1
+// are issued before the MFMAs of tile k and land in registers; they are written to the other buffer after the
+// MFMAs => one barrier per K-step and the HBM/L2 latency hides under the matrix work.
+// Every global load is UNCONDITIONAL (invalid rows/taps read a clamped address and are zeroed when staged):
+// hipcc otherwise puts `s_waitcnt vmcnt(0)` behind each load issued under a divergent branch and serialises them.
+// MFMA: v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fp32 for the parity tests).
+#include "vec.h"
+#include "avec_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// kernel ablation builds (tools/build_abl.sh): bit 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no barrier, 16 no global stores, 32 no epilogue,
+// 64 / 128 no A / B DMA of the shifted-window kernel.  0 in the product.
+#ifndef AVEC_ABL
+#define AVEC_ABL 0
+#endif
+#ifndef AVEC_NT_XCD
+#define AVEC_NT_XCD 1
+#endif
+
+static constexpr int BKB = 128;      // bytes of K per LDS tile row
+static constexpr int LDS_ROW = 144;  // padded LDS row stride in bytes
+
+enum { MODE_PLAIN = 0, MODE_CONV_FWD = 1, MODE_CONV_BWD = 2 };
+
+struct RowSrc {
+  const void* ptr;
+  long long ld;                       // plain: row stride in elements
+  int rows_out, rows_in, step;        // plain: src_row = (m / rows_out) * rows_in + (m % rows_out) * step  (step<=1: identity)
+  int H, W, C, KH, KW, stride, pad, OH, OW;  // conv geometry
+};
+
+struct RowInfo { long long base; int a, b; int valid; };
+
+// ---- row decomposition (constant across the K loop) ----
+template <int MODE>
+__device__ __forceinline__ RowInfo row_info(const RowSrc& s, long long m, long long M) {
+  RowInfo r; r.valid = m < M; r.base = 0; r.a = 0; r.b = 0;
+  if (!r.valid) return r;
+  if (MODE == MODE_PLAIN) {
+    long long row = m;
+    if (s.step > 1) row = (m / s.rows_out) * (long long)s.rows_in + (m % s.rows_out) * (long long)s.step;
+    r.base = row * s.ld;
+  } else if (MODE == MODE_CONV_FWD) {      // m -> (img, oh, ow); source x[img][H][W][C]
+    int ow = (int)(m % s.OW); long long t = m / s.OW; int oh = (int)(t % s.OH); long long img = t / s.OH;
+    r.base = img * (long long)s.H * s.W * s.C; r.a = oh * s.stride - s.pad; r.b = ow * s.stride - s.pad;
+  } else {                                  // CONV_BWD: m -> (img, ih, iw) over HxW; source dy[img][OH][OW][C]
+    int iw = (int)(m % s.W); long long t = m / s.W; int ih = (int)(t % s.H); long long img = t / s.H;
+    r.base = img * (long long)s.OH * s.OW * s.C; r.a = ih + s.pad; r.b = iw + s.pad;
+  }
+  return r;
+}
+
+// ---- pending chunk: raw loaded words + how to finish them when they are staged into LDS ----
+struct Pend { chunk16 lo, hi; int flags; };   // flags bit0: valid, bit1: only the first half of the chunk is inside K (tail)
+
+// element offset of (row r, K index k) or -1;  conv: (kh, kw, c) precomputed by the caller
+template <int MODE>
+__device__ __forceinline__ long long conv_offset(const RowSrc& s, const RowInfo& r, int kh, int kw, int c) {
+  if (MODE == MODE_CONV_FWD) {
+    const int ih = r.a + kh, iw = r.b + kw;
+    const bool ok = r.valid && ih >= 0 && ih < s.H && iw >= 0 && iw < s.W;
+    return ok ? r.base + ((long long)ih * s.W + iw) * s.C + c : -1;
+  } else {
+    const int th = r.a - kh, tw = r.b - kw;
+    int oh = th, ow = tw; bool ok = r.valid && th >= 0 && tw >= 0;
+    if (s.stride == 2) { ok = ok && !((th | tw) & 1); oh = th >> 1; ow = tw >> 1; }
+    else if (s.stride != 1) { oh = th / s.stride; ow = tw / s.stride; ok = ok && oh * s.stride == th && ow * s.stride == tw; }
+    ok = ok && oh < s.OH && ow < s.OW;
+    return ok ? r.base + ((long long)oh * s.OW + ow) * s.C + c : -1;
+  }
+}
+
+// issue the (unconditional) loads of one chunk.  Requirements checked on the host: bf16 element offsets are even (every access
+// dword aligned) and K >= VEC.  A chunk is whole, a tail (nvalid < VEC elements inside K) or empty.  A tail reads the LAST full
+// 16 bytes of the row (in bounds) and is shifted down when staged; flags = valid | (elements to shift) << 4.
+template <typename T, bool SRC_F32, bool A16>
+__device__ __forceinline__ Pend issue_load(const void* base, long long off, int k, int K) {
+  constexpr int VEC = Elt<T>::VEC;
+  Pend p;
+  const bool valid = off >= 0 && k < K;
+  const int sh = (valid && k + VEC > K) ? (k + VEC - K) : 0;        // elements of the chunk beyond K
+  p.flags = (valid ? 1 : 0) | (sh << 4);
+  if (SRC_F32 && sizeof(T) == 2) {                  // 8 fp32 source elements -> one bf16 chunk (host guarantees K % 4 == 0: sh in {0, 4})
+    const float* q = (const float*)base + (valid ? off : 0);
+    if (A16) { p.lo = *(const chunk16*)q; p.hi = *(const chunk16*)(q + ((sh || !valid) ? 0 : 4)); }
+    else { p.lo = ldg16(q); p.hi = ldg16(q + ((sh || !valid) ? 0 : 4)); }
+  } else {
+    const T* q = (const T*)base + (valid ? off - sh : 0);
+    if (A16) p.lo = *(const chunk16*)q; else p.lo = ldg16(q);     // A16: the host proved every chunk address 16-byte aligned -> one dwordx4
+    p.hi = p.lo;
+  }
+  return p;
+}
+
+template <typename T, bool SRC_F32>
+__device__ __forceinline__ chunk16 finish_load(const Pend& p) {
+  chunk16 o;
+  const int sh = p.flags >> 4;
+  if (SRC_F32 && sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      o.w[e] = f32x2_to_bf16x2(__uint_as_float(p.lo.w[2 * e]), __uint_as_float(p.lo.w[2 * e + 1]));
+      o.w[2 + e] = f32x2_to_bf16x2(__uint_as_float(p.hi.w[2 * e]), __uint_as_float(p.hi.w[2 * e + 1]));
+    }
+    if (sh) { o.w[2] = 0u; o.w[3] = 0u; }
+  } else {
+    o = p.lo;
+    if (sh) {                                        // shift the 128-bit chunk down by `sh` elements (rare: only the K tail)
+      int ws = (sizeof(T) == 4) ? sh : (sh >> 1);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) if (ws > t) { o.w[0] = o.w[1]; o.w[1] = o.w[2]; o.w[2] = o.w[3]; o.w[3] = 0u; }
+      if (sizeof(T) == 2 && (sh & 1)) {
+        o.w[0] = (o.w[0] >> 16) | (o.w[1] << 16); o.w[1] = (o.w[1] >> 16) | (o.w[2] << 16);
+        o.w[2] = (o.w[2] >> 16) | (o.w[3] << 16); o.w[3] = o.w[3] >> 16;
+      }
+    }
+  }
+  if (!(p.flags & 1)) { o.w[0] = o.w[1] = o.w[2] = o.w[3] = 0u; }
+  return o;
+}
+
+struct Epi {
+  void* out; long long ldo; int out_f32;
+  void* out_pre; long long ldpre;
+  const float* bias;
+  int act;                         // 0 none, 1 swish, 2 relu (forward activation)
+  float drop_p; const unsigned long long* rng; unsigned stream;
+  const void* res; long long ldres; float alpha; int res_act;
+  const void* dact_z; long long ldz; int dact;   // multiply by act'(z) (1 swish, 2 relu)
+  float* colsum;                   // += column sums of v (bias gradient)
+  float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
+  const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;      // BatchNorm-backward fusion (avec_hip.h): v = alpha*acc + res; mask; stats += (v, v*y)
+  int res_cls0;                    // parity-class order: `res` has one row per class-0 pixel (class-local index), none for the other classes
+};
+
+#ifndef AVEC_TN_BUILTIN_DMA
+#define AVEC_TN_BUILTIN_DMA 0
+#endif
+#ifndef AVEC_TN_CONV_ASM
+#define AVEC_TN_CONV_ASM 1
+#endif
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): id w runs on XCD w % 8.  xcd_logical() gives XCD x the CONTIGUOUS range of
+// logical ids [x*q + min(x, r), ...) (q = total / 8, r = total % 8), so that workgroups with neighbouring logical ids -- the tiles that share a reduction
+// slice of both operands -- fill ONE L2 instead of eight.
+__device__ __forceinline__ int xcd_logical(int w, int total) {
+  const int q = total >> 3, r = total & 7, x = w & 7;
+  return x * q + (x < r ? x : r) + (w >> 3);
+}
+
+struct GemmArgs { RowSrc a; const void* W; long long ldw; long long M; int N, K; Epi e; int fast_conv;    // fast_conv: 32-bit row offsets + per-row tap masks (glds kernel)
+                  // parity classes (backward-data of a stride-2 convolution, glds kernel): input pixels are visited class by class, class = (ih & 1) * 2 + (iw & 1);
+                  // inside a class every row uses the same taps (kh = ih + pad mod 2, kw likewise), so a tile runs only those K-steps: 9 of 36 tap-rows for 3x3
+                  int perm2, pTs[5]; long long pImgs;        // pTs: first tile of each class (pTs[4] = grid size), pImgs: images
+                  int ktail; };                              // plain bf16 rows whose K is 8n + 4 (the 180- / 540-wide audio stage), glds kernel: the last chunk is fixed up in LDS
+
+__device__ __host__ __forceinline__ long long perm2_count(const RowSrc& s, int cls, long long imgs) {      // pixels of a class
+  return imgs * ((s.H + 1 - (cls >> 1)) >> 1) * ((s.W + 1 - (cls & 1)) >> 1);
+}
+
+// parity-class order -> pixel (img, ih, iw) of class-local index mc
+__device__ __forceinline__ void perm2_pixel(const RowSrc& s, int cls, long long mc, long long& img, int& ih, int& iw) {
+  const int Wc = (s.W + 1 - (cls & 1)) >> 1, Hc = (s.H + 1 - (cls >> 1)) >> 1;
+  const int bq = (int)(mc % Wc); const long long t = mc / Wc; const int aq = (int)(t % Hc); img = t / Hc;
+  ih = 2 * aq + (cls >> 1); iw = 2 * bq + (cls & 1);
+}
+
+// csrc/conv_s2.hip: 3x3 / stride-2 shifted-window kernels over the parity classes.  1 = not applicable, 0 = launched, other = error
+int avec_launch_conv_s2(const GemmArgs& g, int mode, hipStream_t st);
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  __device__ static __forceinline__ void run(const chunk16& a, const chunk16& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(const chunk16& a, const chunk16& b, f32x16& c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w[t]), __uint_as_float(b.w[t]), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wm, int wn, int frag_off, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    chunk16 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *(const chunk16*)(As + (wm * (BM / 2) + i * 32) * LDS_ROW + frag_off + kk * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = *(const chunk16*)(Bs + (wn * (BN / 2) + j * 32) * LDS_ROW + frag_off + kk * 32);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+  }
+}
+
+// 4 elements as they lie in memory (conversion deferred: the loads of several rows are issued before any arithmetic); same values as ld4<T>
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16> { uint2 t; __device__ __forceinline__ void load(const bf16* p) { t = *(const uint2*)p; }
+  __device__ __forceinline__ void get(float v[4]) const { v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); } };
+template <> struct Raw4<float> { float4 t; __device__ __forceinline__ void load(const float* p) { t = *(const float4*)p; }
+  __device__ __forceinline__ void get(float v[4]) const { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
+
+// ---- shared epilogue of the NT kernels ----
+template <typename T, int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, long long m0, int n0, int tid, int lane, int wm, int wn, int perm_cls = 0) {
+  // ---- epilogue: accumulators -> LDS (64-row passes) -> coalesced 4-wide rows with fused bias/act/dropout/residual/stats ----
+#if AVEC_ABL
+  if (AVEC_ABL & 32) {            // (every accumulator stays live: no dead-code elimination of the main loop)
+    float sacc = 0.f;
+    for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 1234.5f) ((float*)g.e.out)[0] = 1.f;
+    return;
+  }
+#endif
+  const Epi& e = g.e;
+  constexpr int CLD = BN + 4;                 // fp32 row stride of the staged C tile
+  constexpr int TPR = BN / 4;                 // threads per tile row
+  float* Cs = (float*)smem;
+  const int cg = (tid % TPR) * 4;             // this thread's 4 columns inside the tile (fixed across rows)
+  const int col = n0 + cg;
+  const bool vec_ok = (col + 3 < g.N);
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (col + c < g.N) bias4[c] = e.bias[col + c];
+  }
+  float csum[4] = {0.f, 0.f, 0.f, 0.f}, csq[4] = {0.f, 0.f, 0.f, 0.f};
+  const DropKey dk = drop_key(e.rng, e.stream, e.drop_p);      // (built once: {seed, step} are read here, not per element)
+#pragma unroll 1
+  for (int pass = 0; pass < BM / 64; ++pass) {
+    // a wave owns BM/2 rows = MT 32-row blocks; a pass stages 64 tile rows: both waves' single block (BM 64), one wave's two blocks (BM 128),
+    // or one half of a wave's four blocks (BM 256).  The block index stays a compile-time constant (no indexed register access).
+    if (BM == 64 || wm == pass / (BM / 128 > 0 ? BM / 128 : 1)) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (BM == 256 && (i >> 1) != (pass & 1)) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = (BM == 64 ? wm * 32 : 0) + (i & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[lr * CLD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+      }
+    }
+    __syncthreads();
+    // 4-wide vector I/O whenever the 4 columns are inside N and every row stride keeps them 8/16-byte aligned
+    const bool v4 = vec_ok && !(e.ldo & 3) && !(e.ldpre & 3) && !(e.ldres & 3) && !(e.ldz & 3);
+#if !AVEC_ABL
+    if (BN == 64 && v4 && !e.bnb_y && !g.perm2) {
+      // 64-column tiles (the conformer-sized products): the four row groups of a pass at once -- every residual / act'(z) row is requested before the first
+      // store, ONE memory round trip per pass instead of one per row group (the rolled loop below waits for its loads row group by row group: ~1 us each on
+      // kernels whose whole life is 4-6 us).  Each element is read and written by the same thread, so `out` may alias `res`.  Same arithmetic, same order.
+      constexpr int RPI = 256 / TPR, NIT = 64 / RPI;
+      const bool has_res = e.res != nullptr;
+      Raw4<T> rb[NIT], zb[NIT]; Raw4<float> rf[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const long long row = m0 + pass * 64 + tid / TPR + it * RPI;
+        if (row >= g.M) continue;
+        if (has_res) { if (e.res_act) rb[it].load((const T*)e.res + row * e.ldres + col); else rf[it].load((const float*)e.res + row * e.ldres + col); }
+        if (e.dact) zb[it].load((const T*)e.dact_z + row * e.ldz + col);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int lr = tid / TPR + it * RPI;
+        const long long row = m0 + pass * 64 + lr;
+        if (row >= g.M) continue;
+        float v[4];
+        { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bias4[c];
+        if (e.out_pre) st4<T>((T*)e.out_pre + row * e.ldpre + col, v);
+        if (e.act == 1) { for (int c = 0; c < 4; ++c) v[c] = swishf_(v[c]); } else if (e.act == 2) { for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f); }
+        if (e.drop_p > 0.f) {
+          const unsigned long long i0 = (unsigned long long)row * g.N + col;
+          if (!(g.N & 1)) { float ds[4]; drop4(dk, i0, ds); for (int c = 0; c < 4; ++c) v[c] *= ds[c]; }
+          else { for (int c = 0; c < 4; ++c) v[c] *= drop_one(dk, i0 + c); }
+        }
+        if (e.dact) {
+          float z[4]; zb[it].get(z);
+          for (int c = 0; c < 4; ++c) v[c] *= (e.dact == 1) ? dswishf_(z[c]) : (z[c] > 0.f ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * v[c]; v[c] *= e.alpha; }
+        if (has_res) {
+          float r4[4]; if (e.res_act) rb[it].get(r4); else rf[it].get(r4);
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+      }
+      __syncthreads();
+      continue;
+    }
+#endif
+#pragma unroll 1
+    for (int lr = tid / TPR; lr < 64; lr += 256 / TPR) {
+      long long row = m0 + pass * 64 + lr;
+      const long long rrow_cls = row;           // class-local row (res_cls0)
+      if (g.perm2) {                            // m0 is class-local here: map to the pixel's row of the output
+        if (row >= perm2_count(g.a, perm_cls, g.pImgs) || col >= g.N) continue;
+        long long img; int ih, iw; perm2_pixel(g.a, perm_cls, row, img, ih, iw);
+        row = (img * g.a.H + ih) * (long long)g.a.W + iw;
+      }
+      if (row >= g.M || col >= g.N) continue;
+      float v[4];
+      { const float4 t = *(const float4*)(Cs + lr * CLD + cg); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      if (v4 && e.bnb_y) {
+        // BatchNorm-backward fusion: the product is the gradient of a BatchNorm (+ ReLU) output: add the residual gradient first, apply the ReLU mask, accumulate
+        // (sum d, sum d*y) per column and store the masked gradient
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (v[c] + bias4[c]) * e.alpha;
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) {
+          const long long rrow = e.res_cls0 ? rrow_cls : row;
+          float r4[4];
+          if (e.res_act) ld4<T>((const T*)e.res + rrow * e.ldres + col, r4); else ld4<float>((const float*)e.res + rrow * e.ldres + col, r4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+        float y4[4]; ld4<T>((const T*)e.bnb_y + row * e.ldby + col, y4);
+        if (e.bnb_mask) {
+          float sc[4], sh[4]; ld4<float>(e.bnb_ss + col, sc); ld4<float>(e.bnb_ss + g.N + col, sh);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = (y4[c] * sc[c] + sh[c]) > 0.f ? v[c] : 0.f;
+        } else if (e.dact == 2) {
+          float z[4]; ld4<T>((const T*)e.dact_z + row * e.ldz + col, z);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = z[c] > 0.f ? v[c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * y4[c]; }
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+        continue;
+      }
+      if (v4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bias4[c];
+        if (e.out_pre) st4<T>((T*)e.out_pre + row * e.ldpre + col, v);
+        if (e.act == 1) { for (int c = 0; c < 4; ++c) v[c] = swishf_(v[c]); } else if (e.act == 2) { for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f); }
+        if (e.drop_p > 0.f) {
+          const unsigned long long i0 = (unsigned long long)row * g.N + col;
+          if (!(g.N & 1)) { float ds[4]; drop4(dk, i0, ds); for (int c = 0; c < 4; ++c) v[c] *= ds[c]; }      // (col % 4 == 0: the index is even)
+          else { for (int c = 0; c < 4; ++c) v[c] *= drop_one(dk, i0 + c); }
+        }
+        if (e.dact) {
+          float z[4]; ld4<T>((const T*)e.dact_z + row * e.ldz + col, z);
+          for (int c = 0; c < 4; ++c) v[c] *= (e.dact == 1) ? dswishf_(z[c]) : (z[c] > 0.f ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { csum[c] += v[c]; csq[c] += v[c] * v[c]; v[c] *= e.alpha; }
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) {
+          const long long rrow = e.res_cls0 ? rrow_cls : row;
+          float r4[4];
+          if (e.res_act) ld4<T>((const T*)e.res + rrow * e.ldres + col, r4); else ld4<float>((const float*)e.res + rrow * e.ldres + col, r4);
+          for (int c = 0; c < 4; ++c) v[c] += r4[c];
+        }
+#if AVEC_ABL
+        if (AVEC_ABL & 16) { if (v[0] == 1234.5f) st4<T>((T*)e.out + row * e.ldo + col, v); continue; }
+#endif
+        if (e.out_f32) st4<float>((float*)e.out + row * e.ldo + col, v); else st4<T>((T*)e.out + row * e.ldo + col, v);
+        continue;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (col + c >= g.N) { v[c] = 0.f; continue; }
+        float x = v[c] + bias4[c];
+        if (e.out_pre) stf((T*)e.out_pre + row * e.ldpre + col + c, x);
+        if (e.act == 1) x = swishf_(x); else if (e.act == 2) x = fmaxf(x, 0.f);
+        if (e.drop_p > 0.f) x *= drop_one(dk, (unsigned long long)row * g.N + col + c);
+        if (e.dact) {
+          const float z = ldf((const T*)e.dact_z + row * e.ldz + col + c);
+          x *= (e.dact == 1) ? dswishf_(z) : (z > 0.f ? 1.f : 0.f);
+        }
+        csum[c] += x; csq[c] += x * x;
+        x *= e.alpha;
+        if (e.res && (!e.res_cls0 || perm_cls == 0)) { const long long rrow = e.res_cls0 ? rrow_cls : row; x += e.res_act ? ldf((const T*)e.res + rrow * e.ldres + col + c) : ((const float*)e.res)[rrow * e.ldres + col + c]; }
+        v[c] = x;
+      }
+      if (e.out_f32) { float* o = (float*)e.out + row * e.ldo + col; for (int c = 0; c < 4; ++c) if (col + c < g.N) o[c] = v[c]; }
+      else { T* o = (T*)e.out + row * e.ldo + col; for (int c = 0; c < 4; ++c) if (col + c < g.N) stf(o + c, v[c]); }
+    }
+    __syncthreads();
+  }
+  if (e.colsum || e.stats) {
+    // workgroup-level reduction in LDS (the staged C tile is dead now), then ONE atomic per column per workgroup;
+    // BatchNorm statistics additionally spread over AVEC_STAT_REPLICAS copies to cut same-address contention.
+    float* red = (float*)smem;                 // [4 waves][2][BN]: shuffle-reduce inside each wave, plain stores, no LDS atomics
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      for (int o = TPR; o < 64; o <<= 1) { csum[c] += __shfl_xor(csum[c], o, 64); csq[c] += __shfl_xor(csq[c], o, 64); }
+    const int wv = tid >> 6;
+    if (lane < TPR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { red[(wv * 2 + 0) * BN + cg + c] = csum[c]; red[(wv * 2 + 1) * BN + cg + c] = csq[c]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) { float t = 0.f; for (int w = 0; w < 4; ++w) t += red[(w * 2) * BN + c]; red[8 * BN + c] = t; }   // [sum | sq] totals behind the partials
+    __syncthreads();
+    red += 8 * BN;
+    if (tid < BN && n0 + tid < g.N) {
+      if (e.colsum) atomicAdd(e.colsum + n0 + tid, red[tid]);
+      if (e.stats) {
+        float* rep = e.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 2 * g.N;
+        atomicAdd(rep + n0 + tid, red[tid]); atomicAdd(rep + g.N + n0 + tid, red[BN + tid]);
+      }
+    }
+  }
+}
+
+
+// ---- register-direct epilogue for TRANSPOSED accumulators (round 5) ----
+// The staged epilogue above is 25-40 % of the shifted-window convolution's time (ablation, profiles/r05_shift_epilogue.txt: 43 / 76 of 140 / 189 us forward /
+// backward-data on the 128-channel stage): four passes of accumulators -> LDS -> barrier -> rolled row loop (with a dependent residual load per iteration) -> barrier.
+// Here the product is computed transposed (weights as the MFMA A operand, pixels as B): acc[i][j] is D^T of the 32 x 32 block, a lane owns ONE pixel (lane & 31 of
+// row block i) and the channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column block j.  Four consecutive channels pack into 8 bytes; v_permlane32_swap trades the
+// odd group of the lower half-wave for the even group of the upper one (csrc/conv3x3.hip does the same), after which a lane holds 8 consecutive channels: 16-byte
+// NHWC pieces straight from the registers -- no LDS staging, no barrier, every residual piece requested before the first store.  The residual gradient is added
+// in fp32 before the single rounding (its 16-byte pieces are swapped back to the accumulator layout first: the swap is an involution).  BatchNorm statistics:
+// per-register partial sums over the wave's row blocks, reduce-scatter over the half-wave's pixels (v_permlane16_swap for lane ^ 16, then rotations inside the
+// 16-lane rows), waves combined through LDS, one atomic per column per workgroup like the staged epilogue.
+typedef float f32x2_e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap_pair32(uint2& x, uint2& y) {
+  auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false); x.x = r0[0]; y.x = r0[1];
+  auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false); x.y = r1[0]; y.y = r1[1];
+}
+__device__ __forceinline__ float row_rot_add(float v) {       // sum over the 16 lanes of a row (every lane gets the total): rotations by 8, 4, 2, 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));     // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));     // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));     // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));     // row_ror:1
+  return v;
+}
+// row[i] / valid[i]: output row of this lane's pixel in row block i (clamped into the tensor when invalid); rrow[i]: its row in the residual tensor (`res` non-null);
+// full: (workgroup-uniform) every row of the tile is valid -- the statistics then need no per-row mask
+template <int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_tr(const GemmArgs& g, f32x16 (&acc)[MT][NT], char* smem, const long long (&row)[MT], const bool (&valid)[MT], const bf16* res,
+                                                 const long long (&rrow)[MT], const bool full, int n0, int tid, int lane, int wm, int wn) {
+  const Epi& e = g.e;
+  const int h = lane >> 5;
+  bf16* const out = (bf16*)e.out;
+  const float alpha = e.alpha;
+  float ssum[NT][16], ssq[NT][16];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cb = n0 + wn * (BN / 2) + j * 32 + h * 8;          // this lane's 8-channel piece of 16-channel block k: cb + 16 k
+    uint4 rp[MT][2];
+    if (res) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rp[i][k] = *(const uint4*)(res + rrow[i] * e.ldres + cb + 16 * k);
+    }
+    if (e.stats) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; ssum[j][r] += v; ssq[j][r] += v * v; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = valid[i] ? acc[i][j][r] : 0.f; ssum[j][r] += v; ssq[j][r] += v * v; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      uint2 G[4];
+      if (res) {
+        uint2 R[4] = {make_uint2(rp[i][0].x, rp[i][0].y), make_uint2(rp[i][0].z, rp[i][0].w), make_uint2(rp[i][1].x, rp[i][1].y), make_uint2(rp[i][1].z, rp[i][1].w)};
+        swap_pair32(R[0], R[1]); swap_pair32(R[2], R[3]);       // stored layout -> accumulator layout
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v0 = acc[i][j][4 * q] * alpha + __uint_as_float(R[q].x << 16), v1 = acc[i][j][4 * q + 1] * alpha + __uint_as_float(R[q].x & 0xffff0000u);
+          const float v2 = acc[i][j][4 * q + 2] * alpha + __uint_as_float(R[q].y << 16), v3 = acc[i][j][4 * q + 3] * alpha + __uint_as_float(R[q].y & 0xffff0000u);
+          G[q].x = f32x2_to_bf16x2(v0, v1); G[q].y = f32x2_to_bf16x2(v2, v3);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          G[q].x = f32x2_to_bf16x2(acc[i][j][4 * q] * alpha, acc[i][j][4 * q + 1] * alpha); G[q].y = f32x2_to_bf16x2(acc[i][j][4 * q + 2] * alpha, acc[i][j][4 * q + 3] * alpha);
+        }
+      }
+      swap_pair32(G[0], G[1]); swap_pair32(G[2], G[3]);
+      if (valid[i]) {
+        *(uint4*)(out + row[i] * e.ldo + cb) = make_uint4(G[0].x, G[0].y, G[1].x, G[1].y);
+        *(uint4*)(out + row[i] * e.ldo + cb + 16) = make_uint4(G[2].x, G[2].y, G[3].x, G[3].y);
+      }
+    }
+  }
+  if (e.stats) {
+    // reduce-scatter over the 32 pixels of the half-wave: lane ^ 16 by v_permlane16_swap (registers r and r + 8 trade rows: even rows end with the sums of register r,
+    // odd rows with those of r + 8, each over two rows), then the 16 lanes of a row by rotations
+    float* red = (float*)smem;                 // [wm][sum | sq][BN] partials, then [2][BN] totals (the ring is dead: the K loop ended with a barrier)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float (&v)[16] = t ? ssq[j] : ssum[j];
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 8]), false, false);
+          w[r] = row_rot_add(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+        }
+        if ((lane & 15) == 0) {
+          const int odd = (lane >> 4) & 1;       // odd rows hold registers 8 .. 15
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int R = r + 8 * odd, ch = wn * (BN / 2) + j * 32 + (R & 3) + 8 * (R >> 2) + 4 * h;
+            red[(wm * 2 + t) * BN + ch] = w[r];
+          }
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int t = tid / BN, c = tid % BN;
+      if (n0 + c < g.N) {
+        float* rep = e.stats + (long long)(blockIdx.x % AVEC_STAT_REPLICAS) * 2 * g.N;
+        atomicAdd(rep + t * g.N + n0 + c, red[(0 * 2 + t) * BN + c] + red[(1 * 2 + t) * BN + c]);
+      }
+    }
+  }
+}
+
+// ---- register-direct epilogue of the 64 x 64 plain product (round 5): the conformer-sized launches ----
+// profiles/r04_small_gemm_anatomy.txt: of the 5.2 us such a launch lives, 1.7 go to staging 16 accumulators through LDS (16 ds_write_b32, barrier, float4 reads,
+// barrier) and 0.8 to the stores -- the K loop is 0.8.  With the product transposed (conv_epilogue_tr above) a lane owns ONE output row and, after a
+// v_permlane32_swap of four fp32 registers per 16-channel block, 2 x 8 consecutive columns of it: bias / activation / dropout / act'(z) / alpha / residual are applied
+// in registers in the order of nt_epilogue (same arithmetic, same dropout indices), every operand piece is requested before the first store, nothing touches LDS, no
+// barrier.  Column sums / BatchNorm statistics / the BatchNorm-backward fusion keep the staged epilogue (plain_tr_ok).
+__device__ __forceinline__ void swap4_f32(float (&x)[4], float (&y)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[t]), __float_as_uint(y[t]), false, false);
+    x[t] = __uint_as_float(r[0]); y[t] = __uint_as_float(r[1]);
+  }
+}
+__device__ __forceinline__ void plain_epilogue_tr(const GemmArgs& g, const f32x16& acc, const long long m0, const int n0, const int lane, const int wm, const int wn) {
+  const Epi& e = g.e;
+  const int h = lane >> 5;
+  long long row = m0 + wm * 32 + (lane & 31);
+  const bool rvalid = row < g.M; if (!rvalid) row = g.M - 1;
+  const DropKey dk = drop_key(e.rng, e.stream, e.drop_p);
+  float v[2][8]; bool cvalid[2]; int col[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float x[4], y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { x[t] = acc[8 * k + t]; y[t] = acc[8 * k + 4 + t]; }
+    swap4_f32(x, y);                          // (x, y) = (group 2k, group 2k + 1) of the accumulator layout -> columns +0..3 | +4..7 of this lane's piece
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { v[k][t] = x[t]; v[k][4 + t] = y[t]; }
+    col[k] = n0 + wn * 32 + 16 * k + 8 * h;
+    cvalid[k] = col[k] < g.N;                 // (N % 8 == 0: a piece is inside N or not at all)
+    if (!cvalid[k]) col[k] = g.N - 8;
+  }
+  // operand pieces, all requested up front
+  float4 bq[2][2]; uint4 zq[2], rb[2]; float4 rf[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (e.bias) { bq[k][0] = *(const float4*)(e.bias + col[k]); bq[k][1] = *(const float4*)(e.bias + col[k] + 4); }
+    if (e.dact) zq[k] = *(const uint4*)((const bf16*)e.dact_z + row * e.ldz + col[k]);
+    if (e.res) {
+      if (e.res_act) rb[k] = *(const uint4*)((const bf16*)e.res + row * e.ldres + col[k]);
+      else { rf[k][0] = *(const float4*)((const float*)e.res + row * e.ldres + col[k]); rf[k][1] = *(const float4*)((const float*)e.res + row * e.ldres + col[k] + 4); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float (&w)[8] = v[k];
+    if (e.bias) { w[0] += bq[k][0].x; w[1] += bq[k][0].y; w[2] += bq[k][0].z; w[3] += bq[k][0].w; w[4] += bq[k][1].x; w[5] += bq[k][1].y; w[6] += bq[k][1].z; w[7] += bq[k][1].w; }
+    const bool ok = rvalid && cvalid[k];
+    if (e.out_pre && ok)
+      *(uint4*)((bf16*)e.out_pre + row * e.ldpre + col[k]) = make_uint4(f32x2_to_bf16x2(w[0], w[1]), f32x2_to_bf16x2(w[2], w[3]), f32x2_to_bf16x2(w[4], w[5]), f32x2_to_bf16x2(w[6], w[7]));
+    if (e.act == 1) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = swishf_(w[c]);
+    } else if (e.act == 2) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = fmaxf(w[c], 0.f);
+    }
+    if (e.drop_p > 0.f) {                     // (N is even: the pair hashes of nt_epilogue's drop4)
+      const unsigned long long i0 = (unsigned long long)row * g.N + col[k];
+      float d0[4], d1[4]; drop4(dk, i0, d0); drop4(dk, i0 + 4, d1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { w[c] *= d0[c]; w[4 + c] *= d1[c]; }
+    }
+    if (e.dact) {
+      const uint32_t zz[4] = {zq[k].x, zq[k].y, zq[k].z, zq[k].w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float z = (c & 1) ? __uint_as_float(zz[c >> 1] & 0xffff0000u) : __uint_as_float(zz[c >> 1] << 16);
+        w[c] *= (e.dact == 1) ? dswishf_(z) : (z > 0.f ? 1.f : 0.f);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] *= e.alpha;
+    if (e.res) {
+      if (e.res_act) {
+        const uint32_t rr[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] += (c & 1) ? __uint_as_float(rr[c >> 1] & 0xffff0000u) : __uint_as_float(rr[c >> 1] << 16);
+      } else {
+        w[0] += rf[k][0].x; w[1] += rf[k][0].y; w[2] += rf[k][0].z; w[3] += rf[k][0].w; w[4] += rf[k][1].x; w[5] += rf[k][1].y; w[6] += rf[k][1].z; w[7] += rf[k][1].w;
+      }
+    }
+    if (ok) {
+      if (e.out_f32) {
+        float* o = (float*)e.out + row * e.ldo + col[k];
+        *(float4*)o = make_float4(w[0], w[1], w[2], w[3]); *(float4*)(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
+      } else
+        *(uint4*)((bf16*)e.out + row * e.ldo + col[k]) = make_uint4(f32x2_to_bf16x2(w[0], w[1]), f32x2_to_bf16x2(w[2], w[3]), f32x2_to_bf16x2(w[4], w[5]), f32x2_to_bf16x2(w[6], w[7]));
+    }
+  }
+}
+
+template <int RB> __device__ __forceinline__ int glds_swz(int row) { return RB == 256 ? (row & 15) : RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ u32x4 lds_read128(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory"); return v; }
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128o(unsigned lds_addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory"); return v; }
+// LDS-DMA of N x 16 B per lane as one group: scalar base + per-lane 32-bit byte offsets (no VALU on the issue path); LDS destinations lds0 + 4096 i (wave-uniform)
+// go through M0, saved and restored once per group
+#define AVEC_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+#define AVEC_GLDS_NEXT(k) "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #k ", %2\n\t"
+#define AVEC_GLDS_TAIL "s_mov_b32 m0, %0"
+template <int N> __device__ __forceinline__ void glds16_group(const unsigned (&v)[N], const void* sbase, unsigned lds0) {
+  static_assert(N >= 1 && N <= 5, "group size");
+  unsigned keep;
+  if constexpr (N == 1) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0) : "memory", "scc");
+  if constexpr (N == 2) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]) : "memory", "scc");
+  if constexpr (N == 3) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_TAIL : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+  if constexpr (N == 4) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_NEXT(6) AVEC_GLDS_TAIL
+                                     : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
+  if constexpr (N == 5) asm volatile(AVEC_GLDS_HEAD AVEC_GLDS_NEXT(4) AVEC_GLDS_NEXT(5) AVEC_GLDS_NEXT(6) AVEC_GLDS_NEXT(7) AVEC_GLDS_TAIL
+                                     : "=&s"(keep) : "v"(v[0]), "s"(sbase), "s"(lds0), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory", "scc");
+}
+#undef AVEC_GLDS_HEAD
+#undef AVEC_GLDS_NEXT
+#undef AVEC_GLDS_TAIL
+template <int V> struct IntC { static constexpr int value = V; };

@@ -490,6 +490,7 @@ class ParamArena:
         or None when nothing was stale.  The fp8 shadows and a dtype change take the one-launch path."""
         if self._shadow_dtype != compute_dtype() or getattr(self, "_fp8", None) is not None or not (0 < first_blocks < self.total_blocks):
             self.ensure_fresh()
+            side.wait_stream(torch.cuda.current_stream())      # the one-launch refresh (and the fp8 one) was enqueued AFTER the caller's side.wait_stream: order `side` behind it
             return None
         if not self.dirty:
             return None
