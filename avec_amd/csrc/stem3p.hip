@@ -25,6 +25,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 static __device__ __attribute__((aligned(64))) unsigned char s3p_zero16[64];
 
 static constexpr int S3P_C = 64;
+#ifndef S3P_STAMPS
+#define S3P_STAMPS 0        // 1 (tools builds): shader-clock totals per phase of the forward kernels under abl & 64
+#endif
 
 struct S3P {
   int T3, H, W, OH, OW, PH, PW;
@@ -97,6 +100,13 @@ __device__ __forceinline__ uint32_t s3p_key(uint32_t x, uint32_t qinv) {       /
   const uint32_t m = (uint32_t)((int)x >> 31);
   return ((x ^ (m | 0x80000000u)) & 0xffff0000u) | qinv;
 }
+// the same order-preserving key for BOTH bf16 halves of a word (round 6: the ring holds keys, made once per conv output by the epilogue instead of once per window candidate
+// -- every output is a candidate of 2.25 windows -- by the pool stage, whose per-candidate work is then one v_and_or / v_lshl_or)
+typedef short s3p_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t s3p_key2(uint32_t w) {
+  const s3p_v2s m = __builtin_bit_cast(s3p_v2s, w) >> 15;                       // 0xffff for a negative half
+  return w ^ (__builtin_bit_cast(uint32_t, m) | 0x80008000u);
+}
 
 __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restrict__ vb, const bf16* __restrict__ wsh, const float* __restrict__ bias, const float* __restrict__ gamma,
                                                              bf16* __restrict__ zp, unsigned char* __restrict__ idx, int want_stats, S3P G, ColWs ws, float* stats, int abl) {
@@ -115,12 +125,17 @@ __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restri
 #pragma unroll
   for (int r = 0; r < 35; ++r) rowoff[r] = ((r / 7) * G.SH + (r % 7)) * G.pitch;
   const float b0 = bias ? bias[pl] : 0.f, b1 = bias ? bias[32 + pl] : 0.f;
+  const uint32_t fe0 = gamma[pl] < 0.f ? 0x80008000u : 0u, fe1 = gamma[32 + pl] < 0.f ? 0x80008000u : 0u;      // epilogue: sign flip of this lane's two channels
   // pool stage: this thread's channel, its sign flip (both halves of a word) and its pooled columns
   const int pc_ = tid & 63, qg = tid >> 6;
   const uint32_t flip2 = gamma[pc_] < 0.f ? 0x80008000u : 0u;
   const int pw0 = qg * S3P_PWG;
   float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+  // measurement aid (abl & 64): shader-clock totals per phase of workgroup 0 / wave 0 -> stats[4096 + k] (tools/bench_stem_abl.py prints them)
+  long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define S3P_T() ((S3P_STAMPS && (abl & 64)) ? (long long)clock64() : 0ll)
   for (long long item = blockIdx.x; item < G.items; item += gridDim.x) {
+    const long long tq0 = S3P_T();
     const int band = (int)(item % G.NB); const long long cf = item / G.NB;
     const int fr = (int)(cf % G.T3); const long long clip = cf / G.T3;
     const int ph0 = band * G.pn; const int pnb = min(G.pn, G.PH - ph0);
@@ -128,18 +143,24 @@ __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restri
     const int ncr = cr1 - cr0 + 1, npx = ncr * G.OW;
     const int own0 = (2 * ph0 - cr0) * G.OW;                        // pixels before this one belong to the previous band's statistics
     __syncthreads();                                                // the previous band's slab and ring are no longer read
+    // (round 6, measured and dropped: consecutive frames of a band with a ring of six frame slots and the next frame's rows prefetched -- the wave that waits here 17 % of its
+    //  time, S3P_STAMPS, is covered by the CU's other workgroup: 562-566 us either way)
     if (!(abl & 16)) s3p_issue_slab(slab, vb, clip, fr, 2 * cr0 - 3, G);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ph_t[0] += S3P_T() - tq0;
     int rb = 32 * wave; if (rb >= G.RING) rb -= G.RING;            // ring slot of the wave's first pixel of the current tile
     int next_pool = 0;
     for (int t0 = 0; t0 < npx; t0 += 128) {
+      const long long tq1 = S3P_T();
       const int p = t0 + 32 * wave + pl; const int pc = p < npx ? p : 0;
       const int ohl = pc / G.OW, ow = pc - ohl * G.OW;
       f32x16 acc[2];
       if (abl & 2) { for (int r = 0; r < 16; ++r) { acc[0][r] = (float)(t0 + r); acc[1][r] = (float)(lane + r); } }
       else s3p_conv_tile(slab, ohl, ow, g, wf, rowoff, G, acc);
+      const long long tq2 = S3P_T();
       __syncthreads();                                              // the previous iteration's pool reads are done: ring slots may be overwritten
+      const long long tq3 = S3P_T();
       if (abl & 4) { if (acc[0][3] + acc[1][5] == 1234.5f) st1[0] += 1.f; } else
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -151,12 +172,15 @@ __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restri
           if (pr < npx) {
             if (pr >= own0) { st1[j] += (v0 + v1) + (v2 + v3); st2[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3); }
             int slot = rb + q4; if (slot >= G.RING) slot -= G.RING;
-            *(uint2*)(ring + ((32 * j + pl) * G.RING + slot) * 2) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
+            const uint32_t fe = j ? fe1 : fe0;
+            *(uint2*)(ring + ((32 * j + pl) * G.RING + slot) * 2) = make_uint2(s3p_key2(f32x2_to_bf16x2(v0, v1) ^ fe), s3p_key2(f32x2_to_bf16x2(v2, v3) ^ fe));
           }
         }
       }
       rb += 128; while (rb >= G.RING) rb -= G.RING;
+      const long long tq4 = S3P_T();
       __syncthreads();
+      const long long tq5 = S3P_T();
       const int done = min(t0 + 128, npx);
       while (!(abl & 8) && next_pool < pnb && min((2 * (ph0 + next_pool) + 2 - cr0) * G.OW, npx) <= done) {
         const int ph = ph0 + next_pool;
@@ -171,12 +195,12 @@ __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restri
           const uint32_t* rowp = (const uint32_t*)(ring + (pc_ * G.RING + rr * G.OW) * 2);
           uint32_t D[S3P_PWG + 1];                                  // D[i] = columns (2 (pw0 - 1 + i), + 1)
 #pragma unroll
-          for (int i = 0; i <= S3P_PWG; ++i) { const int k = pw0 - 1 + i; D[i] = rowp[(k >= 0 && 2 * k < G.OW) ? k : 0] ^ flip2; }
+          for (int i = 0; i <= S3P_PWG; ++i) { const int k = pw0 - 1 + i; D[i] = rowp[(k >= 0 && 2 * k < G.OW) ? k : 0]; }      // (keys: s3p_key2 in the epilogue)
 #pragma unroll
           for (int i = 0; i < S3P_PWG; ++i) {
-            if (pw0 + i > 0) best[i] = max(best[i], s3p_key(D[i] & 0xffff0000u, 15u - (kh * 3)));          // column 2 pw - 1
-            best[i] = max(best[i], s3p_key(D[i + 1] << 16, 15u - (kh * 3 + 1)));                             // column 2 pw
-            best[i] = max(best[i], s3p_key(D[i + 1] & 0xffff0000u, 15u - (kh * 3 + 2)));                     // column 2 pw + 1
+            if (pw0 + i > 0) best[i] = max(best[i], (D[i] & 0xffff0000u) | (15u - (kh * 3)));              // column 2 pw - 1
+            best[i] = max(best[i], (D[i + 1] << 16) | (15u - (kh * 3 + 1)));                                 // column 2 pw
+            best[i] = max(best[i], (D[i + 1] & 0xffff0000u) | (15u - (kh * 3 + 2)));                         // column 2 pw + 1
           }
         }
         const long long po = ((cf * G.PH + ph) * (long long)G.PW + pw0) * S3P_C + pc_;
@@ -191,8 +215,11 @@ __global__ __launch_bounds__(256, 2) void stem3p_fwd_kernel(const bf16* __restri
         }
         ++next_pool;
       }
+      if (S3P_STAMPS && (abl & 64)) { const long long tq6 = S3P_T(); ph_t[1] += tq2 - tq1; ph_t[2] += tq3 - tq2; ph_t[3] += tq4 - tq3; ph_t[4] += tq5 - tq4; ph_t[5] += tq6 - tq5; ph_t[6] += 1; }
     }
   }
+#undef S3P_T
+  if (S3P_STAMPS && (abl & 64) && blockIdx.x == 0 && tid == 0 && stats) for (int k = 0; k < 8; ++k) stats[4096 + k] = (float)ph_t[k];
   if (!want_stats) return;
 #pragma unroll
   for (int j = 0; j < 2; ++j) { st1[j] += __shfl_xor(st1[j], 32, 64); st2[j] += __shfl_xor(st2[j], 32, 64); }

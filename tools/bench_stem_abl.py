@@ -23,3 +23,8 @@ for _ in range(10):
     lib.stem3p_fwd(vb.data_ptr(), w8.data_ptr(), bias.data_ptr(), gamma.data_ptr(), zp.data_ptr(), idx.data_ptr(), stats.data_ptr(), B, T, H, W, st)
 e1.record(); torch.cuda.synchronize()
 print("ABL=%s  stem3p_fwd %.1f us (incl. col_finalize)" % (os.environ.get("AVEC_S3P_ABL", "0"), e0.elapsed_time(e1) * 100))
+if int(os.environ.get("AVEC_S3P_ABL", "0")) & 64:
+    t = stats[4096:4104].cpu().tolist()
+    names = ["slab wait", "conv tile", "barrier 1", "ring write + stats", "barrier 2", "pool", "tiles"]
+    tot = sum(t[:6])
+    print("phases of workgroup 0 / wave 0, shader cycles (share): " + ", ".join("%s %.0f (%.0f%%)" % (n, v, 100 * v / tot) for n, v in zip(names[:6], t[:6])) + ", tiles %d, cycles/tile %.0f" % (t[6], tot / max(t[6], 1)))
