@@ -4,8 +4,9 @@ on synthetic LRS2-shaped batches: B=32 per GPU, audio 63 840 samp
     python bench.py [--gpus N --steps K --warmup W]          (N>1: one rank per GPU over RCCL -- started by torch.distributed.run, or by bench.py itself
                                                               when it is run as plain `python bench.py --gpus N`)
 
-Prints ONE JSON line (rank 0): whole-job utterances/s, plus `roofline` for the dominant kernel (implicit-GEMM convolution family,
-timed live with HIP events inside the timed region) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
+Prints ONE JSON line (rank 0): whole-job utterances/s, plus `roofline` (one row per kernel instance of the MFMA product / convolution families: what a launch computes
+comes from an eager, event-bracketed leg run AFTER the timed region -- events cannot be recorded inside the timed hipGraph --, how long it takes inside the replayed step
+from the committed rocprofv3 summary of this command, `roofline.timing_source`) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
 import argparse
 import json
 import os
@@ -117,12 +118,55 @@ def pmc_traffic_kernel(kernel):
     path = pmc_summary_path()
     if not kernel or path is None:
         return None
-    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace(",tr>", ",1>").replace("__hip_bfloat16", "bf16")
+    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace(",tr>", ",1>").replace("__hip_bfloat16", "bf16").replace("(anonymousnamespace)::", "")
     want = norm(kernel)
     for name, v in json.load(open(path))["kernels"].items():
         if norm(name).split("(")[0] == want:
             return round(v["fetch_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0.0))
     return None
+
+
+def graph_kernel_stats():
+    """{normalised kernel name: average duration in us} from the newest committed rocprofv3 --kernel-trace --stats summary of THIS command's graph-replayed step
+    (profiles/rNN_kernel_stats_final.csv), and the file name; ({}, None) when there is none"""
+    import csv
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_final.csv")))
+    if not found:
+        return {}, None
+    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace(",tr>", ",1>").replace("__hip_bfloat16", "bf16").replace("(anonymousnamespace)::", "").split("(")[0]
+    out = {}
+    for r in csv.DictReader(open(found[-1])):
+        out[norm(r["Name"])] = float(r["AverageNs"]) / 1e3
+    return out, os.path.basename(found[-1])
+
+
+def rows_from_graph_trace(roof, peak):
+    """The step that is TIMED is one hipGraph; HIP events cannot be recorded inside it, so the eager leg supplies what a launch computes (kernel instance, algorithmic
+    FLOPs and bytes, launches per step) and the committed rocprofv3 summary of the graph replays supplies how long it takes there (the eager, single-stream leg runs
+    on a cool chip: its durations are 5-35 % off the replayed ones).  Rows whose kernel is not in the summary keep the live event timing and say so."""
+    stats, fname = graph_kernel_stats()
+    norm = lambda s_: s_.replace(" ", "").replace("void", "").replace("false", "0").replace("true", "1").replace(",tr>", ",1>").replace("__hip_bfloat16", "bf16").replace("(anonymousnamespace)::", "").split("(")[0]
+    if not stats:
+        roof["timing_source"] = "live HIP events, eager single-stream leg (no profiles/rNN_kernel_stats_final.csv committed)"
+        return roof
+    for r in roof["rows"]:
+        us = stats.get(norm(r["kernel"]))
+        r["avg_us_eager_events"] = r["avg_us"]
+        if us is None:
+            r["timing"] = "eager events (kernel not in %s)" % fname
+            continue
+        r["timing"] = fname
+        r["avg_us"] = round(us, 2)
+        r["ms_per_step"] = round(r["launches_per_step"] * us / 1e3, 3)
+        r["tflops"] = round(r["alg_gflop_per_launch"] / us / 1e3, 1)
+        r["frac"] = round(r["alg_gflop_per_launch"] / us / 1e3 / peak, 4)
+    top = max(roof["rows"], key=lambda r: r["ms_per_step"])
+    roof.update({"kernel": top["kernel"], "achieved": top["tflops"], "frac": round(top["tflops"] / peak, 5), "launches": top["launches_per_step"],
+                 "avg_launch_ms": round(top["avg_us"] / 1e3, 5), "alg_gflop_per_launch": top["alg_gflop_per_launch"], "alg_bytes_per_launch": top["alg_bytes_per_launch"]})
+    roof["timing_source"] = ("rows[*].avg_us: average kernel duration inside the graph-replayed step, rocprofv3 --kernel-trace --stats of this command (profiles/%s); "
+                             "kernel instance, FLOPs, bytes and launch counts from the eager event-bracketed leg (avg_us_eager_events keeps its timing)" % fname)
+    return roof
 
 
 def spawn_ranks(n):
@@ -285,6 +329,8 @@ def main():
         value = utt / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         roof = ops.KERNEL_TIMER.summary(peak, steps=timed_steps) if not args.no_kernel_timing else None
+        if roof is not None and args.dtype == "bf16" and args.batch == 32 and use_graph and world == 1:
+            roof = rows_from_graph_trace(roof, peak)
         if roof is not None and args.dtype == "bf16" and args.batch == 32:
             roof["traffic"] = pmc_traffic_kernel(roof["kernel"])
             for r in roof["rows"]:                   # per row: measured HBM bytes (PMC summary) next to the algorithmic bytes -> the wasted-traffic ratio is explicit
@@ -303,8 +349,10 @@ def main():
                        "eager_two_stream_ms_per_step": (round(eager2_ms, 2) if not args.no_kernel_timing else None),
                        "notes": "parity: every module against fixtures generated from the reference (tests/golden); the mel front-end is pinned to a restatement of "
                                 "torchaudio's documented MelSpectrogram defaults only (torchaudio is not part of /root/reference: tests/golden/ref_shims.py). "
-                                "roofline.rows come from the eager single-stream leg (event pairs cannot be recorded inside a graph): grouped weight-gradient launches "
-                                "are cut by queue length there (7 launches) and by stream in the graph (8)"},
+                                "bf16 gradient parity (tests/test_gpu_round2.py, test_gpu_round4.py: every gradient tensor of the timed B=32 graph against the oracle) is enforced as "
+                                "|err| <= 1.5 x (error of torch CPU autocast on the same tensor) + 0.02 relative, capped at 0.15 (front-end tensors exempt from the cap); north_star's 1e-3 "
+                                "is met in fp32 mode (B=2, test_full_model_grads_match_oracle).  roofline: see timing_source; grouped weight-gradient launches are cut by queue length in "
+                                "the eager leg (7 launches) and by stream in the graph (8)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

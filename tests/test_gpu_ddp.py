@@ -20,7 +20,7 @@ def _transports():
     return t
 
 
-def _oracle_full_batch():
+def _oracle_full_batch(B=4):
     """the CPU oracle (pinned to the reference, tests/golden/check_oracle_fullsize.py) on the FULL batch of tools/ddp_equiv.py: loss and gradients the two ranks
     together must reproduce (SyncBatchNorm statistics over both shards, gradients averaged over ranks = gradient of the batch-mean loss)"""
     import nnet
@@ -28,27 +28,37 @@ def _oracle_full_batch():
     torch.manual_seed(0)
     model = nnet.AudioVisualEfficientConformerInterCTC()
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in model.state_dict().items()}
-    B = 4
     g = torch.Generator().manual_seed(5)
     video, audio = torch.randn(B, 20, 88, 88, 1, generator=g), 0.1 * torch.randn(B, 12160, generator=g)
-    vlen, alen = torch.tensor([20, 17, 20, 11]), torch.tensor([12160, 10000, 12160, 7000])
-    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor([4, 3, 4, 2])
+    vlen, alen = torch.tensor([20, 17, 20, 11] * (B // 4)), torch.tensor([12160, 10000, 12160, 7000] * (B // 4))
+    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor([4, 3, 4, 2] * (B // 4))
     out = O.av_forward(sd, video, vlen, audio, alen, train=True, stats_out={})
     loss = O.total_loss(out, labels, llen, O.AV_LOSS_WEIGHTS)["loss"]
     loss.backward()
     return float(loss), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
 
 
-@pytest.mark.parametrize("transport", _transports())
+def _cases():
+    """(backend, shared GPU, world, global batch): two ranks over gloo on the one GPU and, where there are two devices, over RCCL; EIGHT ranks (avec_amd.peer.MAX_WORLD: the
+    8-slot pages, epochs and IPC handles of the peer exchange, the early all-reduce ranges) with one utterance each on the one GPU"""
+    t = [pytest.param(("gloo", True, 2, 4), id="gloo, one shared GPU")]
+    t.append(pytest.param(("nccl", False, 2, 4), id="rccl, one GPU per rank", marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")))
+    t.append(pytest.param(("gloo", True, 8, 8), id="gloo, eight ranks on one shared GPU"))
+    return t
+
+
+@pytest.mark.parametrize("transport", _cases())
 @pytest.mark.parametrize("peer_exchange", ["1", "0"], ids=["peer-write SyncBN exchange", "torch.distributed SyncBN exchange"])
 def test_two_rank_step_equals_single_process(tmp_path, peer_exchange, transport):
-    backend, share = transport
+    backend, share, world, B = transport
+    if world > 2 and peer_exchange == "0":
+        pytest.skip("eight ranks: the peer-write exchange is the case of interest")
     single, ddp = str(tmp_path / "single.pt"), str(tmp_path / "ddp.pt")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AVEC_PEER_SYNCBN=peer_exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", single], check=True, env=env, timeout=600)
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", backend] + (["--share-gpu"] if share else []),
-                   check=True, env=env, timeout=900)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AVEC_PEER_SYNCBN=peer_exchange, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", single, "--batch", str(B)], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                    "--master-port", "29533", os.path.join(ROOT, "tools", "ddp_equiv.py"), "--out", ddp, "--backend", backend, "--batch", str(B)] + (["--share-gpu"] if share else []),
+                   check=True, env=env, timeout=1500)
     a, b = torch.load(single), torch.load(ddp)
     assert b["peer"] == (peer_exchange == "1")      # the statistics really travelled the way this case names (IPC peer writes work between two processes on one GPU)
     # the overlapped exchange really ran: (fusion + audio-visual encoder + head) and (audio encoder) ranges, disjoint, inside the arena
@@ -71,7 +81,7 @@ def test_two_rank_step_equals_single_process(tmp_path, peer_exchange, transport)
     if peer_exchange == "1" and share:
         # ... and against the ORACLE on the full batch (not only HIP vs HIP): the two ranks' averaged gradient is the gradient of the batch-mean loss with
         # BatchNorm statistics over the whole batch.  Parameters stored in another physical order (conv weights are channels-last in the arena) are compared by norm.
-        o_loss, o_grad = _oracle_full_batch()
+        o_loss, o_grad = _oracle_full_batch(B)
         assert abs(float(b["loss"]) - o_loss) < 1e-3 * abs(o_loss), (float(b["loss"]), o_loss)
         num = den = 0.0
         n_cmp = 0
@@ -87,11 +97,28 @@ def test_two_rank_step_equals_single_process(tmp_path, peer_exchange, transport)
         assert n_cmp > 400 and (num / den) ** 0.5 < 5e-3, (n_cmp, (num / den) ** 0.5)
 
 
-def test_peer_exchange_stress_and_graph(tmp_path):
-    """avec_amd/peer.py alone: two processes on the one GPU, many sites / vector lengths / rounds against gloo all_reduce, eagerly and replayed from a hipGraph
-    (the epoch counters live on the device)"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_stress.py")], env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.count("PEER STRESS OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
+@pytest.mark.parametrize("world", [2, 8])
+def test_peer_exchange_stress_and_graph(tmp_path, world):
+    """avec_amd/peer.py alone: two / eight (= MAX_WORLD) processes on the one GPU, many sites / vector lengths / rounds against gloo all_reduce, eagerly and replayed from a
+    hipGraph (the epoch counters live on the device)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_stress.py"), str(world)], env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("PEER STRESS OK") == world, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_command_line_eight_ranks_on_one_gpu():
+    """the command line the driver uses for the scaling run (torch.distributed.run, one rank per GPU) with eight ranks sharing cuda:0 over gloo, one utterance each: the step is
+    captured with the peer-write SyncBatchNorm exchange inside, three timed replays, ONE JSON line from rank 0 (so that an 8-GPU node is not the first place this runs)"""
+    import json
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29571",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--backend", "gloo", "--batch", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-kernel-timing"], env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4"),
+                       capture_output=True, text=True, timeout=1500)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["config"]["loss"] == d["config"]["loss"]
+    assert d["config"]["hipgraph"] and d["config"]["syncbn_exchange"] == "peer-write kernels over xGMI", d["config"]
 
 
 @pytest.mark.parametrize("transport", _transports())

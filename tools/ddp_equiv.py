@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--batch", type=int, default=4, help="global batch (a multiple of 4 and of the world size): the four-utterance pattern repeated")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
@@ -31,11 +32,12 @@ def main():
     model.encoder.audio_encoder.spec_augment.eval()
     if world > 1:
         model.distribute_strategy(rank)
-    B = 4
+    B = args.batch
+    assert B % 4 == 0 and B % world == 0
     g = torch.Generator().manual_seed(5)
     video, audio = torch.randn(B, 20, 88, 88, 1, generator=g), 0.1 * torch.randn(B, 12160, generator=g)
-    vlen, alen = torch.tensor([20, 17, 20, 11]), torch.tensor([12160, 10000, 12160, 7000])
-    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor([4, 3, 4, 2])
+    vlen, alen = torch.tensor([20, 17, 20, 11] * (B // 4)), torch.tensor([12160, 10000, 12160, 7000] * (B // 4))
+    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor([4, 3, 4, 2] * (B // 4))
     sl = slice(rank * B // world, (rank + 1) * B // world)
     inputs = [t[sl].to(dev) for t in (video, vlen, audio, alen)]
     targets = (labels[sl].to(dev), llen[sl].to(dev))

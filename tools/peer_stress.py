@@ -1,4 +1,5 @@
-"""Two processes on cuda:0: the SyncBatchNorm peer exchange (avec_amd/peer.py) against gloo all_reduce -- launched by tests/test_gpu_ddp.py."""
+"""N processes (default 2; `python tools/peer_stress.py 8` = avec_amd.peer.MAX_WORLD) on cuda:0: the SyncBatchNorm peer exchange (avec_amd/peer.py) against gloo all_reduce --
+launched by tests/test_gpu_ddp.py."""
 import os
 import socket
 import sys
@@ -26,7 +27,8 @@ def main(rank, world, port):
             got = px.all_reduce_sum(v, ("stress", si))
             ref = v.cpu()
             dist.all_reduce(ref)
-            assert torch.equal(got.cpu(), ref) or torch.allclose(got.cpu(), ref, rtol=0, atol=0), (it, si)
+            # (two ranks: a + b is the same in either order; more ranks: the slots are summed in rank order here and pairwise by gloo -- fp32 rounding apart)
+            assert torch.equal(got.cpu(), ref) or (world > 2 and torch.allclose(got.cpu(), ref, rtol=1e-5, atol=1e-5)), (it, si)
         if rank == 1 and it % 7 == 0:
             torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 4096, device=dev)
     # graph: the same sites replayed 10 times with fresh inputs copied into static buffers
@@ -51,7 +53,7 @@ def main(rank, world, port):
         graph.replay()
         torch.cuda.synchronize()
         for o, r in zip(outs, refs):
-            assert torch.equal(o.cpu(), r), it
+            assert torch.equal(o.cpu(), r) or (world > 2 and torch.allclose(o.cpu(), r, rtol=1e-5, atol=1e-5)), it
     px.check()
     dist.barrier()
     print("PEER STRESS OK rank %d" % rank, flush=True)
@@ -63,4 +65,5 @@ if __name__ == "__main__":
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(main, args=(2, port), nprocs=2)
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    mp.spawn(main, args=(world, port), nprocs=world)
