@@ -263,6 +263,62 @@ extern "C" int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, con
   if (ws.partial) { float* const dst[2] = {stats, stats + C}; return col_finalize(ws, grid.x, grid.y, 2, 128, dst, C, st); }
   return 0;
 }
+// BatchNorm finalize (norm.hip bn_finalize_kernel, training mode) reading the two-pass column-reduction partials of glu_dwconv_fwd_kernel directly: the second pass
+// (col_finalize) and the finalize were two ~4.8 us launches back to back in every conformer block's dependent chain (round 6).  block = 16 channels x 16 slot lanes;
+// partial[(colblock * nslots + slot) * 256 + n * 128 + w], channel c = 128 colblock + w, n = 0 sum / 1 sum of squares.
+__global__ __launch_bounds__(256) void bn_finalize_ws_kernel(const float* __restrict__ partial, int nslots, float count, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                                             long long* nbt, float momentum, float eps, float* ss, int C) {
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool lead = rl == 0 && c < C;
+  float gm = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
+  if (lead) { gm = gamma[c]; bt = beta[c]; if (rmean) { rm = rmean[c]; rv = rvar[c]; } }
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float* p = partial + (size_t)(c >> 7) * nslots * 256 + (c & 127);
+    for (int r = rl; r < nslots; r += 16) { s1 += p[(size_t)r * 256]; s2 += p[(size_t)r * 256 + 128]; }
+  }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (!lead) return;
+  s1 = 0.f; s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+  const float n = count;
+  const float mean = s1 / n, var = fmaxf(s2 / n - mean * mean, 0.f);
+  if (rmean && isfinite(mean) && isfinite(var)) {
+    rmean[c] = (1.f - momentum) * rm + momentum * mean;
+    rvar[c] = (1.f - momentum) * rv + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    if (c == 0 && nbt) *nbt += 1;
+  }
+  const float rs = rsqrtf(var + eps);
+  ss[c] = gm * rs; ss[C + c] = bt - mean * gm * rs; ss[2 * C + c] = mean; ss[3 * C + c] = rs;
+}
+
+// avec_glu_dwconv_fwd + avec_bn_finalize (training mode, local batch statistics over count = B * To rows) as TWO launches instead of three; `stats` ([2C], zeroed) is used
+// only when the reduction runs on atomics (no workspace registered / few partials)
+extern "C" int avec_glu_dwconv_fwd_bn(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats, int B, int T_, int C, int K, int stride, int pad_left,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                      float* ss, hipStream_t st) {
+  AVEC_CHECK_ARG(u && w && out && stats && gamma && beta && ss && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0 && pad_left >= 0 && pad_left < K,
+                 "glu_dwconv_fwd_bn: bad arguments (C=%d K=%d pad_left=%d)", C, K, pad_left);
+  const int To = (T_ - 1) / stride + 1;
+  const int nchunks = (To + DW_TT - 1) / DW_TT;
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, 2, C, st);
+  const size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
+  AVEC_CHECK_ARG(lds <= 64 * 1024, "glu_dwconv_fwd_bn: stride %d too large", stride);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(glu_dwconv_fwd_kernel<T>, grid, dim3(256), lds, st, (const T*)u, w, bias, (T*)out, stats, B, T_, C, K, stride, To, pad_left, nchunks, ws));
+  AVEC_LAUNCH_CHECK();
+  const float count = (float)((long long)B * To);
+  if (ws.partial) {
+    hipLaunchKernelGGL(bn_finalize_ws_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)ws.partial, (int)grid.y, count, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, momentum, eps, ss, C);
+    AVEC_LAUNCH_CHECK();
+    return 0;
+  }
+  return avec_bn_finalize(stats, 1, nullptr, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, ss, C, 1, st);
+}
 extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
                                    int B, int T_, int C, int K, int stride, int pad_left, hipStream_t st) {
   AVEC_CHECK_ARG(dc && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && stride > 0 && pad_left >= 0 && pad_left < K, "dwconv_glu_bwd: bad arguments");

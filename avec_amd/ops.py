@@ -1136,6 +1136,9 @@ def dw_pad_left(conv):
     assert kind == "same", "the fused convolution module supports 'same' and 'causal' padding, got %r" % (kind,)
     return K // 2
 
+CONVMOD_BN_FUSE = os.environ.get("AVEC_CONVMOD_BN_FUSE", "1") != "0"      # conformer convolution module: BatchNorm finalize straight from the depthwise kernel's partial sums
+
+
 class ConvModuleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, _anchor, mod, res_conv, drop_p, sid, training):
@@ -1152,9 +1155,17 @@ class ConvModuleFn(torch.autograd.Function):
         c = empty((Mo, Dp), adt, x2)
         st = BNState(Dp, x2)
         use_batch = training and not getattr(bn, "frozen", False)
-        lib.glu_dwconv_fwd(rt.dt(), u.data_ptr(), dw.weight.data_ptr(), _p(dw.bias), c.data_ptr(), st.stats.data_ptr() if use_batch else None,
-                           B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
-        cptr = bn_finalize(bn, st, Mo, use_batch)
+        if use_batch and not rt.sync_batchnorm() and CONVMOD_BN_FUSE:
+            # local batch statistics: the finalize reads the depthwise kernel's column-reduction partials (one launch less in the block's dependent chain)
+            track = bn.track_running_stats and bn.running_mean is not None
+            lib.glu_dwconv_fwd_bn(rt.dt(), u.data_ptr(), dw.weight.data_ptr(), _p(dw.bias), c.data_ptr(), st.stats.data_ptr(), B, T, Dp, K, stride, dw_pad_left(dw),
+                                  bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                  bn.num_batches_tracked.data_ptr() if track else None, bn.momentum if bn.momentum is not None else 0.1, bn.eps, st.ss.data_ptr(), rt.stream())
+            cptr = None
+        else:
+            lib.glu_dwconv_fwd(rt.dt(), u.data_ptr(), dw.weight.data_ptr(), _p(dw.bias), c.data_ptr(), st.stats.data_ptr() if use_batch else None,
+                               B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
+            cptr = bn_finalize(bn, st, Mo, use_batch)
         a = empty((Mo, Dp), adt, x2)
         lib.bn_apply_fwd(rt.dt(), c.data_ptr(), st.ss.data_ptr(), None, ACT_SWISH, a.data_ptr(), Mo, Dp, rt.stream())
         if res_conv is not None:

@@ -267,6 +267,11 @@ int avec_avgpool_bwd(int dtype, const void* dy, void* dx, long long N, int HW, i
  * the output always has (T - 1) / stride + 1 frames, i.e. the right padding is whatever completes K - 1. */
 int avec_glu_dwconv_fwd(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats,
                         int B, int T, int C, int K, int stride, int pad_left, hipStream_t stream);
+/* avec_glu_dwconv_fwd followed by avec_bn_finalize in training mode over the B * To output rows (local batch statistics): the finalize reads the column-reduction partials
+ * directly (two launches instead of three in the conformer block's dependent chain).  stats: zeroed [2C], used only when the reduction runs on atomics. */
+int avec_glu_dwconv_fwd_bn(int dtype, const void* u, const float* w, const float* bias, void* out, float* stats, int B, int T, int C, int K, int stride, int pad_left,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                           float* ss, hipStream_t stream);
 int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
                         int B, int T, int C, int K, int stride, int pad_left, hipStream_t stream);
 
