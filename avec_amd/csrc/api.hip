@@ -53,7 +53,7 @@ extern "C" int avec_set_reduce_workspace_stream(void* base, long long bytes, hip
 }
 ColWs avec_reduce_ws(size_t partial_floats, hipStream_t st) {
   ColWs ws{nullptr};
-  static const bool off = getenv("AVEC_NO_TREE") != nullptr;
+  static const bool off = false;
   if (off) return ws;
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return ws;
   for (int i = 0; i < g_n_ws_stream; ++i) if (g_ws_stream[i].st == st && g_ws_stream[i].dev == dev) {

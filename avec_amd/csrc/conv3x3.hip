@@ -1065,7 +1065,7 @@ extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const voi
     }
     attr_set = true;
   }
-  static const int wgs_env = getenv("AVEC_C3_WGS") ? atoi(getenv("AVEC_C3_WGS")) : 256;
+  static const int wgs_env = 256;
   C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
   avec_note_kernel("conv3x3_c64_kernel");

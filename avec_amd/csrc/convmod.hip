@@ -329,7 +329,7 @@ extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, con
   size_t lds = (size_t)((DW_TT - 1) * stride + K) * 128 * sizeof(float);
   if (lds < (size_t)4 * (KMAX + 1) * 128 * sizeof(float)) lds = (size_t)4 * (KMAX + 1) * 128 * sizeof(float);      // the reduction image of the weight-gradient kernel
   AVEC_CHECK_ARG(lds <= 64 * 1024, "dwconv_glu_bwd: stride %d too large", stride);
-  static const bool no_fused = getenv("AVEC_NO_DWCONV_FUSED_BWD") != nullptr;
+  static const bool no_fused = false;
   if (stride == 1 && !no_fused) {
     size_t l2 = (size_t)2 * (DW_TT - 1 + K) * 128 * sizeof(float); if (l2 < lds) l2 = lds;
     DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_fused_kernel<T>, grid, dim3(256), l2, st, (const T*)dc, (const T*)u, w, (T*)du, dw, dbias, B, T_, C, K, pad_left, nchunks, ws));

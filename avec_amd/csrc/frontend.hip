@@ -449,7 +449,7 @@ extern "C" int avec_audio_stem_conv_fwd(int dtype, const float* mel, const float
   if (as8_ok(s)) {
     const unsigned nb = as8_blocks(s); ColWs ws = stats ? avec_reduce_ws((size_t)nb * 2 * C, st) : ColWs{nullptr};
     const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 12) * 4;
-    static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+    static const bool no_x = false;
     if (as8x_ok(s) && !no_x) { const size_t l2 = ((size_t)(((n_mels + 2) * 3 + 4 + 3) & ~3) + (size_t)C * 2) * 4;
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_conv8x_kernel<T>, dim3(nb), dim3(256), l2, st, mel, w, bias, (T*)y, stats, s, ws)); }
     else
@@ -481,7 +481,7 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
     const unsigned nb = as8_blocks(s);
     if (phase == 0) {
       ColWs ws = avec_reduce_ws((size_t)nb * 2 * C, st);
-      static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+      static const bool no_x = false;
       if (as8x_ok(s) && !no_x) DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8x_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
       else
       DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_reduce8_kernel<T>, dim3(nb), dim3(256), (size_t)2 * C * 4, st, (const T*)da, (const T*)y, ss, dstats, s, ws));
@@ -490,7 +490,7 @@ extern "C" int avec_audio_stem_bwd(int dtype, const void* da, const void* y, con
     } else {
       ColWs ws = avec_reduce_ws((size_t)nb * 10 * C, st);
       const size_t lds = ((size_t)(n_mels + 2) * 3 + (size_t)C * 10) * 4;
-      static const bool no_x = getenv("AVEC_NO_ASTEM_X") != nullptr;
+      static const bool no_x = false;
       if (as8x_ok(s) && !no_x) { const size_t l2 = ((size_t)(((n_mels + 2) * 3 + 4 + 3) & ~3) + (size_t)C * 10) * 4;
         DISPATCH_T(dtype, hipLaunchKernelGGL(audio_stem_bwd_params8x_kernel<T>, dim3(nb), dim3(256), l2, st, (const T*)da, (const T*)y, mel, ss, gamma, dstats, count_ptr, count,
                                              dw, dbias, dgamma, dbeta, s, ws)); }

@@ -1357,8 +1357,8 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   // every chunk address 16-byte aligned?  (then each chunk is one global_load_dwordx4 instead of two dwordx2)
   const bool a16 = aligned16(g.a.ptr) && aligned16(g.W) && g.K % VEC == 0 && g.ldw % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.a.ld % (f32src ? 4 : VEC) == 0));
-  static const bool use_glds_ = getenv("AVEC_NO_GLDS") == nullptr;
-  static const bool no_ktail = getenv("AVEC_NO_KTAIL") != nullptr;
+  static const bool use_glds_ = true;
+  static const bool no_ktail = false;
   // plain bf16 products take the LDS-DMA kernel whatever their alignment (the DMA takes any source address); K = 8n + 4 with the in-LDS tail fix-up
   const bool plain_any = sizeof(T) == 2 && mode == MODE_PLAIN && !f32src && use_glds_ && !no_ktail && (g.K % 8 == 0 || g.K % 8 == 4) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
                          g.a.step <= 1;
@@ -1380,22 +1380,22 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   // thousands of tiles, -16 % on the deep-K / few-tile ones (512-channel 3x3 stage): chosen by tile count.  AVEC_NT_RB=64/128 forces it.
   const long long ntiles = (long long)grid.x * grid.y;
   const bool rb64 = sizeof(T) == 2 && (rb_env_set ? rb_env == 64 : ntiles >= 1536);
-  static const int stg_env = getenv("AVEC_NT_STG") ? atoi(getenv("AVEC_NT_STG")) : 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
+  static const int stg_env = 3;     // ring depth of the fast implicit-GEMM kernels with 64-byte rows: 3 measured +2..6 % over 2, 4 is -5..10 %
 #define G3(MODE, S_) do { const size_t l2 = (size_t)S_ * (BM + BN) * 64 > epi_lds ? (size_t)S_ * (BM + BN) * 64 : epi_lds; \
     avec_note_kernel("gemm_nt_glds_kernel<%s,%d,%d,%d,%d,1,64>", (sizeof(T) == 2 ? "bf16" : "float"), BM, BN, MODE, S_); if (int r = want_lds(gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>, l2)) return r; hipLaunchKernelGGL((gemm_nt_glds_kernel<T, BM, BN, MODE, S_, true, 64>), grid, dim3(256), l2, st, g); return 0; } while (0)
 #define G(MODE) do { if (MODE != MODE_PLAIN && g.fast_conv) { if (rb64 && stg_env == 3 && (BM + BN) > 128) G3(MODE, 3); if (rb64 && stg_env == 4 && (BM + BN) > 128) G3(MODE, 4); \
     if (rb64) G2(MODE, true, 64); else G2(MODE, true, 128); } G2(MODE, false, 128); } while (0)
-  static const bool use_glds = getenv("AVEC_NO_GLDS") == nullptr;
-  static const bool no_lean = getenv("AVEC_NO_LEAN_NT") != nullptr;
+  static const bool use_glds = true;
+  static const bool no_lean = false;
   if constexpr (sizeof(T) == 2 && BN == 64 && BM == 64) {       // (128 x 64 with the 4-stage ring leaves one workgroup per CU: slower than the general kernel's 2-stage ring)
     // the lean plain kernel: whole 16-byte K-chunks, 32-bit byte offsets into both operands
     const long long arows = g.a.step > 1 ? (g.M / (g.a.rows_out > 0 ? g.a.rows_out : 1) + 1) * (long long)g.a.rows_in : g.M;
-    static const bool no_lean_tail = getenv("AVEC_NO_LEAN_KTAIL") != nullptr;
+    static const bool no_lean_tail = false;
     if (mode == MODE_PLAIN && !f32src && use_glds && !no_lean && g.a.step <= 1 && (g.K % 8 == 0 || (g.ktail && !no_lean_tail)) && g.K >= 8 && g.ldw >= g.K && g.a.ld >= g.K &&
         arows * g.a.ld * 2 < (1ll << 32) && (long long)g.N * g.ldw * 2 < (1ll << 32)) {
       // two-stage ring for products with more than 512 tiles (the slots of the deep ring) and at most 6 K tiles: 3200 x 1024 x 256 + Swish 10.4 -> 8.2 us,
       // 3200 x 768 x 256 8.9 -> 6.4 us, 1600 x 1440 x 360 11.7 -> 9.4 us; step 19.31 -> 19.18 ms (tools/gpu/r4_s2.sh; with 256: no further gain).  AVEC_NT_S2=0: off
-      static const int s2_min = getenv("AVEC_NT_S2") ? atoi(getenv("AVEC_NT_S2")) : 512;
+      static const int s2_min = 512;
       const bool tr = plain_tr_ok(g);
       if (s2_min > 0 && (long long)grid.x * grid.y > s2_min && !g.ktail && g.K <= 384) {
         const size_t l2s = (size_t)2 * (BM + BN) * 128 > epi_lds ? (size_t)2 * (BM + BN) * 128 : epi_lds;
@@ -1452,35 +1452,13 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
   return 0;
 }
 
-// wide tiles of the fast implicit-GEMM kernel (bf16, 64-byte LDS rows, 3-stage ring)
-template <int BM, int BN>
-static int launch_nt_wide(const GemmArgs& g_in, int mode, hipStream_t st) {
-  GemmArgs g = g_in;
-  dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN));
-  if (g.perm2 && mode == MODE_CONV_BWD) {
-    g.pTs[0] = 0; for (int c = 0; c < 4; ++c) g.pTs[c + 1] = g.pTs[c] + (int)((perm2_count(g.a, c, g.pImgs) + BM - 1) / BM);
-    grid.x = (unsigned)g.pTs[4];
-  } else g.perm2 = 0;
-  const size_t epi_lds = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4, ring = (size_t)3 * (BM + BN) * 64;
-  const size_t lds = ring > epi_lds ? ring : epi_lds;
-  avec_note_kernel("gemm_nt_glds_kernel<bf16,%d,%d,%d,3,1,64>", BM, BN, mode);
-  if (mode == MODE_CONV_FWD) {
-    if (int r = want_lds(gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>, lds)) return r;
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_FWD, 3, true, 64>), grid, dim3(256), lds, st, g);
-  } else {
-    if (int r = want_lds(gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_BWD, 3, true, 64>, lds)) return r;
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16, BM, BN, MODE_CONV_BWD, 3, true, 64>), grid, dim3(256), lds, st, g);
-  }
-  return 0;
-}
-
 // host side: 1 = not applicable (caller continues with the generic kernels), 0 = launched, other = error
 static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
   static const bool off = getenv("AVEC_NO_CONV_SHIFT") != nullptr;
   const RowSrc& a = g_in.a;
   if (off || mode == MODE_PLAIN || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW || a.W > 31 || a.C % 32 != 0) return 1;
   if (!aligned16(a.ptr) || !aligned16(g_in.W) || g_in.ldw % 8 != 0 || g_in.M * a.C >= (1ll << 31) || (long long)g_in.N * g_in.ldw >= (1ll << 31) || g_in.N < 64) return 1;
-  static const bool xcd_order = getenv("AVEC_SHIFT_XCD") ? atoi(getenv("AVEC_SHIFT_XCD")) != 0 : true;
+  static const bool xcd_order = true;
   GemmArgs g = g_in; g.perm2 = 0; g.pTs[0] = xcd_order ? 1 : 0;        // (no parity classes here: pTs[0] is this kernel's tile-order switch)
 #define S(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64 + 512 + (BM / 64 - 1) * 2048, epi = (size_t)64 * (BN + 4) * 4 + 10 * BN * 4; const size_t lds = ring > epi ? ring : epi; \
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
@@ -1510,22 +1488,9 @@ template <typename T>
 static int launch_nt(const GemmArgs& g, int mode, int src_f32, hipStream_t st) {
   // tile choice: big tiles only when they still fill the chip (256 CUs)
   long long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-  static const int tile_env = getenv("AVEC_NT_TILE") ? atoi(getenv("AVEC_NT_TILE")) : 0;      // experiments: 128 -> 128x128, 12864 -> 128x64, 64 -> 64x64 for every plain product
-  if (tile_env && mode == MODE_PLAIN) {
-    if (tile_env == 128 && g.N > 64) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
-    if (tile_env == 12864) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
-    if (tile_env == 64) return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
-  }
-  static const int wide_env = getenv("AVEC_NT_WIDE") ? atoi(getenv("AVEC_NT_WIDE")) : 0;
-  if constexpr (sizeof(T) == 2) {
-    if (wide_env && mode != MODE_PLAIN && g.fast_conv && !src_f32 && aligned16(g.a.ptr) && aligned16(g.W) && g.K % 8 == 0 && g.ldw % 8 == 0) {
-      if (wide_env == 1 && g.N >= 256) return launch_nt_wide<128, 256>(g, mode, st);
-      if (wide_env == 3 && g.N >= 128) return launch_nt_wide<256, 128>(g, mode, st);
-    }
-  }
   if (g.N > 64 && t128 >= 384) return launch_nt_mode<T, 128, 128>(g, mode, src_f32, st);
   // plain bf16 products with whole 16-byte K-chunks: the lean 64 x 64 kernel beats the general 128 x 64 one up to the sizes the model has (3200 x 1024 x 256: 11.3 vs 11.8 us)
-  static const bool no_lean = getenv("AVEC_NO_LEAN_NT") != nullptr;
+  static const bool no_lean = false;
   const bool lean = sizeof(T) == 2 && mode == MODE_PLAIN && !src_f32 && !no_lean && g.K % 8 == 0 && ((g.M + 63) / 64) * ((g.N + 63) / 64) <= 4096;      // (K = 8n + 4 with many tiles: the general 128 x 64 kernel is faster, 14.3 vs 16.0 us at 6400 x 720 x 180; the lean kernel takes those shapes only where 64 x 64 tiles are chosen anyway)
   if (!lean && ((g.M + 127) / 128) * ((g.N + 63) / 64) >= 384) return launch_nt_mode<T, 128, 64>(g, mode, src_f32, st);
   return launch_nt_mode<T, 64, 64>(g, mode, src_f32, st);
@@ -1550,7 +1515,7 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
     const int KE = dtype == AVEC_BF16 ? 64 : 32;
     const long long imgs = a_mode == MODE_CONV_FWD ? (M + (long long)a_rows->OH * a_rows->OW - 1) / ((long long)a_rows->OH * a_rows->OW) : (M + (long long)a_rows->H * a_rows->W - 1) / ((long long)a_rows->H * a_rows->W);
     const long long src_elems = imgs * (a_mode == MODE_CONV_FWD ? (long long)a_rows->H * a_rows->W : (long long)a_rows->OH * a_rows->OW) * a_rows->C;
-    static const bool no_fast = getenv("AVEC_NO_FAST_CONV") != nullptr;
+    static const bool no_fast = false;
     g.fast_conv = !no_fast && a_rows->C % KE == 0 && a_rows->KH * a_rows->KW <= 32 && src_elems + (long long)(a_rows->W + a_rows->OW + 2) * a_rows->C * 4 < (1ll << 31) &&
                   (a_mode == MODE_CONV_FWD || a_rows->stride == 1 || a_rows->stride == 2);
     static const bool no_perm = getenv("AVEC_NO_PERM2") != nullptr;
@@ -1631,7 +1596,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
   const bool a16 = nbatch == 1 && aligned16(g.P) && aligned16(g.q.ptr) && g.Iq % VEC == 0 && g.Jq % VEC == 0 && g.ldp % VEC == 0 &&
                    (mode != MODE_PLAIN || (g.q.ld % (f32src ? 4 : VEC) == 0));
   if (sizeof(T) == 2 && a16 && !f32src && !g.Oact && (mode == MODE_PLAIN || g.q_mg != 0)) {        // bf16: LDS-DMA + transposed-read kernel (gathered operand: images of <= 4096 output pixels)
-    static const bool use_tr = getenv("AVEC_NO_TR") == nullptr;
+    static const bool use_tr = true;
     if (use_tr) {
       // reduction rows per LDS tile: 32 (two 16 KB stages for 128x128) keeps 4 workgroups resident per CU; measured on the ResNet weight
       // gradients 1.2-2.1x over 64-row tiles (2 per CU), and 4-stage rings (1 per CU) are 1.5-2x slower: occupancy hides the HBM latency
@@ -1647,7 +1612,7 @@ static int launch_tn_tile(TnArgs g, int mode, int q_f32, int nbatch, hipStream_t
     }
   }
   if (g.pcs) {      // kernels without the fused column sums: a separate pass (plain atomics only when weight gradients run on their own stream)
-    static const bool side_wgrad = getenv("AVEC_WGRAD_STREAM") && getenv("AVEC_WGRAD_STREAM")[0] == '1';
+    static const bool side_wgrad = false;
     if (int r = colsum_launch(sizeof(T) == 2 ? AVEC_BF16 : AVEC_F32, g.P, g.ldp, g.pcs, g.M, g.I, !side_wgrad, st)) return r;
   }     // kernels without the fused column sums
 #define L(MODE, F, A) do { avec_note_kernel("gemm_tn_kernel<%s,%d,%d,%d,%d,%d>", (sizeof(T) == 2 ? "bf16" : "float"), BI, BJ, MODE, (int)F, (int)A); if (int r = want_lds(gemm_tn_kernel<T, BI, BJ, MODE, F, A>, lds)) return r; hipLaunchKernelGGL((gemm_tn_kernel<T, BI, BJ, MODE, F, A>), grid, dim3(256), lds, st, g); } while (0)
@@ -1686,7 +1651,7 @@ static int gemm_tn_impl(int dtype, const void* P, long long ldp, const void* Q, 
     bool exact = true; for (int px = 0; px < ohw && exact; ++px) exact = (int)(((unsigned)px * mg) >> 20) == px / q_rows->OW;
     g.q_ohw = ohw; g.q_mg = exact ? (int)mg : 0;
   }
-  { static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr; g.xcd_map = no_xcd ? 0 : 1; }
+  { static const bool no_xcd = false; g.xcd_map = no_xcd ? 0 : 1; }
   g.sPo = strides ? strides[0] : 0; g.sPi = strides ? strides[1] : 0; g.sQo = strides ? strides[2] : 0; g.sQi = strides ? strides[3] : 0;
   g.sOo = strides ? strides[4] : 0; g.sOi = strides ? strides[5] : 0;
   // P batches stay dword aligned; Q batches may start on any element (heads of odd width, d = 45: the plain-load kernels issue unaligned dword loads, which gfx950 serves)
@@ -1732,7 +1697,7 @@ extern "C" int avec_gemm_tn_batched_store(int dtype, const void* P, long long ld
 
 extern "C" int avec_gemm_tn_batched_multi(int dtype, const avec_tn_batched_t* items, int n, hipStream_t stream) {
   AVEC_CHECK_ARG(items && n >= 1 && n <= AVEC_TN_MULTI_MAX, "gemm_tn_batched_multi: need 1..%d problems (got %d)", AVEC_TN_MULTI_MAX, n);
-  static const bool off = getenv("AVEC_NO_TN_MULTI") != nullptr;
+  static const bool off = false;
   TnMulti m; m.n = 0; m.first[0] = 0;
   if (!off) tn_collect = &m;
   int rc = 0;
@@ -1771,12 +1736,12 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
   for (int k = 0; k < n; ++k) AVEC_CHECK_ARG(tn_item_ok(dtype, items[k]), "gemm_tn_grouped: item %d is not eligible (bf16 operands, row strides >= widths, bias sums need I %% 4 == 0)", k);
   // tile size: 128x128 tiles read each operand byte half as often as 64x64 (these products are bound by L2 traffic), but a group must still cover the
   // chip: take the big tile when the group has enough of them
-  static const int bt_env = getenv("AVEC_TNG_TILE") ? atoi(getenv("AVEC_TNG_TILE")) : 0;
+  static const int bt_env = 0;
   long long t128 = 0;
   for (int k = 0; k < n; ++k) t128 += (long long)((items[k].I + 127) / 128) * ((items[k].J + 127) / 128);
   const int BT = bt_env == 64 || bt_env == 128 ? bt_env : (t128 >= 96 ? 128 : 64);
   // common reduction-slice length: the largest multiple of 64 rows (>= 256) that still yields ~wg_target workgroups over the whole group
-  static const long long wg_env = getenv("AVEC_TNG_WGS") ? atoll(getenv("AVEC_TNG_WGS")) : 0;
+  static const long long wg_env = 0;
   const long long wg_target = wg_env > 0 ? wg_env : 512;       // every slice costs I*J atomics: 256-512 beat 1536 by 0.2 ms in the step; with the lean DMA loop 512 beats 384 (21.14 vs 21.24 ms, two same-box sweeps)
   long long per = 256;
   for (long long cand = 8192; cand >= 256; cand -= 64) {
@@ -1797,10 +1762,10 @@ extern "C" int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int 
     first += t.gx * t.gy * t.split;
   }
   grp.total = first;
-  static const bool no_xcd = getenv("AVEC_NO_XCD_MAP") != nullptr;
+  static const bool no_xcd = false;
   grp.xcd_map = no_xcd ? 0 : 1;
-  static const int kt_env = getenv("AVEC_TNG_KT") ? atoi(getenv("AVEC_TNG_KT")) : 64;       // reduction rows per LDS tile
-  static const int stg_env = getenv("AVEC_TNG_STAGES") ? atoi(getenv("AVEC_TNG_STAGES")) : 2;
+  static const int kt_env = 64;       // reduction rows per LDS tile
+  static const int stg_env = 2;
   const int KT = kt_env == 32 ? 32 : 64, STG = (stg_env == 4 && KT == 32) ? 4 : 2;       // (2 x 64 rows and 4 x 32 rows measure the same, 3 stages are slower: profiles/r03_tn_grouped.txt)
   const size_t lds = (size_t)STG * KT * (BT + BT) * 2;
   avec_note_kernel("gemm_tn_tr_grouped_kernel<%d,%d,%d>", BT, STG, KT);

@@ -2,6 +2,7 @@
 //   CTC      : nnet/losses.py:311-334  (log_softmax -> nn.CTCLoss(blank=0, reduction="none", zero_infinity))
 //   Adam     : nnet/optimizers.py:61-93 over torch.optim.Adam (coupled L2 weight decay), lr from a device scalar
 //   shadows  : compute-dtype copies of the GEMM weights in the two layouts the NT kernels want
+#include <atomic>
 #include "vec.h"
 #include "avec_hip.h"
 
@@ -277,17 +278,23 @@ __global__ __launch_bounds__(256) void ctc_alpha_lds_kernel(const float* __restr
 extern "C" long long avec_ctc_workspace_floats(int B, int T, int Lmax) { return (long long)B * ((long long)T * (2 * Lmax + 1) + T); }
 
 // Waves per utterance of the all-LDS kernels: the log-normaliser and gradient phases work frame by frame, one frame per wave and pass -- 16 waves when their
-// occupancy histograms still fit the 64 KB (each is V floats), else 4.  AVEC_CTC_WAVES=4: the round-1 shape
+// occupancy histograms still fit the 64 KB (each is V floats), else 4
 static int ctc_waves(size_t lds4, int V) {
-  static const int want = getenv("AVEC_CTC_WAVES") ? atoi(getenv("AVEC_CTC_WAVES")) : 16;
+  static const int want = 16;
   if (want < 16 || lds4 + (size_t)12 * V * 4 > 128 * 1024) return 4;
-  static bool attr_set = false, attr_ok = false;           // (more than 64 KB of dynamic LDS has to be asked for once per kernel)
-  if (!attr_set) {
-    attr_set = true;
-    attr_ok = hipFuncSetAttribute((const void*)ctc_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-              hipFuncSetAttribute((const void*)ctc_lds_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-    if (!attr_ok) (void)hipGetLastError();
+  // (more than 64 KB of dynamic LDS has to be asked for once per kernel AND device; the call is cheap, the state is per device and published with release / acquire
+  //  so that a second device or a concurrent first call from the autograd thread never launches without it)
+  static std::atomic<int> state[16];                        // per device: 0 unknown, 1 granted, 2 refused
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  int stt = state[dev].load(std::memory_order_acquire);
+  if (stt == 0) {
+    const bool ok = hipFuncSetAttribute((const void*)ctc_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)ctc_lds_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    stt = ok ? 1 : 2;
+    state[dev].store(stt, std::memory_order_release);
   }
+  const bool attr_ok = stt == 1;
   return (attr_ok || lds4 + (size_t)12 * V * 4 <= 64 * 1024) ? 16 : 4;
 }
 extern "C" int avec_ctc_loss(const float* logits, const long long* in_lens, const long long* targets, const long long* tgt_lens, float* nll, float* mean_out,

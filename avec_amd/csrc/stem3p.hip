@@ -399,243 +399,8 @@ __device__ __forceinline__ void s3p_glds16(const void* gsrc, unsigned lds_dst_un
 // columns 4 Cg .. 4 Cg + 3, (R, Cg) = (S / ncg, S % ncg), ncg = OW / 4; a tile is 8 steps (tile row m = 16 s + k).  With this order the gather address of a lane's 8 pixels of a
 // step is  (tap offset + g * 4 pitch)  +  (R * 8 pitch + Cg * 16: wave-uniform)  +  ((e >> 2) * 2 pitch + (e & 3) * 4: immediates when the pitch is a compile-time constant):
 // one VALU add per step instead of ~50 (at ~4 cycles per wave64 VALU instruction and 2 waves per SIMD only ~8 VALU instructions hide under one MFMA).
-template <int PITCH_CT>
-__global__ __launch_bounds__(512) void stem3p_wgrad_kernel(const bf16* __restrict__ vb, const bf16* __restrict__ wsh, const float* __restrict__ bias, const bf16* __restrict__ dpm,
-                                                            const unsigned char* __restrict__ idx, const float* __restrict__ ss, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dstats, const float* count_ptr, float count, float* dw, float* dgamma, float* dbeta,
-                                                            S3P G, S3W Q, ColWs ws, int abl) {
-  extern __shared__ __attribute__((aligned(16))) char s3[];
-  char* const slab = s3;                                            // [6 slots][SLOT]: rows of pitch bytes, SH rows per frame
-  char* const dpl = slab + 6 * Q.SLOT;                              // [2][DPB]: pooled gradients (masked) of the band's pn + 1 pooled rows, [row][pw][64] bf16
-  char* const ixl = dpl + 2 * Q.DPB;                                // [2][IXB]: their window slots, [row][pw][64] u8
-  char* const tiles = ixl + 2 * Q.IXB;                              // [2][128 px][64 ch] bf16, chunk c of row m at slot c ^ (4 * ((m >> 1) & 1))
-  const int pitch = PITCH_CT ? PITCH_CT : G.pitch;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5, pl = lane & 31;
-  const int pgp = wave >> 1, chh = wave & 1;                        // conv part: pixel group / channel half of this wave
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)s3;
-  if (blockIdx.x == 0 && dgamma && tid < S3P_C) { atomicAdd(dgamma + tid, dstats[S3P_C + tid]); atomicAdd(dbeta + tid, dstats[tid]); }
-  // ---- conv part: weights of this wave's 32 channels (MFMA A operand: row = channel) ----
-  chunk16 wf[18];
-#pragma unroll
-  for (int s = 0; s < 18; ++s) wf[s] = ldg16(wsh + (long long)(32 * chh + pl) * 288 + (2 * s + g) * 8);
-  // ---- wgrad part: accumulators (this lane's tap x 64 channels), transposed-read offsets of the dz tile ----
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  int tkd, toff;                                                    // tap -> frame offset kd and byte offset inside a frame slot (row kh, element kw + 1 behind the 8-byte left pad, rows 2 g, 2 g + 1 of the step)
-  { const int k = 32 * wave + pl; const int r = k / 7 > 34 ? 34 : k / 7; tkd = r / 7; toff = (r % 7) * pitch + (k % 7 + 1) * 2 + 8 + g * 4 * pitch; }
-  int eoff[8];                                                      // (generic pitch) offsets of the lane's 8 pixels inside a step
-#pragma unroll
-  for (int e = 0; e < 8; ++e) eoff[e] = (e >> 2) * 2 * pitch + (e & 3) * 4;
-  const int g4 = lane >> 4, t16 = lane & 15;
-  int offb[2][2];
-#pragma unroll
-  for (int hh2 = 0; hh2 < 2; ++hh2) {
-    const int row = 8 * (g4 >> 1) + 4 * hh2 + (t16 >> 2);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int cb = 32 * j + 16 * (g4 & 1); offb[j][hh2] = row * 128 + ((((cb >> 3) + ((t16 & 3) >> 1)) ^ (4 * ((row >> 1) & 1))) << 4) + (t16 & 1) * 8; }
-  }
-  // ---- stage-2 constants of this thread's 8 channels: dz = A (dr - B - (acc - mu') Cc),  mu' = mean - bias ----
-  const int cg = tid & 7;
-  const float inv_n = 1.f / (count_ptr ? *count_ptr : count);
-  float cA[8], cB[8], cC[8], cMu[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cg * 8 + e; const float rs = ss[3 * S3P_C + c];
-    cA[e] = gamma[c] * rs; cB[e] = dstats[c] * inv_n; cC[e] = dstats[S3P_C + c] * inv_n * rs; cMu[e] = ss[2 * S3P_C + c] - (bias ? bias[c] : 0.f);
-  }
-  const int trow = 32 * pgp + pl;                                   // conv part: this lane's row of a tile = step 2 pgp + (pl >> 4), k = pl & 15
-  const int tsw = 4 * ((trow >> 1) & 1);
-  const int ck = pl & 15, crho = ck >> 2, ckap = ck & 3, cstep = 2 * pgp + (pl >> 4);
-  // stage 2: task u of wave w handles the 8 tile rows of parity class c (row parity rp, column parity cp) in steps 2 q, 2 q + 1; the classes of a wave's two tasks are
-  // complementary ((0,0) + (1,1): 1 + 4 candidate windows, (0,1) + (1,0): 2 + 2), so every wave does about the same work and the window loops are wave-uniform
-  const int ncg = G.OW >> 2;
-  const unsigned ncg_m = ((1u << 20) + (unsigned)ncg - 1u) / (unsigned)ncg;      // S / ncg = (S * ncg_m) >> 20 for the step indices of a band (S < 4096, ncg <= 64: exact) -- a per-lane integer division is ~35 VALU instructions
-
-  // one frame slot: chunk q = tid (SLOT = 512 chunks >= SH * CPR) <- input row ir0 + q / CPR of frame `itf`, chunk q % CPR (zero page: padding chunks, rows outside the frame)
-  auto dma_frame = [&](long long clip, int itf, int ir0, int slot) {
-    const int row = tid / G.CPR, j = tid - row * G.CPR; const int ih = ir0 + row;
-    const bool ok = row < G.SH && itf >= 0 && itf < G.T3 && ih >= 0 && ih < G.H && j >= 1 && j <= G.CPR - 2;
-    const void* sp = ok ? (const void*)(vb + ((clip * G.T3 + itf) * (long long)G.H + ih) * G.W + (j - 1) * 8) : (const void*)s3p_zero16;
-    s3p_glds16(sp, lds0 + slot * Q.SLOT + wave * 1024);
-  };
-  // the band's pooled rows ph0 .. ph0 + pn of frame cf: contiguous in memory; rows beyond PH come from the zero page
-  auto dma_pooled = [&](long long cf, int ph0, int buf) {
-    const int nrow = G.pn + 1;
-    const long long dp0 = ((cf * G.PH + ph0) * (long long)G.PW) * S3P_C;     // element offset of the first pooled pixel (bf16 / u8 alike)
-    const int valid_px = (min(G.PH, ph0 + nrow) - ph0) * G.PW;
-    for (int q0 = wave * 64; q0 < Q.DPB / 16; q0 += 512) {          // 8 chunks of 16 B per pooled pixel
-      const int q = q0 + lane;
-      const void* sp = (q >> 3) < valid_px ? (const void*)(dpm + dp0 + (long long)q * 8) : (const void*)s3p_zero16;
-      s3p_glds16(sp, lds0 + 6 * Q.SLOT + buf * Q.DPB + q0 * 16);
-    }
-    for (int q0 = wave * 64; q0 < Q.IXB / 16; q0 += 512) {          // 4 chunks per pooled pixel
-      const int q = q0 + lane;
-      const void* sp = (q >> 2) < valid_px ? (const void*)(idx + dp0 + (long long)q * 16) : (const void*)s3p_zero16;
-      s3p_glds16(sp, lds0 + 6 * Q.SLOT + 2 * Q.DPB + buf * Q.IXB + q0 * 16);
-    }
-  };
-
-  for (long long unit = blockIdx.x; unit < Q.units; unit += gridDim.x) {
-    const int chunk = (int)(unit % Q.NCH); const int band = (int)((unit / Q.NCH) % G.NB); const long long clip = unit / ((long long)Q.NCH * G.NB);
-    const int f0 = chunk * Q.CH, f1 = min(G.T3, f0 + Q.CH);
-    const int ph0 = band * G.pn; const int pnb = min(G.pn, G.PH - ph0);
-    const int cr0 = 2 * ph0, cr1 = min(G.OH - 1, 2 * (ph0 + pnb) - 1);
-    const int ncr = cr1 - cr0 + 1, NS = ((ncr + 3) >> 2) * ncg, ntile = (NS + 7) >> 3;
-    const int ir0 = 2 * cr0 - 3;
-    __syncthreads();                                                // the previous unit is done with every buffer (nothing is in flight: it ended with vmcnt(0))
-#pragma unroll 1
-    for (int d = -2; d <= 2; ++d) { int sl = (f0 + d) % 6; if (sl < 0) sl += 6; dma_frame(clip, f0 + d, ir0, sl); }
-    dma_pooled(clip * G.T3 + f0, ph0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int f = f0; f < f1; ++f) {
-      const long long cf = clip * G.T3 + f;
-      const int pb = (f - f0) & 1;
-      if (f + 1 < f1 && !(abl & 8)) { dma_frame(clip, f + 3, ir0, (f + 3) % 6); dma_pooled(cf + 1, ph0, pb ^ 1); }      // one frame ahead (their buffers were last read in frame f - 1)
-      int fb[5];                                                    // byte offset of the slot of frame f + kd - 2
-#pragma unroll
-      for (int kd = 0; kd < 5; ++kd) { int sl = (f + kd - 2) % 6; if (sl < 0) sl += 6; fb[kd] = sl * Q.SLOT; }
-      const char* dpb = dpl + pb * Q.DPB; const char* ixb = ixl + pb * Q.IXB;
-
-      auto conv_tile = [&](int t) {                                 // raw z^T of tile t -> tiles[t & 1]
-        int S = 8 * t + cstep; if (S >= NS) S = 0;
-        const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
-        const char* pix = slab + (2 * (4 * R + crho)) * pitch + 4 * (4 * Cg + ckap) + 8;
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        chunk16 fa[18];
-        auto ldfrag = [&](int s) {
-          const int ra = 2 * s > 34 ? 34 : 2 * s, rb_ = 2 * s + 1 > 34 ? 34 : 2 * s + 1;
-          const int offA = fb[ra / 7] + (ra % 7) * pitch, offB = fb[rb_ / 7] + (rb_ % 7) * pitch;
-          const uint32_t* rp = (const uint32_t*)(pix + (g ? offB : offA));
-          chunk16 fr; fr.w[0] = rp[0]; fr.w[1] = rp[1]; fr.w[2] = rp[2]; fr.w[3] = rp[3]; return fr;
-        };
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fa[s] = ldfrag(s);
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-          if (s + 4 < 18) fa[s + 4] = ldfrag(s + 4);
-          asm volatile("" ::: "memory");
-          asm volatile("" : "+v"(fa[s].w[0]), "+v"(fa[s].w[1]), "+v"(fa[s].w[2]), "+v"(fa[s].w[3]));      // (the use stays below the requests of step s + 4)
-          z = s3p_mma(wf[s], fa[s], z);
-        }
-        char* tw = tiles + (t & 1) * 16384 + trow * 128;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)                                 // channels 32 chh + 8 a + 4 g .. + 3 = half g of chunk 4 chh + a
-          *(uint2*)(tw + (((4 * chh + a) ^ tsw) << 4) + 8 * g) = make_uint2(f32x2_to_bf16x2(z[4 * a], z[4 * a + 1]), f32x2_to_bf16x2(z[4 * a + 2], z[4 * a + 3]));
-      };
-
-      auto stage2 = [&](int t) {                                    // tiles[t & 1]: z -> dz in place (rows beyond the band: zero)
-        char* tb = tiles + (t & 1) * 16384;
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-          const int c = u ? 3 - (wave & 3) : (wave & 3); const int rp = c >> 1, cp = c & 1;      // (wave-uniform)
-          const int q = 2 * u + (wave >> 2);
-          const int j = lane >> 3;
-          const int s = 2 * q + (j >> 2), rho = rp + 2 * ((j >> 1) & 1), kap = cp + 2 * (j & 1);
-          const int row = 16 * s + 4 * rho + kap;
-          const int S = 8 * t + s; const int R = (int)(((unsigned)S * ncg_m) >> 20), Cg = S - R * ncg;
-          const int hl = 4 * R + rho, w = 4 * Cg + kap; const int h = cr0 + hl;
-          const bool pv = S < NS && hl < ncr;
-          char* zp_ = tb + row * 128 + ((cg ^ (4 * ((row >> 1) & 1))) << 4);
-          float o[8];
-          if (pv) {
-            // candidate windows: rows oh = h >> 1 (slot kh = 1 + rp) and, for odd h, oh + 1 (kh = 0); likewise for columns
-            const int ohA = h >> 1, owA = w >> 1;
-            float dr[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dr[e] = 0.f;
-            for (int a = 0; a <= rp; ++a)
-              for (int b = 0; b <= cp; ++b) {
-                const int oh = ohA + a, ow_ = owA + b;
-                const bool ok = oh < G.PH && ow_ < G.PW;
-                const unsigned slotq = (unsigned)((a ? 0 : 1 + rp) * 3 + (b ? 0 : 1 + cp));
-                const int lp = ok ? ((oh - ph0) * G.PW + ow_) : 0;
-                const uint2 sel = *(const uint2*)(ixb + lp * 64 + cg * 8);
-                const uint4 gq = *(const uint4*)(dpb + lp * 128 + cg * 16); const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const unsigned sq = ((e < 4 ? sel.x : sel.y) >> (8 * (e & 3))) & 255u;
-                  const float gv = (e & 1) ? __uint_as_float(gw[e >> 1] & 0xffff0000u) : __uint_as_float(gw[e >> 1] << 16);
-                  if (ok && sq == slotq) dr[e] += gv;
-                }
-              }
-            const uint4 tz = *(const uint4*)zp_; const uint32_t wv[4] = {tz.x, tz.y, tz.z, tz.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float zl = __uint_as_float(wv[e] << 16), zh = __uint_as_float(wv[e] & 0xffff0000u);
-              o[2 * e] = cA[2 * e] * (dr[2 * e] - cB[2 * e] - (zl - cMu[2 * e]) * cC[2 * e]);
-              o[2 * e + 1] = cA[2 * e + 1] * (dr[2 * e + 1] - cB[2 * e + 1] - (zh - cMu[2 * e + 1]) * cC[2 * e + 1]);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = 0.f;
-          }
-          *(uint4*)zp_ = make_uint4(f32x2_to_bf16x2(o[0], o[1]), f32x2_to_bf16x2(o[2], o[3]), f32x2_to_bf16x2(o[4], o[5]), f32x2_to_bf16x2(o[6], o[7]));
-        }
-      };
-
-      auto wgrad_tile = [&](int t) {                                // D += A^T x dz of tiles[t & 1]
-        const char* tb = tiles + (t & 1) * 16384;
-        const char* gb = slab + fb[tkd] + toff;                     // this lane's tap (and row pair 2 g) at pixel (0, 0) of the band
-        const int S0 = 8 * t; int R = S0 / ncg, Cg = S0 - R * ncg;  // (wave-uniform: scalar registers)
-        uint32_t gl[2][8];
-        auto gather = [&](int s, uint32_t (&o)[8]) {
-          int Rs = R, Cs = Cg + s; while (Cs >= ncg) { Cs -= ncg; ++Rs; }
-          const char* gp = gb + (Rs * 8 * pitch + Cs * 16);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = *(const unsigned short*)(gp + (PITCH_CT ? (e >> 2) * 2 * PITCH_CT + (e & 3) * 4 : eoff[e]));
-        };
-        const int nst = min(8, NS - S0);
-        gather(0, gl[0]);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {                               // 16 pixels per step: this lane's 8 = rows 2 g, 2 g + 1 x 4 columns
-          if (s < nst) {
-            const char* db = tb + (16 * s) * 128;
-            const chunk16 fb0 = s3p_tr8(db + offb[0][0], db + offb[0][1]), fb1 = s3p_tr8(db + offb[1][0], db + offb[1][1]);
-            if (s + 1 < 8 && s + 1 < nst) gather(s + 1, gl[(s + 1) & 1]);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(gl[s & 1][e]));      // (packing stays below the next step's requests: one LDS round trip per step, not per pair)
-            chunk16 fa2;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) fa2.w[e >> 1] = gl[s & 1][e] | (gl[s & 1][e + 1] << 16);
-            acc[0] = s3p_mma(fa2, fb0, acc[0]); acc[1] = s3p_mma(fa2, fb1, acc[1]);
-          }
-        }
-      };
-
-      if (!(abl & 1)) conv_tile(0);
-      S3P_BAR();
-      if (!(abl & 2)) stage2(0);
-      S3P_BAR();
-      for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile && !(abl & 1)) conv_tile(t + 1);
-        if (!(abl & 4)) wgrad_tile(t);
-        S3P_BAR();
-        if (t + 1 < ntile) { if (!(abl & 2)) stage2(t + 1); S3P_BAR(); }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next frame's slab slot and pooled band have landed
-      S3P_BAR();
-    }
-  }
-  // D[k][c] -> dw[c][245] (fp32): through the workspace partial ([64][245] per workgroup) or atomics
-  {
-    float* mine = ws.partial ? ws_slot(ws, 0, blockIdx.x, gridDim.x, S3P_C * 245) : nullptr;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * g, c = 32 * j + pl;
-        if (k < 245) { if (mine) mine[c * 245 + k] = acc[j][r]; else atomicAdd(dw + c * 245 + k, acc[j][r]); }
-      }
-  }
-}
-
+// (The eight-wave lockstep version of this kernel -- conv -> barrier -> stage 2 -> barrier -> product, all waves together: 1 018 us against 936 us with the two wave roles
+// below -- was removed in round 6)
 template <int PITCH_CT>
 __global__ __launch_bounds__(512) void stem3p_wgrad_roles_kernel(const bf16* __restrict__ vb, const bf16* __restrict__ wsh, const float* __restrict__ bias, const bf16* __restrict__ dpm,
                                                             const unsigned char* __restrict__ idx, const float* __restrict__ ss, const float* __restrict__ gamma,
@@ -1024,20 +789,11 @@ extern "C" int avec_stem3p_wgrad(const void* video_bf16, const void* w_shadow, c
   AVEC_CHECK_ARG(((((size_t)video_bf16) | ((size_t)dpool_masked) | ((size_t)idx)) & 15) == 0, "stem3p_wgrad: operands must be 16-byte aligned");
   S3P G; S3W Q; size_t lf, lb, lw;
   AVEC_CHECK_ARG(s3p_geom(G, clips, T_, H, W, &lf, &lb) && s3w_geom(G, clips, Q, &lw), "stem3p_wgrad: frame %dx%d not supported", H, W);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)stem3p_wgrad_kernel<208>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem3p_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { avec_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr = true;
-  }
   unsigned nb = 256; if ((long long)nb > Q.units) nb = (unsigned)Q.units;
   ColWs ws = avec_reduce_ws((size_t)nb * S3P_C * 245, st);
-  avec_note_kernel("stem3p_wgrad_kernel");
+  avec_note_kernel("stem3p_wgrad_roles_kernel");
   static const int abl = getenv("AVEC_S3W_ABL") ? atoi(getenv("AVEC_S3W_ABL")) : 0;      // kernel ablation (measurement only): 1 no conv part, 2 no stage 2, 4 no weight-gradient part, 8 no DMA prefetch
-  static const bool roles = getenv("AVEC_S3W_ROLES") == nullptr || atoi(getenv("AVEC_S3W_ROLES")) != 0;      // producer / consumer wave roles (round 5); 0: the eight-wave lockstep kernel
-  if (roles) {
-    static bool attr2 = false;
+  { static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)stem3p_wgrad_roles_kernel<208>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem3p_wgrad_roles_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1046,18 +802,13 @@ extern "C" int avec_stem3p_wgrad(const void* video_bf16, const void* w_shadow, c
     }
     const size_t lw2 = lw + 1024;             // + the stage-2 constant table
     AVEC_CHECK_ARG(lw2 <= 160 * 1024, "stem3p_wgrad: LDS");
-    if (G.pitch == 208)
+    if (G.pitch == 208)      // (W = 88: the gather offsets of a step are instruction immediates)
       hipLaunchKernelGGL(stem3p_wgrad_roles_kernel<208>, dim3(nb), dim3(512), lw2, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
                          dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
     else
       hipLaunchKernelGGL(stem3p_wgrad_roles_kernel<0>, dim3(nb), dim3(512), lw2, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
                          dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
-  } else if (G.pitch == 208)      // (W = 88: the gather offsets of a step are instruction immediates)
-    hipLaunchKernelGGL(stem3p_wgrad_kernel<208>, dim3(nb), dim3(512), lw, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
-                       dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
-  else
-    hipLaunchKernelGGL(stem3p_wgrad_kernel<0>, dim3(nb), dim3(512), lw, st, (const bf16*)video_bf16, (const bf16*)w_shadow, bias, (const bf16*)dpool_masked, idx, ss, gamma,
-                       dstats, count_ptr, count, dw, dgamma, dbeta, G, Q, ws, abl);
+  }
   AVEC_LAUNCH_CHECK();
   if (ws.partial) { float* const dst[1] = {dw}; return col_finalize(ws, 1, nb, 1, S3P_C * 245, dst, S3P_C * 245, st); }
   return 0;

@@ -99,7 +99,7 @@ static inline ColWs col_ws(dim3 grid, int NV, hipStream_t st) { return avec_redu
 // AVEC_COLWS_MIN_ATOMICS: one-pass below this many atomics (default 16384).  Round 4 measured the step with 70 000 (the BatchNorm reductions of the conformer
 // convolution modules lose their second-pass launch, ~4.7 us each inside a dependent chain): 20.00 vs 19.90 ms; with 270 000: 21.2 ms -- the contended fp32 atomics
 // cost more than the launch they replace.
-static inline long long col_ws_min_atomics() { static long long v = -1; if (v < 0) { const char* e = getenv("AVEC_COLWS_MIN_ATOMICS"); v = e ? atoll(e) : 16384; } return v; }
+static inline long long col_ws_min_atomics() { return 16384; }
 static inline ColWs col_ws_if(dim3 grid, int NV, int C, hipStream_t st) {
   const long long atomics = (long long)grid.y * NV * C;
   return atomics > col_ws_min_atomics() ? col_ws(grid, NV, st) : ColWs{nullptr};
@@ -142,7 +142,7 @@ __device__ __forceinline__ void colreduce8_atomic(float (&part)[NV][8], float* c
   }
 }
 static inline bool col8_ok(int C) { return C % 8 == 0 && C <= 2048; }
-static inline long long col8_cap() { static long long cap = 0; if (!cap) { const char* e = getenv("AVEC_COL8_BLOCKS"); cap = e ? atoll(e) : 1024;      /* re-swept at the end of round 3 (tools/bench_bn.py): 1024 beats 2048 on every ResNet stage but the first (equal there) */ if (cap < 1) cap = 1; } return cap; }
+static inline long long col8_cap() { return 1024; }      /* re-swept at the end of round 3 (tools/bench_bn.py): 1024 beats 2048 on every ResNet stage but the first (equal there) */
 static inline unsigned col8_blocks(long long M, int C) { const int R = 256 / (C / 8); long long nb = (M + R - 1) / R; if (nb > col8_cap()) nb = col8_cap(); return (unsigned)nb; }
 // grid size + workspace of a flat 8-wide launch (finish with col_finalize(ws, 1, nb, NV, C, dst, C, st)); without a workspace the
 // block count is kept low (every block issues NV*C atomics)

@@ -326,9 +326,9 @@ int wgrad3x3_pairs_grouped(const avec_wgrad3x3_item_t* items, int n, hipStream_t
     g.cum[i + 1] = g.cum[i] + (long long)kinds * g.stages[i] * g.wt[i];
     total_stages += (long long)kinds * g.stages[i];
   }
-  static const int wgs_env = getenv("AVEC_WP_WGS") ? atoi(getenv("AVEC_WP_WGS")) : 256;
+  static const int wgs_env = 256;
   const int grid = (int)(total_stages < wgs_env ? total_stages : wgs_env);
-  static const int ranges_env = getenv("AVEC_WP_RANGES") ? atoi(getenv("AVEC_WP_RANGES")) : 0;      // A/B: 1 = kind-major order (one range per layer)
+  static const int ranges_env = 0;      // A/B: 1 = kind-major order (one range per layer)
   for (int i = 0; i < n; ++i) {      // ranges: one share ~ one kind over one range
     const int kinds = (items[i].C / 64) * (items[i].C / 128);
     const double shares = (double)grid * (double)(g.cum[i + 1] - g.cum[i]) / (double)g.cum[n];

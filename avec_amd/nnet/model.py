@@ -300,10 +300,10 @@ class Model(Module):
             with torch.cuda.graph(graph, **gkw):        # (the optimizer's device-side {step, lr} pair exists since the warm-up; each replay is preceded by prepare_step)
                 static_losses = body()
         except Exception as e:
-            if not (dist_mode and state["in_graph"] and peer.active() is not None):
+            if not (dist_mode and state["in_graph"]):
                 raise
             cap_err = e
-        if dist_mode and state["in_graph"] and peer.active() is not None:
+        if dist_mode and state["in_graph"]:
             # the fallback must be the SAME on every rank: a rank that keeps captured collectives beside one that issues them eagerly is a collective mismatch
             flag = torch.tensor([0.0 if cap_err is None else 1.0], device=self.device)
             torch.cuda.synchronize()
@@ -414,7 +414,7 @@ class Model(Module):
 
     def eval_step(self, inputs, targets, verbose=0):
         with torch.no_grad():
-            rt.reset_zero_pool(self.device)          # (the scratch pool hands out PRE-ZEROED accumulators: whatever earlier steps or replays of other shapes left there must go)
+            rt.reset_zero_pool(self.device, create=False)      # (the scratch pool hands out PRE-ZEROED accumulators: whatever earlier steps or replays of other shapes left there must go; an evaluation-only process never allocates it)
             batch_losses, batch_metrics, batch_truths, batch_preds = self.forward_model(inputs, targets, verbose=verbose)
             return self._own_losses(batch_losses), batch_metrics, batch_truths, batch_preds
 

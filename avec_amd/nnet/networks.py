@@ -236,10 +236,10 @@ class AudioVisualEfficientConformerEncoder(nn.Module):
             main = torch.cuda.current_stream()
             rt.stream()                                   # default reduction workspace registered before the fork
             # weight shadows: the visual front-end's on this stream (the stem starts at once), the other 80 % on the audio stream beside the stem's forward
-            # pass (a persistent kernel that leaves the HBM idle); this stream waits for them in front of the visual back-end.  AVEC_SHADOW_SPLIT=0: one launch
+            # pass (a persistent kernel that leaves the HBM idle); this stream waits for them in front of the visual back-end.
             arena = rt.arena_of(self)
             sh_ev = None
-            split = arena is not None and not audio_first_env() and os.environ.get("AVEC_SHADOW_SPLIT", "1") != "0"
+            split = arena is not None and not audio_first_env()
             if split:
                 side.wait_stream(main)
                 sh_ev = arena.ensure_fresh_split(arena.prefix_blocks(self.video_encoder.front_end), side)

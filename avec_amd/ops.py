@@ -145,10 +145,10 @@ def empty(shape, dtype, ref):
     return torch.empty(shape, dtype=dtype, device=ref.device)
 
 
-TN_MULTI = os.environ.get("AVEC_TN_MULTI", "1") == "1"                     # attention backward: dK, dV and dE as one launch (0: three)
-ATTN_ODD_VALU = os.environ.get("AVEC_ATTN_ODD_VALU", "0") == "1"             # A/B: odd head widths take the VALU column pass of the attention backward (round 2)
-CAST_DEFER = os.environ.get("AVEC_CAST_DEFER", "1") == "1"                   # fp32-input weight gradients: cast once and join the grouped launch (0: a launch of their own)
-TNG_ALIGNED_ONLY = os.environ.get("AVEC_TNG_ALIGNED_ONLY", "0") == "1"       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
+TN_MULTI = True                     # attention backward: dK, dV and dE as one launch (0: three)
+ATTN_ODD_VALU = False             # A/B: odd head widths take the VALU column pass of the attention backward (round 2)
+CAST_DEFER = True                   # fp32-input weight gradients: cast once and join the grouped launch (0: a launch of their own)
+TNG_ALIGNED_ONLY = False       # A/B: only 16-byte-aligned operands take the grouped weight-gradient launch
 
 
 def _chunk_readable(t, ld, width, rows):
@@ -232,15 +232,17 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
     return out
 
 
+# (The module-level switches of this file -- TN_MULTI, PREP_FUSE, LN_PAIR, RELU_BITMASK, STEM3P, ... -- are plain constants since round 6: the alternatives they select
+# are kept for the parity tests that flip them in-process (tests/test_gpu_round3.py, test_gpu_round4.py, test_gpu_parity.py), not as environment switches.)
 # ---- deferred parameter gradients ------------------------------------------------------------------------------------------------------------
 # Weight gradients (dW = dY^T X), bias gradients and LayerNorm gamma/beta gradients only feed the optimizer: nothing in the backward chain waits for
 # them.  Launched one by one they are ~45 % of a conformer block's backward launches, each latency-bound (a few hundred workgroups, 12-21 us).  Inside a
 # backward pass they are therefore QUEUED per stream (the operand tensors stay referenced) and submitted as grouped launches (avec_gemm_tn_grouped,
 # avec_layernorm_param_grads_grouped: one grid over the tiles of up to 32 / 40 products) when a queue fills, at the explicit flush points (end of the audio
-# branch, before an early gradient all-reduce) and by a final autograd callback when the backward pass ends.  AVEC_DEFER_WGRAD=0 restores immediate launches.
+# branch, before an early gradient all-reduce) and by a final autograd callback when the backward pass ends.  ops.DEFER_WGRAD = False restores immediate launches.
 DEFER_WGRAD = os.environ.get("AVEC_DEFER_WGRAD", "1") != "0"
-_TN_WHY = os.environ.get("AVEC_TN_WHY", "0") == "1"      # debugging aid: print every weight-gradient product that misses the grouped launch
-_TN_FLUSH_AT = int(os.environ.get("AVEC_DEFER_TN_MAX", str(TN_GROUP_MAX)))
+_TN_WHY = False      # debugging aid: print every weight-gradient product that misses the grouped launch
+_TN_FLUSH_AT = TN_GROUP_MAX
 _DEFER = {"queues": {}, "task": -1}
 
 
@@ -392,7 +394,7 @@ def layernorm_fwd(x, w, b, M, D, out_f32, eps):
 # (avec_layernorm_bwd_prep).  Forward: a module tags its output tensor with (alpha, drop_p, rng stream); the consumer module remembers the tag of its input.
 # Backward: the consumer's LayerNorm backward produces the prepared gradient and leaves it under dx's address; the producer module takes it if the address, the
 # backward pass, the shape and its own (alpha, drop_p, stream) all match, and launches grad_prep otherwise (gradient accumulated from several consumers, ...).
-PREP_FUSE = os.environ.get("AVEC_PREP_FUSE", "1") != "0"
+PREP_FUSE = True
 _PREP_READY = {"task": -1, "m": {}}
 
 
@@ -560,7 +562,7 @@ def linear(x, weight, bias, out_f32=True):
 # norm's launch also produces the next one's output (avec_layernorm_fwd2) and leaves it on its result tensor; FeedForwardFn picks it up when the tensor, the
 # parameters and eps are the ones it was made for.  Backward: the feed-forward module's LayerNorm backward also runs the closing norm's (avec_layernorm_bwd2) and
 # leaves dx1 under the address of the gradient it returns; LayerNormFn.backward takes it if that very tensor comes back from autograd (one consumer), else computes.
-LN_PAIR = os.environ.get("AVEC_LN_PAIR", "1") != "0"
+LN_PAIR = True
 _LN2_READY = {"task": -1, "m": {}}
 
 
@@ -751,7 +753,7 @@ def _attn_args(qkv, e, lens, len_div, mask, o, lse, B, H, T, d, D, q_full=0):
 # ONE product PE [2T-1][D] x W_all^T [D][L D] gives every block's E as a column slice, and in backward the L gradients dE_l accumulate in one [2T-1][L D] buffer that
 # takes ONE cast and ONE weight-gradient product when the last of them has arrived: 2 (L - 1) launches less per stage and pass.  Versioned by the arena's shadow
 # refresh counter (E follows the weights), per sequence length.
-POS_GROUP = os.environ.get("AVEC_POS_GROUP", "1") != "0"
+POS_GROUP = True
 _POS_CACHE = {}
 
 
@@ -1066,7 +1068,7 @@ class BNState:
         self.C = C
 
 
-RELU_BITMASK = os.environ.get("AVEC_RELU_BITMASK", "1") == "1"    # ResNet block ends: the backward pass reads a 1-bit ReLU mask instead of the saved block output (0: reads `out`)
+RELU_BITMASK = True    # ResNet block ends: the backward pass reads a 1-bit ReLU mask instead of the saved block output (0: reads `out`)
 def bn_finalize(bn, st, count, training):
     """bn: module with weight/bias/running_mean/running_var/num_batches_tracked/momentum/eps"""
     C = st.C
@@ -1120,7 +1122,7 @@ def _add_local_affine_grads(dstats, gw, gb, C, key):
         return dstats, False
     from . import peer
     px = peer.active()
-    if px is not None and dstats.is_cuda and dstats.is_contiguous() and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
+    if px is not None and dstats.is_cuda and dstats.is_contiguous() :
         return px.all_reduce_sum_fused(dstats, 1, 2 * C, None, key, dgamma=gw, dbeta=gb, C=C), True      # local affine gradients added inside the exchange kernel
     lib.bn_affine_grads(dstats.data_ptr(), gw.data_ptr(), gb.data_ptr(), C, rt.stream())
     return rt.all_reduce_small(dstats, key), True
@@ -1136,7 +1138,7 @@ def dw_pad_left(conv):
     assert kind == "same", "the fused convolution module supports 'same' and 'causal' padding, got %r" % (kind,)
     return K // 2
 
-CONVMOD_BN_FUSE = os.environ.get("AVEC_CONVMOD_BN_FUSE", "1") != "0"      # conformer convolution module: BatchNorm finalize straight from the depthwise kernel's partial sums
+CONVMOD_BN_FUSE = True      # conformer convolution module: BatchNorm finalize straight from the depthwise kernel's partial sums
 
 
 class ConvModuleFn(torch.autograd.Function):
@@ -1462,10 +1464,10 @@ def conv2d_fwd(x, weight, N, H, W, Cin, stride, stats=None):
     return y, OH, OW
 
 
-SLAB_CONV = os.environ.get("AVEC_NO_SLAB_CONV") is None
-SLAB_WGRAD128 = os.environ.get("AVEC_NO_SLAB_WGRAD128") is None
-SHORTCUT_SUBGRID = os.environ.get("AVEC_SHORTCUT_SUBGRID", "1") != "0"        # ResNet projection shortcuts: input gradient on the subsampled grid (res_cls0)
-GROUP_WGRAD128 = os.environ.get("AVEC_GROUP_WGRAD128", "1") != "0"          # the wide layers' weight gradients as one grouped launch at the end of the backward pass
+SLAB_CONV = True
+SLAB_WGRAD128 = True
+SHORTCUT_SUBGRID = True        # ResNet projection shortcuts: input gradient on the subsampled grid (res_cls0)
+GROUP_WGRAD128 = True          # the wide layers' weight gradients as one grouped launch at the end of the backward pass
 
 
 def _slab_conv(H, W, Cin, Cout, KH, KW, stride):
@@ -1485,7 +1487,7 @@ class BnbFuse:
 
 # BatchNorm-backward reductions inside the backward-data epilogues (ResNet stages 2-4).  Correct (tests/test_gpu_round3.py) but SLOWER in the step (25.32 vs 25.07 ms, same box):
 # the extra y / mask tile loads sit on the critical path of each workgroup's epilogue while the stand-alone reductions run at 0.5 of the HBM peak.  Opt-in.
-BNB_FUSE = os.environ.get("AVEC_BNB_FUSE", "0") == "1"
+BNB_FUSE = False
 
 
 def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None, dx_res_cls0=False):
@@ -1641,10 +1643,10 @@ class ResNetBlockFn(torch.autograd.Function):
         return (dx.view(N, H, W, Cin) if dx is not None else None), None, None, None, None
 
 
-STEM3D_DIRECT = os.environ.get("AVEC_STEM3D_DIRECT", "1") != "0"      # direct (no im2col) bf16 visual-stem kernels
-STEM3P_FUSED_WGRAD = os.environ.get("AVEC_STEM3P_FUSED", "1") != "0"  # ... and the weight gradient computed from the recomputed tiles in the same kernel (no dz tensor)
-STEM_GRAD_CLONE = os.environ.get("AVEC_STEM_GRAD_CLONE", "0") == "1"   # the stem's backward masks the incoming gradient IN PLACE (it is the first ResNet block's dx: 99 MB, nothing else reads it); 1 = work on a copy
-STEM3P = os.environ.get("AVEC_STEM3P", "1") != "0"                    # ... with the max pool inside the convolution kernel and the pre-pool tensor recomputed in backward (stem3p.hip)
+STEM3D_DIRECT = True      # direct (no im2col) bf16 visual-stem kernels
+STEM3P_FUSED_WGRAD = True  # ... and the weight gradient computed from the recomputed tiles in the same kernel (no dz tensor)
+STEM_GRAD_CLONE = False   # the stem's backward masks the incoming gradient IN PLACE (it is the first ResNet block's dx: 99 MB, nothing else reads it); 1 = work on a copy
+STEM3P = True                    # ... with the max pool inside the convolution kernel and the pre-pool tensor recomputed in backward (stem3p.hip)
 
 
 class VideoStemFn(torch.autograd.Function):

@@ -81,7 +81,7 @@ def sync_batchnorm():
 # conformer GEMMs of the two kinds could overlap instead of running back to back.  MEASURED (MI355X, B=32, hipGraph step): 46.3 ms with the
 # side stream against 43.8 ms without -- the two kernel streams fight for L2 / LDS and the fork/join edges cost more than the tail overlap
 # gains -- so it is OFF by default; AVEC_WGRAD_STREAM=1 enables it for experiments.
-_SIDE = {"streams": {}, "pending": set(), "enabled": os.environ.get("AVEC_WGRAD_STREAM", "0") == "1"}
+_SIDE = {"streams": {}, "pending": set(), "enabled": False}
 
 
 def wgrad_fork(*tensors):
@@ -145,7 +145,9 @@ def branch_stream():
 # BatchNorm statistic accumulators (64 replicas x 2C floats per layer, 2C per layer in backward) must start at zero; ~90 of them per step
 # would each cost a fill launch.  They are carved out of one buffer that a training step zeroes ONCE at its start (Model.train_step / the
 # captured graph body); allocations only move forward inside a step, so nothing handed out is reused before the next reset.  Outside a
-# training step (evaluation, direct op calls) the pool is never reset: once exhausted, plain torch.zeros takes over.
+# training step the pool is reset by eval_step only when it already exists (tensors returned by an earlier step that are views of it -- a captured step's
+# static losses -- are invalidated by the next train or eval call: Model._own_losses hands out copies); direct op calls never reset it: once exhausted, plain torch.zeros
+# takes over.
 _ZPOOL = {"buf": {}, "off": {}, "floats": 128 << 20}       # 512 MB of address space; only what a step used (its high-water mark: ~0.36 GB at the bench shape, mostly the skewed dS matrices of the attention backward) is re-zeroed
 
 
@@ -163,10 +165,13 @@ def zeros_scratch(n, device):
     return buf[off:off + n]
 
 
-def reset_zero_pool(device):
-    """start of a training step: every scratch buffer of the previous step is dead (same-stream order); re-zero what was handed out"""
+def reset_zero_pool(device, create=True):
+    """start of a training step: every scratch buffer of the previous step is dead (same-stream order); re-zero what was handed out.
+    create=False (evaluation): a process that never trained does not allocate the pool -- zeros_scratch() then hands out plain torch.zeros."""
     key = str(device)
     buf = _ZPOOL["buf"].get(key)
+    if buf is None and not create:
+        return
     if buf is None:
         buf = _ZPOOL["buf"][key] = torch.zeros(_ZPOOL["floats"], dtype=torch.float32, device=device)
         _ZPOOL["off"][key] = 0
@@ -634,7 +639,7 @@ def sync_bn_stats(stats, nrep, C, count, key=None):
     if stats.is_cuda:
         from . import peer
         px = peer.active()
-        if px is not None and nrep * 2 * C <= 2048 and os.environ.get("AVEC_PEER_FUSED", "1") != "0":
+        if px is not None and nrep * 2 * C <= 2048 :
             # few replicas: collapsed inside the exchange kernel (one launch).  The 64 replicas of the GEMM epilogues stay with the grid-wide collapse kernel: summed by
             # the exchange's single workgroup they cost more than the launch they save (measured: 22.45 vs 21.75 ms per step under a one-rank group)
             return px.all_reduce_sum_fused(stats, nrep, 2 * C, float(count), key)

@@ -33,7 +33,7 @@ extern "C" {
 
 #define AVEC_F32 0
 #define AVEC_BF16 1
-#define AVEC_ABI_VERSION 3      /* 2: avec_epilogue_t grew (bnb_*, res_cls0); avec_struct_size() handshake.  3: the row-resident module chains (avec_ffn_chain_*, avec_ln_gemm, avec_layernorm_*_sum) were removed */
+#define AVEC_ABI_VERSION 4      /* 2: avec_epilogue_t grew (bnb_*, res_cls0); avec_struct_size() handshake.  3: the row-resident module chains (avec_ffn_chain_*, avec_ln_gemm, avec_layernorm_*_sum) were removed.  4: avec_glu_dwconv_fwd_bn added */
 #define AVEC_STAT_REPLICAS 64   /* `stats` buffers handed to avec_gemm_nt hold this many [2N] replicas (block b adds to replica b % 64) */
 
 int avec_version(void);
