@@ -31,7 +31,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned c3_u32x4;
 
 __device__ __attribute__((aligned(64))) unsigned char c3_zero16[64];     // source of the zero border (LDS-DMA has no immediate fill)
 
-struct C3Args { const bf16* x; const bf16* w; bf16* y; const bf16* res; float* stats; int N, H, W, flip; };
+struct C3Args { const bf16* x; const bf16* w; bf16* y; const bf16* res; float* stats; int N, H, W, flip; const unsigned char* rmask; };      // rmask: one bit per element of res (added where set)
 
 __device__ __forceinline__ int c3_wslot(int n, int c) { return (c & ~15) | ((c & 15) ^ (n & 15)); }
 // slab: 256-byte rows of two pixels (16 chunks), chunk index XOR (pair index & 7): a ds_read_b128 lane group that reads 16 CONSECUTIVE pixels (any parity of the
@@ -327,6 +327,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C3Args a) {
 // requested in one go behind the barrier, the previous image's stores two per tap under taps 1-4, the eight residual pieces at tap 5.  Their residual pieces are
 // 16-byte fragments of 32 different 128-byte lines per instruction, and spread over the taps by hand (as in the forward kernel above) they cost more issue time than
 // the finer overlap gains: 189-210 us against 175 us in this form and 197 us with the slab by LDS-DMA (forward: 166 -> 149 us; profiles/r05_slab_phases.txt).
+__device__ __forceinline__ unsigned c3_mask2(unsigned b, int d) {      // bits 2 d, 2 d + 1 -> AND mask of the two bf16 halves of dword d
+  return ((0u - ((b >> (2 * d)) & 1u)) & 0xffffu) | ((0u - ((b >> (2 * d + 1)) & 1u)) & 0xffff0000u);
+}
 __global__ __launch_bounds__(512) void conv3x3_c64_res_kernel(C3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem; char* Sl = smem + C3_WBYTES;
@@ -475,6 +478,25 @@ __global__ __launch_bounds__(512) void conv3x3_c64_res_kernel(C3Args a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int k = 0; k < 2; ++k) resp[j][i][k] = *(const uint4*)(ro + (long long)pm[i] * 64 + j * 32 + k * 16 + chq);
+      if (a.rmask) {                         // the residual passes a ReLU mask (one byte per 8-channel piece): the masked gradient is never a tensor of its own
+        const unsigned char* mo = a.rmask + n * HW * 8;
+        unsigned mb[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) mb[j][i][k] = mo[((long long)pm[i] * 64 + j * 32 + k * 16 + chq) >> 3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const unsigned b = mb[j][i][k];
+              resp[j][i][k].x &= c3_mask2(b, 0); resp[j][i][k].y &= c3_mask2(b, 1); resp[j][i][k].z &= c3_mask2(b, 2); resp[j][i][k].w &= c3_mask2(b, 3);
+            }
+      }
     }
 #pragma unroll 1
     for (int tap = 5; tap < 9; ++tap) one_tap(tap);
@@ -1052,7 +1074,15 @@ extern "C" int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int K
   return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && H * W <= 512 && (H + 2) * (W + 1) + 1 <= C3_MAXPIX && H >= 1 && W >= 2;
 }
 
+static int conv3x3_c64_impl(const void* x, const void* w, void* y, const void* res, const unsigned char* rmask, float* stats, long long images, int H, int W, int flip, hipStream_t st);
 extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, float* stats, long long images, int H, int W, int flip, hipStream_t st) {
+  return conv3x3_c64_impl(x, w, y, res, nullptr, stats, images, H, W, flip, st);
+}
+extern "C" int avec_conv3x3_c64_res_masked(const void* x, const void* w, void* y, const void* res, const unsigned char* res_mask, long long images, int H, int W, int flip, hipStream_t st) {
+  AVEC_CHECK_ARG(res && res_mask, "conv3x3_c64_res_masked: null residual / mask");
+  return conv3x3_c64_impl(x, w, y, res, res_mask, nullptr, images, H, W, flip, st);
+}
+static int conv3x3_c64_impl(const void* x, const void* w, void* y, const void* res, const unsigned char* rmask, float* stats, long long images, int H, int W, int flip, hipStream_t st) {
   AVEC_CHECK_ARG(x && w && y && images > 0, "conv3x3_c64: null buffer");
   AVEC_CHECK_ARG(avec_conv3x3_c64_supported(H, W, 64, 64, 3, 3, 1), "conv3x3_c64: %dx%d images do not fit the slab", H, W);
   static bool attr_set = false;
@@ -1066,7 +1096,7 @@ extern "C" int avec_conv3x3_c64(const void* x, const void* w, void* y, const voi
     attr_set = true;
   }
   static const int wgs_env = 256;
-  C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip;
+  C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip; a.rmask = rmask;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
   avec_note_kernel("conv3x3_c64_kernel");
   // (statistics AND a residual in one launch would need 36 + 32 + 64 registers beside the accumulators: it spills, and a spilled register of an in-flight asm load is

@@ -1432,12 +1432,14 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
         else { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD, true>, lt)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD, true>), grid, dim3(256), lt, st, g); }
         return 0;
       }
+      if (g.e.res_mask) { avec_set_error("gemm_nt: res_mask needs the register-direct epilogue"); return -1; }
       avec_note_kernel("gemm_nt_conv_lean_kernel<%d,%d>", BN, mode);
       if (mode == MODE_CONV_FWD) { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_FWD>), grid, dim3(256), l2, st, g); }
       else { if (int r = want_lds(gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>, l2)) return r; hipLaunchKernelGGL((gemm_nt_conv_lean_kernel<BN, MODE_CONV_BWD>), grid, dim3(256), l2, st, g); }
       return 0;
     }
   }
+  if (g.e.res_mask) { avec_set_error("gemm_nt: res_mask needs the register-direct epilogue (no kernel with it takes this product)"); return -1; }
   if ((a16 || plain_any) && !f32src && use_glds) { if (mode == MODE_PLAIN) G(MODE_PLAIN); else if (mode == MODE_CONV_FWD) G(MODE_CONV_FWD); else G(MODE_CONV_BWD); }
 #undef G2
 #undef G3
@@ -1473,11 +1475,12 @@ static int launch_conv_shift(const GemmArgs& g_in, int mode, hipStream_t st) {
 #define ST(BM, BN, MODE) do { const size_t ring = (size_t)3 * BN * 64 + (size_t)2 * (BM + 64) * 64 + 512 + (BM / 64 - 1) * 2048; const size_t lds = ring; \
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN)); \
     avec_note_kernel("conv3x3_shift_kernel<%d,%d,%d,tr>", BM, BN, MODE); if (int r = want_lds(conv3x3_shift_kernel<BM, BN, MODE, true>, lds)) return r; hipLaunchKernelGGL((conv3x3_shift_kernel<BM, BN, MODE, true>), grid, dim3(256), lds, st, g); return 0; } while (0)
-  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && e256 > e128))) {
+  if (g.N >= 128 && (bm_env == 256 || (bm_env == 0 && e256 > e128) || (g.e.res_mask && tr_ok))) {
     if (tr_ok) { if (mode == MODE_CONV_FWD) ST(256, 128, MODE_CONV_FWD); else ST(256, 128, MODE_CONV_BWD); }
     if (mode == MODE_CONV_FWD) S(256, 128, MODE_CONV_FWD); else S(256, 128, MODE_CONV_BWD);
   }
 #undef ST
+  if (g.e.res_mask) { avec_set_error("gemm_nt: res_mask needs the register-direct epilogue (N >= 128, bf16 output and residual in 16-byte pieces)"); return -1; }
   if (g.N >= 128) { if (mode == MODE_CONV_FWD) S(128, 128, MODE_CONV_FWD); else S(128, 128, MODE_CONV_BWD); }
   if (mode == MODE_CONV_FWD) S(128, 64, MODE_CONV_FWD); else S(128, 64, MODE_CONV_BWD);
 #undef S
@@ -1528,7 +1531,9 @@ extern "C" int avec_gemm_nt(int dtype, const void* A, const avec_rows_t* a_rows,
   e.act = ep->act; e.drop_p = ep->drop_p; e.rng = (const unsigned long long*)ep->rng; e.stream = ep->rng_stream;
   e.res = ep->res; e.ldres = ep->ldres; e.alpha = ep->alpha; e.res_act = ep->res_act; e.dact_z = ep->dact_z; e.ldz = ep->ldz; e.dact = ep->dact;
   e.colsum = ep->colsum; e.stats = ep->stats;
-  e.bnb_y = ep->bnb_y; e.ldby = ep->ldby; e.bnb_ss = ep->bnb_ss; e.bnb_mask = ep->bnb_mask; e.res_cls0 = ep->res_cls0;
+  e.bnb_y = ep->bnb_y; e.ldby = ep->ldby; e.bnb_ss = ep->bnb_ss; e.bnb_mask = ep->bnb_mask; e.res_cls0 = ep->res_cls0; e.res_mask = ep->res_mask;
+  AVEC_CHECK_ARG(!e.res_mask || (dtype == AVEC_BF16 && !a_f32 && a_mode != AVEC_ROWS_PLAIN && e.res && e.res_act && !e.res_cls0 && e.ldres % 8 == 0),
+                 "gemm_nt: res_mask needs a bf16 convolution product with a bf16 residual whose rows are whole 8-element pieces");
   AVEC_CHECK_ARG(!e.res_cls0 || (g.perm2 && e.res), "gemm_nt: res_cls0 needs a bf16 stride-2 backward-data product that runs in parity-class order");
   AVEC_CHECK_ARG(!e.bnb_y || (e.stats && N % 4 == 0 && !(e.ldo & 3) && !(e.ldby & 3) && !(e.ldres & 3) && !(e.ldz & 3) && !(e.ldpre & 3) && (!e.bnb_mask || e.bnb_ss) && (e.bnb_mask || e.dact == 2 || e.dact == 0)),
                  "gemm_nt: the BatchNorm-backward fusion needs stats, N %% 4 == 0 and row strides that are multiples of 4");

@@ -144,7 +144,13 @@ struct Epi {
   float* stats;                    // += [N] sum, [N] sum of squares of v (BatchNorm batch statistics), AVEC_STAT_REPLICAS copies
   const void* bnb_y; long long ldby; const float* bnb_ss; int bnb_mask;      // BatchNorm-backward fusion (avec_hip.h): v = alpha*acc + res; mask; stats += (v, v*y)
   int res_cls0;                    // parity-class order: `res` has one row per class-0 pixel (class-local index), none for the other classes
+  const unsigned char* res_mask;   // one bit per element of `res` (bf16, register-direct epilogue): the residual is added where the bit is set
 };
+
+// bits 2 d, 2 d + 1 of `b` -> an AND mask for the two bf16 halves of dword d of an 8-element piece
+__device__ __forceinline__ unsigned mask2(unsigned b, int d) {
+  return ((0u - ((b >> (2 * d)) & 1u)) & 0xffffu) | ((0u - ((b >> (2 * d + 1)) & 1u)) & 0xffff0000u);
+}
 
 #ifndef AVEC_TN_BUILTIN_DMA
 #define AVEC_TN_BUILTIN_DMA 0
@@ -466,6 +472,17 @@ __device__ __forceinline__ void conv_epilogue_tr(const GemmArgs& g, f32x16 (&acc
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int k = 0; k < 2; ++k) rp[i][k] = *(const uint4*)(res + rrow[i] * e.ldres + cb + 16 * k);
+      if (e.res_mask) {                                            // (8 consecutive columns of a row = one byte of the bit mask)
+        unsigned mb[MT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) mb[i][k] = e.res_mask[(rrow[i] * e.ldres + cb + 16 * k) >> 3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { rp[i][k].x &= mask2(mb[i][k], 0); rp[i][k].y &= mask2(mb[i][k], 1); rp[i][k].z &= mask2(mb[i][k], 2); rp[i][k].w &= mask2(mb[i][k], 3); }
+      }
     }
     if (e.stats) {
 #pragma unroll

@@ -31,7 +31,7 @@ class Epilogue(ctypes.Structure):
                 ("dact_z", ctypes.c_void_p), ("ldz", ctypes.c_longlong), ("dact", ctypes.c_int),
                 ("colsum", ctypes.c_void_p), ("stats", ctypes.c_void_p),
                 ("bnb_y", ctypes.c_void_p), ("ldby", ctypes.c_longlong), ("bnb_ss", ctypes.c_void_p), ("bnb_mask", ctypes.c_int),
-                ("res_cls0", ctypes.c_int)]
+                ("res_cls0", ctypes.c_int), ("res_mask", ctypes.c_void_p)]
 
 
 class Attn(ctypes.Structure):

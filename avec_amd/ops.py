@@ -199,7 +199,7 @@ def gemm_nt_fp8(A, ent, out, M, N, K, *, bias=None, act=ACT_NONE, out_pre=None, 
 
 def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=None, bias=None, act=ACT_NONE, out_pre=None,
             drop_p=0.0, sid=0, res=None, res_act=False, alpha=1.0, dact_z=None, dact=0, colsum=None, stats=None, out_f32=False,
-            ldo=None, ldres=None, dtype=None, flops=None, bnb=None, res_cls0=False, abytes=None):
+            ldo=None, ldres=None, dtype=None, flops=None, bnb=None, res_cls0=False, abytes=None, res_mask=None):
     ep = Epilogue()
     ep.out, ep.ldo, ep.out_f32 = out.data_ptr(), (N if ldo is None else ldo), int(out_f32)
     if out_pre is not None:
@@ -210,6 +210,8 @@ def gemm_nt(A, W, out, M, N, K, *, rows=None, mode=ROWS_PLAIN, a_f32=False, ldw=
         ep.drop_p, ep.rng, ep.rng_stream = drop_p, rt.rng_state(out.device).data_ptr(), sid
     if res is not None:
         ep.res, ep.ldres, ep.res_act, ep.res_cls0 = res.data_ptr(), (N if ldres is None else ldres), int(res_act), int(res_cls0)
+        if res_mask is not None:
+            ep.res_mask = res_mask.data_ptr()
     ep.alpha = alpha
     if dact_z is not None:
         ep.dact_z, ep.ldz, ep.dact = dact_z.data_ptr(), N, dact
@@ -1490,8 +1492,9 @@ class BnbFuse:
 BNB_FUSE = False
 
 
-def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None, dx_res_cls0=False):
-    """dx_res_cls0: dx_res holds rows for the (even row, even column) input pixels only (stride-2 layers, bf16: include/avec_hip.h res_cls0)"""
+def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res=None, bnb=None, dx_res_cls0=False, dx_res_mask=None):
+    """dx_res_cls0: dx_res holds rows for the (even row, even column) input pixels only (stride-2 layers, bf16: include/avec_hip.h res_cls0)
+    dx_res_mask: one bit per element of dx_res (the ReLU mask written by avec_bn_apply_fwd_mask): dx = conv^T(dy) + (bit ? dx_res : 0) (see res_mask_ok)"""
     Cout, KH, KW = weight.shape[0], weight.shape[2], weight.shape[3]
     pad = (KH - 1) // 2
     M = N * OH * OW
@@ -1530,7 +1533,10 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     dx = empty((N * H * W, Cin), rt.act_dtype(), dy)
     if _slab_conv(H, W, Cin, Cout, KH, KW, stride):
         ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
-        lib.conv3x3_c64(dy.data_ptr(), sh.bwd.data_ptr(), dx.data_ptr(), _p(dx_res), None, N, H, W, 1, rt.stream())
+        if dx_res_mask is not None:
+            lib.conv3x3_c64_res_masked(dy.data_ptr(), sh.bwd.data_ptr(), dx.data_ptr(), dx_res.data_ptr(), dx_res_mask.data_ptr(), N, H, W, 1, rt.stream())
+        else:
+            lib.conv3x3_c64(dy.data_ptr(), sh.bwd.data_ptr(), dx.data_ptr(), _p(dx_res), None, N, H, W, 1, rt.stream())
         if ev is not None:
             KERNEL_TIMER.stop(ev, (2, 1), 2.0 * N * H * W * Cin * KH * KW * Cout, 2.0 * (2 * N * H * W * Cin + Cout * KH * KW * Cin + M * Cout))
         return dx
@@ -1538,11 +1544,21 @@ def conv2d_bwd(dy, x, weight, N, H, W, Cin, stride, OH, OW, need_dx=True, dx_res
     # over input pixels are structurally zero and are skipped by the parity-class kernel: they are not counted
     fuse = bnb if (bnb is not None and BNB_FUSE and rt.act_dtype() == torch.bfloat16 and Cin % 4 == 0) else None
     gemm_nt(dy, sh.bwd, dx, N * H * W, Cin, KH * KW * Cout, rows=rows_conv(H, W, Cout, KH, KW, stride, pad, OH, OW), mode=ROWS_CONV_BWD,
-            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, bnb=fuse, res_cls0=dx_res_cls0,
+            res=dx_res, res_act=True, flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, bnb=fuse, res_cls0=dx_res_cls0, res_mask=dx_res_mask,
             abytes=2.0 * (N * H * W * Cin * (2 if dx_res is not None else 1) + Cout * KH * KW * Cin + M * Cout))
     if fuse is not None:
         fuse.done = True
     return dx
+
+
+RES_MASK = True      # identity-residual ResNet blocks: the block-output gradient enters the first convolution's backward-data epilogue through the 1-bit ReLU mask (no masked copy of it is written)
+
+
+def res_mask_ok(H, W, Cin, Cout, stride):
+    """can conv2d_bwd add a bit-masked residual for this 3x3 layer?  The stage-1 slab kernel, or the shifted-window kernel with its register-direct epilogue (csrc/gemm.hip)"""
+    if rt.act_dtype() != torch.bfloat16 or stride != 1 or Cin != Cout:
+        return False
+    return _slab_conv(H, W, Cin, Cout, 3, 3, 1) or (Cin >= 128 and Cin % 32 == 0 and W <= 31)
 
 
 class ResNetBlockFn(torch.autograd.Function):
@@ -1612,7 +1628,11 @@ class ResNetBlockFn(torch.autograd.Function):
         pre2 = ResNetBlockFn._READY.pop(dout.data_ptr(), None) if ctx.chain else None      # the consumer block already masked dout and reduced it against y2
         if pre2 is not None and pre2.y is not y2:
             raise RuntimeError("ResNetBlock backward: a fused BatchNorm-backward request does not belong to this block (the block output has another consumer?)")
-        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=True, pre=pre2, mask=ctx.relu_mask)
+        # the gradient that passed the block's final ReLU is needed twice more (second BatchNorm's backward above all, then as the residual branch's gradient): with the bit
+        # mask at hand nobody needs it as a tensor -- the consumers below apply the mask themselves
+        lazy_dres = (RES_MASK and not BNB_FUSE and ctx.relu_mask is not None and pre2 is None and
+                     (has_proj or (conv1.weight.shape[2] == 3 and res_mask_ok(H, W, Cin, Cout, stride) and not KERNEL_TIMER.enabled)))
+        dy2, dres = bn_backward(bn2, st2, c2, Mo, dout, y2, out, ACT_RELU, Mo, want_dres=not lazy_dres, pre=pre2, mask=ctx.relu_mask)
         f1 = BnbFuse(y1, st1.ss, None, Cout)        # BatchNorm 1 + ReLU: the mask comes from the pre-activation itself
         da1 = conv2d_bwd(dy2, a1, conv2.weight, N, OH, OW, Cout, 1, OH, OW, bnb=f1)
         dy1, _ = bn_backward(bn1, st1, c1, Mo, da1, y1, None, ACT_RELU, Mo, pre=f1 if f1.done else None)      # no residual before this ReLU: the mask is recomputed from y1 (one tensor less to read)
@@ -1621,7 +1641,10 @@ class ResNetBlockFn(torch.autograd.Function):
         fx = BnbFuse(prev[0], prev[2].ss, prev[1], prev[3]) if prev is not None else None
         if has_proj:
             convr, bnr = blk.residual[0], blk.residual[1]
-            dyr, _ = bn_backward(bnr, str_, cr, Mo, dres, yr, None, ACT_NONE, Mo)
+            if lazy_dres:
+                dyr, _ = bn_backward(bnr, str_, cr, Mo, dout, yr, None, ACT_NONE, Mo, mask=ctx.relu_mask)      # (mask variant: d = bit ? dout : 0, no activation of its own)
+            else:
+                dyr, _ = bn_backward(bnr, str_, cr, Mo, dres, yr, None, ACT_NONE, Mo)
             kr = convr.weight.shape[2]
             if (SHORTCUT_SUBGRID and need_dx and stride == 2 and kr == 1 and rt.act_dtype() == torch.bfloat16 and Cin % 64 == 0 and Cout % 64 == 0
                     and conv1.weight.shape[2] == 3 and not _slab_conv(H, W, Cin, Cout, 3, 3, stride)):
@@ -1635,7 +1658,10 @@ class ResNetBlockFn(torch.autograd.Function):
                 dx = conv2d_bwd(dyr, x, convr.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx)
                 dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dx, bnb=fx)
         else:
-            dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres, bnb=fx)
+            if lazy_dres:
+                dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dout, dx_res_mask=ctx.relu_mask, bnb=fx)
+            else:
+                dx = conv2d_bwd(dy1, x, conv1.weight, N, H, W, Cin, stride, OH, OW, need_dx=need_dx, dx_res=dres, bnb=fx)
         if fx is not None and fx.done:
             if len(ResNetBlockFn._READY) > 64:
                 ResNetBlockFn._READY.clear()

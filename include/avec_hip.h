@@ -82,6 +82,11 @@ typedef struct avec_epilogue {
    * 1x1 / stride-2 shortcut convolution sends to the same input (nnet/blocks.py: ResNetBlock.residual), computed as a plain product on the subsampled grid --
    * instead of a full-size, three-quarters-zero tensor.  Rejected (< 0) when the launch cannot run in parity-class order. */
   int res_cls0;
+  /* ReLU mask on the RESIDUAL operand (round 6): one bit per element of `res` (bit e of byte (row * ldres + col) / 8 = column col + e, the layout avec_bn_apply_fwd_mask
+   * writes): out = alpha * v + (bit ? res : 0).  The backward-data product of a ResNetBlock's first convolution adds the block-output gradient that passed the final ReLU
+   * (nnet/blocks.py:88-91) -- with this the masked gradient is never written out as a tensor of its own.  bf16 residual, register-direct epilogue kernels only (an error
+   * otherwise). */
+  const unsigned char* res_mask;
 } avec_epilogue_t;
 
 /* C[m][n] = epi(sum_k A[m][k] W[n][k]).  Replaces aten::addmm/mm of layers.Linear.forward (nnet/layers.py:64-76),
@@ -358,6 +363,8 @@ int avec_stem_pool_bwd(int dtype, const void* dpool, const unsigned char* idx, c
  * 72 KB of LDS ((H+2)(W+2) <= 576, even): weights stay in LDS, every input byte crosses L2 -> LDS once.  bf16 only. */
 int avec_conv3x3_c64_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride);
 int avec_conv3x3_c64(const void* x, const void* w, void* y, const void* res, float* stats, long long images, int H, int W, int flip, hipStream_t stream);
+/* the same with a residual whose ReLU mask (one bit per element, as avec_epilogue_t.res_mask) is applied while it is added: y = conv(x) + (bit ? res : 0) */
+int avec_conv3x3_c64_res_masked(const void* x, const void* w, void* y, const void* res, const unsigned char* res_mask, long long images, int H, int W, int flip, hipStream_t stream);
 /* weight gradient of the same layers (what avec_gemm_tn with ROWS_CONV_FWD computes): dw fp32 [64][9][64] (row stride 576) += sum over images / pixels of
  * dy[p][co] * x[p + tap - 1][ci]; x, dy NHWC bf16.  Needs avec_conv3x3_c64_supported and H * (W + 1) <= 512. */
 int avec_wgrad3x3_c64(const void* x, const void* dy, float* dw, long long images, int H, int W, hipStream_t stream);

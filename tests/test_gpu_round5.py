@@ -214,3 +214,39 @@ def test_plain_product_register_direct_epilogue(tmp_path):
     assert set(res["tr"]) == set(res["staged"])
     for k in res["tr"]:
         assert torch.equal(res["tr"][k], res["staged"][k]), (k, float((res["tr"][k] - res["staged"][k]).abs().max()))
+
+
+@pytest.mark.parametrize("Nimg,H,C", [(300, 11, 128), (700, 6, 256), (900, 3, 512), (40, 22, 64)])
+def test_backward_data_adds_bit_masked_residual(Nimg, H, C):
+    """avec_epilogue_t.res_mask / avec_conv3x3_c64_res_masked (round 6): dx = conv^T(dy) + (bit ? res : 0) with the 1-bit ReLU mask of avec_bn_apply_fwd_mask -- bit-identical to
+    the same launch fed the residual masked beforehand (the masked copy the BatchNorm backward used to write), on the shifted-window kernel (stages 2-4) and the stage-1 slab kernel"""
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import lib, ROWS_CONV_BWD
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d, adt = torch.device("cuda:0"), torch.bfloat16
+        g = torch.Generator().manual_seed(Nimg + H)
+        M = Nimg * H * H
+        dy = torch.randn(M, C, generator=g).to(adt).to(d)
+        Wb = (torch.randn(C, 9 * C, generator=g) / (3 * C ** 0.5)).to(adt).to(d)
+        res = torch.randn(M, C, generator=g).to(adt).to(d)
+        bits = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).to(d)
+        keep = ((bits.view(-1, 1) >> torch.arange(8, device=d, dtype=torch.uint8)) & 1).view(M, C).bool()
+        res_m = torch.where(keep, res, torch.zeros_like(res))
+        a, b = torch.full((M, C), float("nan"), device=d, dtype=adt), torch.full((M, C), float("nan"), device=d, dtype=adt)
+        if C == 64:
+            lib.conv3x3_c64_res_masked(dy.data_ptr(), Wb.data_ptr(), a.data_ptr(), res.data_ptr(), bits.data_ptr(), Nimg, H, H, 1, torch.cuda.current_stream().cuda_stream)
+            lib.conv3x3_c64(dy.data_ptr(), Wb.data_ptr(), b.data_ptr(), res_m.data_ptr(), None, Nimg, H, H, 1, torch.cuda.current_stream().cuda_stream)
+        else:
+            rows = ops.rows_conv(H, H, C, 3, 3, 1, 1, H, H)
+            ops.gemm_nt(dy, Wb, a, M, C, 9 * C, rows=rows, mode=ROWS_CONV_BWD, res=res, res_act=True, res_mask=bits)
+            k1 = lib.raw("avec_last_kernel")().decode()
+            assert k1.endswith(",tr>"), k1
+            ops.gemm_nt(dy, Wb, b, M, C, 9 * C, rows=rows, mode=ROWS_CONV_BWD, res=res_m, res_act=True)
+        torch.cuda.synchronize()
+        assert not torch.isnan(a.float()).any()
+        assert torch.equal(a, b)
+        assert not torch.equal(a, torch.zeros_like(a))
+    finally:
+        avec_amd.set_compute_dtype("f32")
