@@ -1098,7 +1098,7 @@ static int conv3x3_c64_impl(const void* x, const void* w, void* y, const void* r
   static const int wgs_env = 256;
   C3Args a; a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.res = (const bf16*)res; a.stats = stats; a.N = (int)images; a.H = H; a.W = W; a.flip = flip; a.rmask = rmask;
   const int grid = (int)(images < wgs_env ? images : wgs_env);
-  avec_note_kernel("conv3x3_c64_kernel");
+  avec_note_kernel(stats ? "conv3x3_c64_kernel<true,false>" : res ? "conv3x3_c64_res_kernel" : "conv3x3_c64_kernel<false,false>");
   // (statistics AND a residual in one launch would need 36 + 32 + 64 registers beside the accumulators: it spills, and a spilled register of an in-flight asm load is
   // wrong code -- no caller needs the pair: forward launches carry statistics, backward-data launches the residual)
   AVEC_CHECK_ARG(!(stats && res), "conv3x3_c64: statistics and a residual in the same launch are not supported");

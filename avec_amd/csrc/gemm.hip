@@ -1405,7 +1405,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
           if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2, true>, lt)) return r;
           hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2, true>), grid, dim3(256), lt, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
         }
-        avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2>", BM, BN);
+        avec_note_kernel("gemm_nt_plain_kernel<%d,%d,2,false>", BM, BN);
         if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 2>, l2s)) return r;
         hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 2>), grid, dim3(256), l2s, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
       }
@@ -1416,7 +1416,7 @@ static int launch_nt_mode(const GemmArgs& g_in, int mode, int src_f32, hipStream
         if (int r = want_lds(gemm_nt_plain_kernel<BM, BN, 4, true>, lt)) return r;
         hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN, 4, true>), grid, dim3(256), lt, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
       }
-      avec_note_kernel("gemm_nt_plain_kernel<%d,%d,4>", BM, BN);
+      avec_note_kernel("gemm_nt_plain_kernel<%d,%d,4,false>", BM, BN);
       if (int r = want_lds(gemm_nt_plain_kernel<BM, BN>, l2)) return r;
       hipLaunchKernelGGL((gemm_nt_plain_kernel<BM, BN>), grid, dim3(256), l2, st, g.a.ptr, g.W, g.a.ld, g.ldw, g.M, g.N, g.K, g.ktail, g); return 0;
     }

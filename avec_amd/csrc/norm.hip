@@ -612,7 +612,10 @@ static inline unsigned bn8_blocks(long long n8, int C, unsigned cap) {
   return (unsigned)nb;
 }
 constexpr int BN8_U = 2;        // chunks in flight per thread in the element-wise passes (3 and 4: no gain)
-constexpr int BN8_UR = 1;       // ... in the reduction pass (2 measured 4-6 % slower there)
+#ifndef AVEC_BN8_UR
+#define AVEC_BN8_UR 1
+#endif
+constexpr int BN8_UR = AVEC_BN8_UR;       // ... in the reduction pass (2 measured 4-6 % slower there)
 constexpr unsigned BN8_CAP_FWD = 8192, BN8_CAP_BWD = 3072;      // grid caps: the 3-operand backward pass likes fewer, longer-running blocks (115200 x 256: 41.5 -> 36.7 us,
                                                                 // 28800 x 512: 28.0 -> 21.9 us), the forward pass the opposite (32.9 vs 33.9 us); tools/bench_bn.py
 

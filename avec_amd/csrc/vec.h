@@ -142,7 +142,10 @@ __device__ __forceinline__ void colreduce8_atomic(float (&part)[NV][8], float* c
   }
 }
 static inline bool col8_ok(int C) { return C % 8 == 0 && C <= 2048; }
-static inline long long col8_cap() { return 1024; }      /* re-swept at the end of round 3 (tools/bench_bn.py): 1024 beats 2048 on every ResNet stage but the first (equal there) */
+#ifndef AVEC_COL8_CAP
+#define AVEC_COL8_CAP 1024
+#endif
+static inline long long col8_cap() { return AVEC_COL8_CAP; }      /* re-swept at the end of round 3 (tools/bench_bn.py): 1024 beats 2048 on every ResNet stage but the first (equal there) */
 static inline unsigned col8_blocks(long long M, int C) { const int R = 256 / (C / 8); long long nb = (M + R - 1) / R; if (nb > col8_cap()) nb = col8_cap(); return (unsigned)nb; }
 // grid size + workspace of a flat 8-wide launch (finish with col_finalize(ws, 1, nb, NV, C, dst, C, st)); without a workspace the
 // block count is kept low (every block issues NV*C atomics)

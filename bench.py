@@ -159,8 +159,8 @@ def rows_from_graph_trace(roof, peak):
         r["timing"] = fname
         r["avg_us"] = round(us, 2)
         r["ms_per_step"] = round(r["launches_per_step"] * us / 1e3, 3)
-        r["tflops"] = round(r["alg_gflop_per_launch"] / us / 1e3, 1)
-        r["frac"] = round(r["alg_gflop_per_launch"] / us / 1e3 / peak, 4)
+        r["tflops"] = round(r["alg_gflop_per_launch"] / us * 1e3, 1)            # GFLOP / us = PFLOP/s
+        r["frac"] = round(r["alg_gflop_per_launch"] / us * 1e3 / peak, 4)
     top = max(roof["rows"], key=lambda r: r["ms_per_step"])
     roof.update({"kernel": top["kernel"], "achieved": top["tflops"], "frac": round(top["tflops"] / peak, 5), "launches": top["launches_per_step"],
                  "avg_launch_ms": round(top["avg_us"] / 1e3, 5), "alg_gflop_per_launch": top["alg_gflop_per_launch"], "alg_bytes_per_launch": top["alg_bytes_per_launch"]})
