@@ -170,9 +170,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 // Both halves of the backward pass in ONE launch (stride 1: every conformer block but the two stage boundaries): the workgroup of the weight-gradient kernel also
 // stages the dc rows its 32 frames can see (K - 1 rows of halo, fp32, zero outside the sequence) and produces du for those frames -- one launch, one pass over u and dc
 // instead of two (the input-gradient kernel re-read K dc rows per element from L2).  LDS: (31 + K) x 128 floats twice.
+// BatchNorm(+Swish) backward folded into the staging pass (round 6): with bnb.c set, `dc` is the gradient of the BatchNorm + Swish OUTPUT and the rows staged in LDS are
+//   dc = gamma rstd (d - mean(d) - xhat mean(d xhat)),  d = da * swish'(scale c + shift)          (avec_bn_bwd_apply's arithmetic, act = Swish)
+// from the reduced sums `dstats` -- the apply pass and its tensor disappear from the conformer block's chain; workgroup (0, 0) adds dgamma / dbeta.
+struct DwBnb { const void* c; const float* ss; const float* gamma; const float* dstats; float inv_n; float* dgamma; float* dbeta; };
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_fused_kernel(const T* __restrict__ dc, const T* __restrict__ u, const float* __restrict__ w, T* __restrict__ du, float* dw, float* dbias,
-                                                                   int B, int Tn, int C, int K, int padl, int nchunks, ColWs ws) {
+                                                                   int B, int Tn, int C, int K, int padl, int nchunks, ColWs ws, DwBnb bnb = DwBnb{nullptr}) {
   extern __shared__ __attribute__((aligned(16))) float gs[];
   const int NR = DW_TT - 1 + K;
   float* const ds = gs + NR * 128;
@@ -181,12 +185,29 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_fused_kernel(const T* __re
   stage_glu<T>(gs, u, b, Tn, C, col, t0 - padl, nto - 1 + K);
   {                                                            // dc rows of frames t0 + padl - (K - 1) + j, j < nto - 1 + K
     const int f0 = t0 + padl - (K - 1), nrows = nto - 1 + K, cc = col < C ? col : 0;
+    float bA[4], bM1[4], bM2[4], bMu[4], bRs[4], bSc[4], bSh[4];
+    if (bnb.c) {
+      float g4[4], s1[4], s2[4];
+      ld4<float>(bnb.ss + cc, bSc); ld4<float>(bnb.ss + C + cc, bSh); ld4<float>(bnb.ss + 2 * C + cc, bMu); ld4<float>(bnb.ss + 3 * C + cc, bRs);
+      ld4<float>(bnb.gamma + cc, g4); ld4<float>(bnb.dstats + cc, s1); ld4<float>(bnb.dstats + C + cc, s2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bA[e] = g4[e] * bRs[e]; bM1[e] = s1[e] * bnb.inv_n; bM2[e] = s2[e] * bnb.inv_n; }
+      if (blockIdx.y == 0 && ty == 0 && col < C && bnb.dgamma) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(bnb.dgamma + col + e, s2[e]); atomicAdd(bnb.dbeta + col + e, s1[e]); }
+      }
+    }
     for (int r0 = ty; r0 < nrows; r0 += 48) {
       float d[6][4];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const int r = r0 + 8 * q, f = f0 + r; const bool ok = r < nrows && col < C && f >= 0 && f < Tn;
         ld4<T>(dc + ((long long)b * Tn + (ok ? f : 0)) * C + cc, d[q]);
+        if (bnb.c) {
+          float cv[4]; ld4<T>((const T*)bnb.c + ((long long)b * Tn + (ok ? f : 0)) * C + cc, cv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float dd = d[q][e] * dswishf_(cv[e] * bSc[e] + bSh[e]); d[q][e] = bA[e] * (dd - bM1[e] - (cv[e] - bMu[e]) * bRs[e] * bM2[e]); }
+        }
         if (!ok) d[q][0] = d[q][1] = d[q][2] = d[q][3] = 0.f;
       }
 #pragma unroll
@@ -318,6 +339,28 @@ extern "C" int avec_glu_dwconv_fwd_bn(int dtype, const void* u, const float* w, 
     return 0;
   }
   return avec_bn_finalize(stats, 1, nullptr, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, ss, C, 1, st);
+}
+// avec_bn_bwd_apply (act = Swish, local batch statistics over B * T rows, dstats = the reduced (sum d, sum d xhat) of avec_bn_bwd_reduce) + avec_dwconv_glu_bwd in ONE launch
+// (stride 1): da = gradient of the BatchNorm + Swish output, c = the BatchNorm input (= the depthwise convolution's output); dgamma / dbeta += dstats.
+extern "C" int avec_dwconv_glu_bwd_bn(int dtype, const void* da, const void* c, const float* ss, const float* gamma, const float* dstats, float count, const void* u, const float* w,
+                                      void* du, float* dw, float* dbias, float* dgamma, float* dbeta, int B, int T_, int C, int K, int pad_left, hipStream_t st) {
+  AVEC_CHECK_ARG(da && c && ss && gamma && dstats && count > 0.f && u && w && du && dw && B > 0 && T_ > 0 && C > 0 && C % 4 == 0 && K > 0 && K <= KMAX && pad_left >= 0 && pad_left < K,
+                 "dwconv_glu_bwd_bn: bad arguments");
+  const int nchunks = (T_ + DW_TT - 1) / DW_TT;
+  dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * nchunks)); ColWs ws = col_ws_if(grid, KMAX + 1, C, st);
+  size_t l2 = (size_t)2 * (DW_TT - 1 + K) * 128 * sizeof(float);
+  if (l2 < (size_t)4 * (KMAX + 1) * 128 * sizeof(float)) l2 = (size_t)4 * (KMAX + 1) * 128 * sizeof(float);
+  AVEC_CHECK_ARG(l2 <= 64 * 1024, "dwconv_glu_bwd_bn: kernel size %d too large", K);
+  DwBnb bnb{c, ss, gamma, dstats, 1.f / count, dgamma, dbeta};
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_glu_bwd_fused_kernel<T>, grid, dim3(256), l2, st, (const T*)da, (const T*)u, w, (T*)du, dw, dbias, B, T_, C, K, pad_left, nchunks, ws, bnb));
+  AVEC_LAUNCH_CHECK();
+  if (ws.partial) {
+    float* dst[KMAX + 1];
+    for (int k = 0; k < KMAX; ++k) dst[k] = (k < K) ? dw + (long long)k * C : nullptr;
+    dst[KMAX] = dbias;
+    return col_finalize(ws, grid.x, grid.y, KMAX + 1, 128, dst, C, st);
+  }
+  return 0;
 }
 extern "C" int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
                                    int B, int T_, int C, int K, int stride, int pad_left, hipStream_t st) {

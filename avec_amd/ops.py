@@ -1194,13 +1194,21 @@ class ConvModuleFn(torch.autograd.Function):
             dacc = grad_prep(dy, Mo, Dp, drop_p=drop_p, sid=sid)
         linear_bwd_weight(dacc, a, pw2.weight, Mo, bias=pw2.bias)
         da = linear_bwd_input(dacc, pw2.weight, Mo, out_f32=False)
-        if use_batch:
-            dc, _ = bn_backward(bn, st, cptr, Mo, da, c, None, ACT_SWISH, Mo)
-        else:   # eval / frozen statistics: dc = da * swish'(pre) * scale  -> reuse the apply kernel with zero batch terms
-            dc = _bn_eval_backward(bn, st, da, c, ACT_SWISH, Mo)
         du = empty((M, 2 * Dp), adt, dy)
-        lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), dw.weight.data_ptr(), du.data_ptr(), grad_of(dw.weight).data_ptr(),
-                           None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
+        if use_batch and CONVMOD_BN_FUSE and stride == 1 and not rt.sync_batchnorm():
+            # local batch statistics, stride 1: the reduction pass, then the BatchNorm-backward arithmetic inside the depthwise kernel's staging pass (no apply launch, no dc tensor)
+            dstats = rt.zeros_scratch(2 * Dp, da.device)
+            lib.bn_bwd_reduce(rt.dt(), da.data_ptr(), c.data_ptr(), None, st.ss.data_ptr(), ACT_SWISH, dstats.data_ptr(), Mo, Dp, rt.stream())
+            lib.dwconv_glu_bwd_bn(rt.dt(), da.data_ptr(), c.data_ptr(), st.ss.data_ptr(), bn.weight.data_ptr(), dstats.data_ptr(), float(Mo), u.data_ptr(), dw.weight.data_ptr(),
+                                  du.data_ptr(), grad_of(dw.weight).data_ptr(), None if dw.bias is None else grad_of(dw.bias).data_ptr(),
+                                  grad_of(bn.weight).data_ptr(), grad_of(bn.bias).data_ptr(), B, T, Dp, K, dw_pad_left(dw), rt.stream())
+        else:
+            if use_batch:
+                dc, _ = bn_backward(bn, st, cptr, Mo, da, c, None, ACT_SWISH, Mo)
+            else:   # eval / frozen statistics: dc = da * swish'(pre) * scale  -> reuse the apply kernel with zero batch terms
+                dc = _bn_eval_backward(bn, st, da, c, ACT_SWISH, Mo)
+            lib.dwconv_glu_bwd(rt.dt(), dc.data_ptr(), u.data_ptr(), dw.weight.data_ptr(), du.data_ptr(), grad_of(dw.weight).data_ptr(),
+                               None if dw.bias is None else grad_of(dw.bias).data_ptr(), B, T, Dp, K, stride, dw_pad_left(dw), rt.stream())
         linear_bwd_weight(du, h, pw1.weight, M, bias=pw1.bias)
         dh = linear_bwd_input(du, pw1.weight, M, out_f32=False)
         if res_conv is None:

@@ -279,6 +279,10 @@ int avec_glu_dwconv_fwd_bn(int dtype, const void* u, const float* w, const float
                            float* ss, hipStream_t stream);
 int avec_dwconv_glu_bwd(int dtype, const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias,
                         int B, int T, int C, int K, int stride, int pad_left, hipStream_t stream);
+/* avec_bn_bwd_apply (act = Swish, local batch statistics: count = B * T rows, dstats = the (sum d, sum d * xhat) of avec_bn_bwd_reduce) folded into avec_dwconv_glu_bwd's
+ * staging pass (stride 1): da = gradient of the BatchNorm + Swish output, c = the BatchNorm input; dgamma / dbeta += dstats.  One launch and one tensor less in the block's chain. */
+int avec_dwconv_glu_bwd_bn(int dtype, const void* da, const void* c, const float* ss, const float* gamma, const float* dstats, float count, const void* u, const float* w,
+                           void* du, float* dw, float* dbias, float* dgamma, float* dbeta, int B, int T, int C, int K, int pad_left, hipStream_t stream);
 
 /* ---- attention (avec_amd/csrc/attention.hip) ------------------------------------------------ */
 typedef struct avec_attn {
