@@ -52,7 +52,8 @@ __device__ __forceinline__ void conv_s2_body(const GemmArgs& g, char* smem, cons
   // ---- DMA plan.  Window row wr <-> coarse pixel pw = m0 - HALO + wr (forward) / m0 + wr (backward), clamped into [0, P).  Pass i: row 64 i + tid / 4, physical slot tid % 4
   // carrying logical chunk slot ^ swz(row); the 16-row piece: row 64 NAF + (16 wave + lane) / 4, slot lane % 4.
   unsigned aoff[NAF + 1];
-  const unsigned amax = (unsigned)(((FWD ? (long long)(P / (unsigned)(OH * OW)) * H * Wd : (long long)P) * C - 8) * 2);       // last 16-byte piece of the source tensor
+  const unsigned amax = (unsigned)(((FWD ? (long long)(P / (unsigned)(OH * OW)) * H * Wd : (long long)P) * C - C + 24) * 2);  // last 16-byte piece of chunk 0 of the LAST pixel: the chunk
+                                                                               // step (cc 64 bytes) is added to the base pointer after this clamp, so the clamp must leave room for it
   auto plan = [&](const int wr, const int slot) -> unsigned {
     int pws = (int)m0 + wr - (FWD ? S2_HALO : 0); pws = pws < 0 ? 0 : pws;
     const unsigned pw = (unsigned)pws >= P ? P - 1 : (unsigned)pws;

@@ -197,6 +197,43 @@ print("OK")
 ''' % ROOT
 
 
+@pytest.mark.parametrize("Nimg,H,Cin,Cout", [(4, 7, 64, 64), (2, 7, 128, 64), (3, 5, 256, 128)])
+def test_stride2_conv_reads_stay_inside_the_input(Nimg, H, Cin, Cout):
+    """csrc/conv_s2.hip gathers the four parity-class windows by LDS-DMA with clamped byte offsets; the chunk step (64 bytes per 32 channels) is added to the base pointer AFTER
+    the clamp, so the clamp must stop C - 32 channels short of the end (round 6: it did not -- a read of up to 2 C - 64 bytes past the tensor, harmless in a step where the next
+    allocation follows, an intermittent memory fault for a small tensor at the end of a mapping).  The input sits at the very END of its own allocator segment here (odd
+    H: the class (1,1) window of the last image row is the one that used to run over), the output must match torch, and the process must survive."""
+    import torch.nn.functional as F
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import lib, ROWS_CONV_FWD
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        d, adt = torch.device("cuda:0"), torch.bfloat16
+        g = torch.Generator().manual_seed(Nimg + H + Cin)
+        x = torch.randn(Nimg, H, H, Cin, generator=g).to(adt)
+        Wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(adt)
+        OH = (H - 1) // 2 + 1
+        M = Nimg * OH * OH
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), Wt.float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+        W = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+        torch.cuda.empty_cache()
+        seg = torch.empty(24 << 20, dtype=torch.uint8, device=d)              # > 10 MB: the caching allocator maps a segment of exactly this size for it
+        n = x.numel()
+        xd = seg[seg.numel() - 2 * n:].view(adt).view(Nimg, H, H, Cin)
+        xd.copy_(x)
+        y = torch.full((M, Cout), float("nan"), device=d, dtype=adt)
+        for _ in range(20):
+            ops.gemm_nt(xd, W, y, M, Cout, 9 * Cin, rows=ops.rows_conv(H, H, Cin, 3, 3, 2, 1, OH, OH), mode=ROWS_CONV_FWD)
+        name = lib.raw("avec_last_kernel")()
+        name = name if isinstance(name, str) else name.decode()
+        torch.cuda.synchronize()
+        assert "conv3x3_s2_fwd" in name, name
+        assert float((y.float().cpu() - ref).norm() / ref.norm()) < 4e-3
+    finally:
+        avec_amd.set_compute_dtype("bf16")
+
+
 def test_plain_product_register_direct_epilogue(tmp_path):
     """gemm_nt_plain_kernel<64,64,*,tr> (transposed product + plain_epilogue_tr: the conformer's Linear / pointwise-convolution launches, nnet/layers.py:31-60) against
     fp32 math on the same bf16 operands for every fused epilogue it takes (bias, Swish / ReLU, pre-activation copy, dropout, act'(z), alpha, fp32 and bf16 residual,
