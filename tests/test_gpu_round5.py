@@ -231,7 +231,65 @@ def test_stride2_conv_reads_stay_inside_the_input(Nimg, H, Cin, Cout):
         assert "conv3x3_s2_fwd" in name, name
         assert float((y.float().cpu() - ref).norm() / ref.norm()) < 4e-3
     finally:
-        avec_amd.set_compute_dtype("bf16")
+        avec_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("where", ["segment start", "segment end"])
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,stride", [(4, 7, 64, 64, 1), (3, 6, 128, 128, 1), (40, 11, 128, 128, 1), (5, 3, 512, 512, 1), (4, 7, 64, 128, 2), (6, 11, 128, 256, 2), (9, 6, 256, 512, 2)])
+def test_conv_fast_paths_read_only_their_operands(Nimg, H, Cin, Cout, stride, where):
+    """the LDS-DMA window / gather kernels of the 3x3 convolutions (csrc/gemm.hip shifted windows, csrc/conv_s2.hip parity classes) address their A operand with clamped
+    offsets: with the operand at the very START or the very END of its own allocator segment (nothing mapped next to it on that side) forward and backward-data must
+    neither fault nor change their results"""
+    import torch.nn.functional as F
+    import avec_amd
+    from avec_amd import ops
+    from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
+    avec_amd.set_compute_dtype("bf16")
+    try:
+        _operands_at_segment_edges(Nimg, H, Cin, Cout, stride, where)
+    finally:
+        avec_amd.set_compute_dtype("f32")
+
+
+def _operands_at_segment_edges(Nimg, H, Cin, Cout, stride, where):
+    import torch.nn.functional as F
+    from avec_amd import ops
+    from avec_amd.lib import ROWS_CONV_FWD, ROWS_CONV_BWD
+    d, adt = torch.device("cuda:0"), torch.bfloat16
+    g = torch.Generator().manual_seed(Nimg * 7 + H + Cin + stride)
+    x = torch.randn(Nimg, H, H, Cin, generator=g).to(adt)
+    Wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(adt)
+    OH = (H - 1) // stride + 1
+    M, MI = Nimg * OH * OH, Nimg * H * H
+    dy = torch.randn(M, Cout, generator=g).to(adt)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, Wt.float(), stride=stride, padding=1)
+    yr.backward(dy.float().reshape(Nimg, OH, OH, Cout).permute(0, 3, 1, 2))
+    ref, dref = yr.detach().permute(0, 2, 3, 1).reshape(M, Cout), xr.grad.permute(0, 2, 3, 1).reshape(MI, Cin)
+    W = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+    Wb = Wt.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous().to(d)
+
+    def isolated(t):
+        torch.cuda.empty_cache()
+        seg = torch.empty(24 << 20, dtype=torch.uint8, device=d)          # > 10 MB: a segment of exactly this size is mapped for it
+        nb = t.numel() * 2
+        v = (seg[:nb] if where == "segment start" else seg[seg.numel() - nb:]).view(adt).view(t.shape)
+        v.copy_(t)
+        return seg, v
+
+    seg, xd = isolated(x)
+    y = torch.full((M, Cout), float("nan"), device=d, dtype=adt)
+    for _ in range(10):
+        ops.gemm_nt(xd, W, y, M, Cout, 9 * Cin, rows=ops.rows_conv(H, H, Cin, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_FWD)
+    torch.cuda.synchronize()
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) < 4e-3
+    del xd, seg
+    seg, dyd = isolated(dy)
+    dx = torch.full((MI, Cin), float("nan"), device=d, dtype=adt)
+    for _ in range(10):
+        ops.gemm_nt(dyd, Wb, dx, MI, Cin, 9 * Cout, rows=ops.rows_conv(H, H, Cout, 3, 3, stride, 1, OH, OH), mode=ROWS_CONV_BWD)
+    torch.cuda.synchronize()
+    assert float((dx.float().cpu() - dref).norm() / dref.norm()) < 4e-3
 
 
 def test_plain_product_register_direct_epilogue(tmp_path):
