@@ -884,7 +884,10 @@ class AttentionModuleFn(torch.autograd.Function):
             if doo is None:
                 doo = grad_prep(dy, M, D, drop_p=drop_p, sid=sid)
         linear_bwd_weight(doo, o, wo, Mp, bias=bo)
-        do = linear_bwd_input(doo, wo, Mp, out_f32=False)
+        # dV = P^T dO reads dO per head in whole 16-byte chunks (gemm_tn_batched: J = d rounded up to the vector width): for head widths that are not a multiple of it
+        # (d = 45, 90) the last head's last chunk ends up to 12 bytes behind the row -- behind the TENSOR in its last row: 16 readable bytes follow it
+        do = torch.empty(Mp * D + 8, dtype=adt, device=dy.device)[:Mp * D].view(Mp, D)
+        do = linear_bwd_input(doo, wo, Mp, out_f32=False, out=do)
         dqkv = empty((Mp, 3 * D), adt, dy)
         pg, pgi = ctx.pos_group
         if pg is not None:

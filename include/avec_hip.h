@@ -138,6 +138,9 @@ int avec_gemm_tn_grouped_ok(int dtype, const avec_tn_item_t* item);
 int avec_gemm_tn_grouped(int dtype, const avec_tn_item_t* items, int n, hipStream_t stream);
 int avec_gemm_tn_batched(int dtype, const void* P, long long ldp, const void* Q, long long ldq, float* O, long long ldo, long long M, int I, int J,
                          int nb_outer, int nb_inner, const long long* strides6, hipStream_t stream);
+/* (batched: as above, rows of P / Q are read in whole 16-byte chunks up to the next multiple of the vector width -- 8 bf16 / 4 fp32 elements -- of I / J, counted from the
+ * batch's first column; with batches laid side by side in a row (attention heads of width 45 or 90) the last batch's last chunk of the LAST row ends up to 12 bytes behind the
+ * operand: the caller keeps 16 bytes readable there) */
 /* the same products STORED in the activation dtype (one workgroup per tile reduces over all M rows: no split, no atomics, no zero-filled fp32 staging):
  * dK and dV of the attention backward go straight into the Q|K|V gradient matrix */
 int avec_gemm_tn_batched_store(int dtype, const void* P, long long ldp, const void* Q, long long ldq, void* O_act, long long ldo, long long M, int I, int J,

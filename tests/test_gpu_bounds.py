@@ -1,0 +1,26 @@
+"""Every kernel of a training step keeps its reads and writes inside its operands (GPU).
+
+tools/guard/guard_alloc.cpp is a PyTorch pluggable allocator that gives each tensor its own virtual range with unmapped memory on both sides (hipMemAddressReserve / hipMemMap),
+flush against the END of the mapped part (tail) or its START (head): a kernel that reaches past that side of any tensor takes a GPU memory fault and the process aborts.
+tools/guard/guard_pass.py runs one eager training step (forward, backward, Adam) of the audio-visual model on it.  Round 6 found two over-reads this way / by its manual
+precursor: the stride-2 convolution's class-window gather (csrc/conv_s2.hip clamp) and dV = P^T dO of the attention backward for head widths 45 / 90 (16-byte chunks of the
+last head: dO now has 16 readable bytes behind it, include/avec_hip.h states the contract)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode", ["tail", "head"])
+@pytest.mark.parametrize("cfg", [["--batch", "2", "--dtype", "bf16"], ["--batch", "3", "--dtype", "f32"], ["--batch", "1", "--dtype", "bf16", "--dist"]],
+                         ids=["bf16, two utterances", "fp32, three utterances", "bf16, one utterance, one-rank data-parallel paths"])
+def test_training_step_on_the_guard_page_allocator(mode, cfg):
+    env = dict(os.environ, GUARD_MODE=mode, GUARD_GAP_MB="16", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard", "guard_pass.py")] + cfg, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "GUARD PASS OK mode=%s" % mode in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    n = int(r.stdout.split("allocations=")[1].split()[0])
+    assert n > 1500, r.stdout      # the step really allocated through the guard allocator

@@ -1,0 +1,57 @@
+// Guard-page allocator for PyTorch (torch.cuda.memory.CUDAPluggableAllocator): test infrastructure, not part of the product.
+// Every allocation gets its own virtual range with an UNMAPPED granule on both sides (hipMemAddressReserve / hipMemCreate / hipMemMap); the block sits flush against the end
+// (GUARD_MODE=tail, default) or the start (GUARD_MODE=head) of the mapped part, so a kernel that reads or writes past that side of a tensor takes a memory fault instead of
+// silently touching a neighbour.  tests/test_gpu_bounds.py runs a whole training pass on it.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+struct Rec { char* va; size_t va_size; size_t map_size; hipMemGenericAllocationHandle_t h; };
+static std::map<void*, Rec> g_live;
+static std::mutex g_mu;
+static size_t g_gran = 0, g_gap = 0;      // g_gap: unmapped bytes on each side of a block (GUARD_GAP_MB, default one granule)
+static long long g_count = 0, g_bytes = 0;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "guard_alloc: %s failed: %s\n", #x, hipGetErrorString(e_)); abort(); } } while (0)
+
+extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
+  if (size <= 0) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  CK(hipSetDevice(device));
+  hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+  if (!g_gran) {
+    CK(hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum));
+    const char* gm = getenv("GUARD_GAP_MB"); g_gap = gm ? (size_t)atoi(gm) << 20 : g_gran; g_gap = (g_gap + g_gran - 1) / g_gran * g_gran;
+  }
+  const size_t msz = ((size_t)size + g_gran - 1) / g_gran * g_gran, vsz = msz + 2 * g_gap;
+  Rec r; void* va = nullptr;
+  CK(hipMemAddressReserve(&va, vsz, g_gran, nullptr, 0));
+  r.va = (char*)va; r.va_size = vsz; r.map_size = msz;
+  CK(hipMemCreate(&r.h, msz, &prop, 0));
+  CK(hipMemMap(r.va + g_gap, msz, 0, r.h, 0));
+  hipMemAccessDesc d; memset(&d, 0, sizeof(d)); d.location = prop.location; d.flags = hipMemAccessFlagsProtReadWrite;
+  CK(hipMemSetAccess(r.va + g_gap, msz, &d, 1));
+  const char* mode = getenv("GUARD_MODE");
+  const size_t align = (size_t)size >= (1u << 20) ? 256 : 16;          // (the library asks for 256-byte aligned workspaces; everything else needs 16)
+  const size_t sz_al = ((size_t)size + align - 1) / align * align;
+  char* p = (mode && !strcmp(mode, "head")) ? r.va + g_gap : r.va + g_gap + msz - sz_al;
+  g_live[p] = r; ++g_count; g_bytes += (long long)msz;
+  return p;
+}
+extern "C" void guard_free(void* ptr, ssize_t, int device, hipStream_t) {
+  if (!ptr) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_live.find(ptr);
+  if (it == g_live.end()) { fprintf(stderr, "guard_alloc: free of unknown pointer %p\n", ptr); abort(); }
+  CK(hipSetDevice(device));
+  CK(hipDeviceSynchronize());                     // the tensor died on the host; work that uses it may still be queued on any stream
+  Rec r = it->second; g_live.erase(it);
+  CK(hipMemUnmap(r.va + g_gap, r.map_size));
+  CK(hipMemRelease(r.h));
+  CK(hipMemAddressFree(r.va, r.va_size));
+}
+extern "C" long long guard_stats(int what) { return what == 0 ? g_count : what == 1 ? g_bytes : (long long)g_gran; }

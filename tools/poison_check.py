@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--dist", action="store_true")
+    ap.add_argument("--noise", action="store_true", help="keep dropout and SpecAugment on (same masks in every pass: the RNG step is rewound)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -35,14 +36,16 @@ def main():
     avec_amd.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
     model = nnet.AudioVisualEfficientConformerInterCTC()
-    for m in model.modules():
+    for m in (model.modules() if not args.noise else []):
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
         if hasattr(m, "drop_rate"):
             m.drop_rate = 0.0
     model.compile(losses=nnet.CTCLoss(zero_infinity=True, assert_shorter=False))
     model = model.to(dev).train()
-    model.encoder.audio_encoder.spec_augment.eval()
+    if not args.noise:
+        model.encoder.audio_encoder.spec_augment.eval()
+    from avec_amd import runtime as rt
     if args.dist:
         model.distribute_strategy(0)
     B = args.batch
@@ -55,6 +58,7 @@ def main():
     ref = None
     for name, val in (("zero", 0.0), ("nan", float("nan")), ("1e30", 1e30), ("-3e4", -3e4), ("nan again", float("nan"))):
         model.arena.grad.zero_()
+        rt.rng_state(dev)[1] = 0
         poison(dev, val)
         if args.dist:
             model.arena.arm_early_all_reduce(True)
