@@ -20,7 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                          ids=["bf16, two utterances", "fp32, three utterances", "bf16, one utterance, one-rank data-parallel paths"])
 def test_training_step_on_the_guard_page_allocator(mode, cfg):
     env = dict(os.environ, GUARD_MODE=mode, GUARD_GAP_MB="16", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard", "guard_pass.py")] + cfg, env=env, capture_output=True, text=True, timeout=900)
+    for attempt in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard", "guard_pass.py")] + cfg, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode == 0 or "Memory access fault" in r.stderr or attempt == 2:
+            break                 # (a fault is the finding; anything else -- the virtual-memory calls of the allocator itself failing -- gets one more try)
     assert r.returncode == 0 and "GUARD PASS OK mode=%s" % mode in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     n = int(r.stdout.split("allocations=")[1].split()[0])
     assert n > 1500, r.stdout      # the step really allocated through the guard allocator
