@@ -27,3 +27,27 @@ def test_training_step_on_the_guard_page_allocator(mode, cfg):
     assert r.returncode == 0 and "GUARD PASS OK mode=%s" % mode in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     n = int(r.stdout.split("allocations=")[1].split()[0])
     assert n > 1500, r.stdout      # the step really allocated through the guard allocator
+
+
+def _losses(stdout):
+    import re
+    return [float(x) for x in re.findall(r"(?:step \d+|eval) loss ([-0-9.eE+naif]+)", stdout)]
+
+
+@pytest.mark.parametrize("cfg,tol", [(["--batch", "2", "--dtype", "f32", "--eval"], 1e-5), (["--batch", "3", "--dtype", "bf16", "--dist", "--eval"], 2e-3)],
+                         ids=["fp32, train step + evaluation step", "bf16, one-rank data-parallel paths, train step + evaluation step"])
+def test_results_do_not_depend_on_memory_nobody_wrote(cfg, tol):
+    """GUARD_MODE=plain: one hipMalloc per tensor, every new block filled with 0xFF (NaN in fp32 / bf16, -1 in integers) before it is handed out -- no block ever comes back with
+    the plausible contents of an earlier tensor, which is what makes a read of unwritten memory repeat bit for bit on the caching allocator.  The losses of a training step and of
+    the evaluation step after it (i.e. after the Adam update) must equal those of the same pass on zero-filled blocks.
+    (The guard-page mode above cannot serve for this: on hipMemCreate memory plain stores of ANY kernel -- torch's own included -- get lost run to run on this stack, so only its
+    memory faults are evidence; profiles/r06_notes.txt.)"""
+    out = {}
+    for fill in ("0", "255"):
+        env = dict(os.environ, GUARD_MODE="plain", GUARD_FILL=fill, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard", "guard_pass.py")] + cfg, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "GUARD PASS OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        out[fill] = _losses(r.stdout)
+    assert len(out["0"]) == 2 and len(out["255"]) == 2, out
+    for a, b in zip(out["0"], out["255"]):
+        assert a == a and b == b and abs(a - b) <= tol * abs(a), out

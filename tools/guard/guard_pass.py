@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--dist", action="store_true")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--no-guard", action="store_true")
+    ap.add_argument("--eval", action="store_true", help="after the training steps: one evaluation step (eval-mode BatchNorm, greedy CTC decoding of the outputs)")
     args = ap.parse_args()
     so = os.path.join(HERE, "libguard_alloc.so")
     if not args.no_guard:
@@ -85,6 +86,11 @@ def main():
         losses, _, _ = model.train_step(inputs, targets, precision=precision)          # eager: forward, backward, (all-reduce,) Adam
         torch.cuda.synchronize()
         print("step %d loss %.6f" % (step, float(losses["loss"])), flush=True)
+    if args.eval:
+        model.eval()
+        losses, metrics, truths, preds = model.eval_step(inputs, targets)
+        torch.cuda.synchronize()
+        print("eval loss %.6f, %d hypotheses" % (float(losses["loss"]), len(preds) if preds is not None else 0), flush=True)
     if not args.no_guard:
         import ctypes
         lib = ctypes.CDLL(so)
