@@ -35,3 +35,15 @@ def test_asm_load_kernels_do_not_spill(src, tmp_path):
     assert hit, "none of %r found in the resource report of %s" % (GUARDED[src], src)
     bad = {k: v for k, v in hit.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)}
     assert not bad, "inline-asm load kernels must not spill (their vmcnt waits are hand-counted): %r" % bad
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_guard_page_allocator_builds_and_exports_the_pluggable_allocator_entry_points(tmp_path):
+    """tools/guard/guard_alloc.cpp (test infrastructure of tests/test_gpu_bounds.py): compiles here without a GPU and exports what torch.cuda.memory.CUDAPluggableAllocator binds"""
+    import ctypes
+    so = str(tmp_path / "libguard_alloc.so")
+    r = subprocess.run(["hipcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "guard", "guard_alloc.cpp")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dll = ctypes.CDLL(so)
+    for name in ("guard_malloc", "guard_free", "guard_stats"):
+        assert hasattr(dll, name), name
