@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("mode", ["tail", "head"])
-@pytest.mark.parametrize("cfg", [["--batch", "2", "--dtype", "bf16"], ["--batch", "3", "--dtype", "f32"], ["--batch", "1", "--dtype", "bf16", "--dist"]],
-                         ids=["bf16, two utterances", "fp32, three utterances", "bf16, one utterance, one-rank data-parallel paths"])
+@pytest.mark.parametrize("cfg", [["--batch", "2", "--dtype", "bf16"], ["--batch", "3", "--dtype", "f32"], ["--batch", "1", "--dtype", "bf16", "--dist"],
+                                 ["--batch", "3", "--dtype", "bf16", "--frames", "29"]],
+                         ids=["bf16, two utterances", "fp32, three utterances", "bf16, one utterance, one-rank data-parallel paths", "bf16, three ragged utterances of up to 29 frames"])
 def test_training_step_on_the_guard_page_allocator(mode, cfg):
     env = dict(os.environ, GUARD_MODE=mode, GUARD_GAP_MB="16", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
     for attempt in (1, 2):

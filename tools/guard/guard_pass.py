@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--dist", action="store_true")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--no-guard", action="store_true")
+    ap.add_argument("--frames", type=int, default=20, help="video frames per utterance (audio: 640 samples per frame minus a ragged tail)")
     ap.add_argument("--eval", action="store_true", help="after the training steps: one evaluation step (eval-mode BatchNorm, greedy CTC decoding of the outputs)")
     args = ap.parse_args()
     so = os.path.join(HERE, "libguard_alloc.so")
@@ -76,9 +77,13 @@ def main():
             px.all_reduce_sum_fused = checked
     B = args.batch
     g = torch.Generator().manual_seed(5)
-    video, audio = torch.randn(B, 20, 88, 88, 1, generator=g), 0.1 * torch.randn(B, 12160, generator=g)
-    vlen, alen = torch.tensor(([20, 17, 20, 11] * B)[:B]), torch.tensor(([12160, 10000, 12160, 7000] * B)[:B])
-    labels, llen = torch.randint(1, 256, (B, 4), generator=g), torch.tensor(([4, 3, 4, 2] * B)[:B])
+    T = args.frames
+    L = 12160 if T == 20 else T * 640 - 160         # 20 frames <-> 12160 samples as everywhere in the tests; 100 frames <-> 63 840 samples as in bench.py
+    video, audio = torch.randn(B, T, 88, 88, 1, generator=g), 0.1 * torch.randn(B, L, generator=g)
+    vlen = torch.tensor(([T, max(T - 3, 1), T, max(T - 9, 1)] * B)[:B])
+    alen = torch.tensor(([L, max(L - 2160, 400), L, max(L - 5160, 400)] * B)[:B])
+    nl = max(2, min(4, T // 6))
+    labels, llen = torch.randint(1, 256, (B, nl), generator=g), torch.tensor(([nl, nl - 1, nl, max(nl - 2, 1)] * B)[:B])
     inputs = [t.to(dev) for t in (video, vlen, audio, alen)]
     targets = (labels.to(dev), llen.to(dev))
     precision = torch.bfloat16 if args.dtype == "bf16" else torch.float32
